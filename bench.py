@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""Headline benchmark: TT-embedding lookups/sec on the ogbn-products configuration
+(BASELINE.json configs[1]: p=[125,140,140], q=[4,5,5], r=[16,16], batch 2048).
+
+A "step" is one pass of the hot path over one mini-batch: TTEmbeddingBag.forward on the
+batch's frontier ids plus its backward with the SGD update of the TT cores -- what
+sage_dgl_partition.py:train() makes the layer do per iteration.  The frontier of a
+2048-seed batch with fan-out [5,10,15] is 10^5..10^6 unique ids; the
+workload uses 409 600 = 2048 x 200 unique uniform ids, bag length 1, as DGL delivers them.
+
+  python bench.py --gpus 1 --steps 50 --warmup 10
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1 is data parallel (weak scaling): every rank looks up its own batch, the flattened
+core gradients are summed with one RCCL all-reduce, then the fused SGD epilogue runs.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "falcon-ttdforgnns_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+P, Q, RANKS, N_EMB, D = [125, 140, 140], [4, 5, 5], [16, 16], 2449029, 100
+F0 = 2 * Q[0] * RANKS[0] * Q[1] * RANKS[1]          # stage-1 GEMM flops per lookup
+F1 = 2 * Q[0] * Q[1] * RANKS[1] * Q[2]              # stage-2 GEMM flops per lookup
+FWD_FLOPS, BWD_FLOPS = F0 + F1, 3 * F0 + 2 * F1     # 13 440 / 37 120
+PEAK_F32_MFMA_TFLOPS = 157.3                        # MI355X_MICROARCH.md, chip-level parameters
+PEAK_HBM_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--ids", type=int, default=409600, help="frontier ids per step per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--path", default="auto", choices=["auto", "generic", "fast3"])
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a ROCm device (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    import ttemb_native as nat
+    from FBTT.tt_embeddings_ops import TTEmbeddingBag
+    from ttemb_dist import TTDataParallel
+    nat.set_path({"auto": nat.PATH_AUTO, "generic": nat.PATH_GENERIC, "fast3": nat.PATH_FAST3}[args.path])
+
+    torch.manual_seed(1234)
+    N = args.ids
+    emb = TTEmbeddingBag(N_EMB, D, RANKS, P, Q, sparse=(world == 1), use_cache=False, weight_dist="normal",
+                         learning_rate=0.01, batch_count=N)
+    dp = TTDataParallel(emb) if world > 1 else None
+    if dp is not None:
+        dp.broadcast_parameters(0)
+    rng = np.random.default_rng(2 + rank)
+    n_sets = 4  # rotate a few frontiers so that no step re-reads the previous step's ids
+    id_sets = [torch.from_numpy(rng.choice(N_EMB, size=N, replace=False).astype(np.int64)).cuda()
+               for _ in range(n_sets)]
+    offsets = torch.arange(N + 1, dtype=torch.int64, device="cuda")
+    d_out = ((torch.rand(N, D, device="cuda") - 0.5) * 0.1)
+
+    def step(i):
+        out = emb(id_sets[i % n_sets], offsets)
+        out.backward(d_out)
+        if dp is not None:
+            dp.step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    value = world * N * args.steps / elapsed
+
+    result = None
+    if rank == 0:
+        # roofline leg: the chain kernels bracketed by HIP events on their own stream
+        nat.profile_enable(True)
+        fwd_ms, bwd_ms = [], []
+        for i in range(10):
+            step(i)
+            fwd_ms.append(nat.profile_read(0))
+            bwd_ms.append(nat.profile_read(1))
+        nat.profile_enable(False)
+        fwd, bwd = float(np.mean(fwd_ms)), float(np.mean(bwd_ms))
+        dom_name, dom_ms, dom_flops = ("tt_backward_chain", bwd, BWD_FLOPS) if bwd >= fwd else \
+                                      ("tt_forward_chain", fwd, FWD_FLOPS)
+        achieved = N * dom_flops / (dom_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 3),
+                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "kernel_ms": round(dom_ms, 4), "flops_per_lookup": dom_flops,
+                    "fwd_kernel_ms": round(fwd, 4), "bwd_kernel_ms": round(bwd, 4),
+                    "fwd_achieved_tflops": round(N * FWD_FLOPS / (fwd * 1e-3) / 1e12, 3),
+                    "fwd_output_gbs": round(N * (8 + 4 * D) / (fwd * 1e-3) / 1e9, 1),
+                    "peak_hbm_gbs": PEAK_HBM_GBS}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import cpu_einsum
+            n_cpu = 65536
+            r = cpu_einsum.time_baseline(P, Q, [1] + RANKS + [1], n_cpu, N_EMB, seed=1234, budget_s=12.0)
+            cpu = {"value": round(r["lookups_per_s"], 1), "unit": "lookups/s", "cores": r["threads"],
+                   "kind": "port",
+                   "sample": f"{r['iters']} fwd+bwd+SGD steps of {n_cpu} unique uniform ids "
+                             f"(torch index_select+einsum, fp32, {r['seconds']:.1f} s)"}
+        result = {
+            "metric": "tt_embedding_lookups_per_sec", "value": round(value, 1), "unit": "lookups/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "ogbn-products TTEmbeddingBag fwd+bwd+SGD per step, frontier of a "
+                                   "2048-seed batch = 409600 unique uniform ids per GPU, bag length 1",
+                       "p": P, "q": Q, "tt_ranks": RANKS, "num_embeddings": N_EMB, "ids_per_gpu_step": N,
+                       "parallelism": f"dp{world}", "kernel_path": args.path},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

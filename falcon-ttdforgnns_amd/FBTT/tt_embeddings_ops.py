@@ -1,0 +1,437 @@
+"""MI355X-native Tensor-Train embedding bag -- drop-in for the reference's
+``FBTT.tt_embeddings_ops`` (same import path, class names, constructor arguments,
+attributes and state_dict keys; reference: FBTT/tt_embeddings_ops.py:432-965).
+
+What differs is everything underneath: the lookups, gradients, optimiser epilogues
+and the LFU row cache run in ``libttemb_hip.so`` (hand-written HIP for gfx950,
+C ABI in ``include/ttemb.h``) through ``ttemb_native``.  There is no
+``batch_count`` chunking (the argument is accepted and ignored: partial products
+never leave the chip), and no host synchronisation in ``forward`` -- the split
+between TT-computed and cached ids stays on the device.
+
+No CPU fallback exists: modules can be *constructed* without a GPU (so that shape
+logic, initialisers and checkpoints can be exercised anywhere) but ``forward`` on
+CPU tensors raises ``RuntimeError``.
+"""
+from __future__ import annotations
+
+import logging
+import math
+from enum import Enum, unique
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+from torch import nn
+
+import ttemb_native as _nat
+
+__all__ = ["OptimType", "BufferList", "tt_matrix_to_full", "suggested_tt_shapes", "TTLookupFunction",
+           "TableBatchedTTEmbeddingBag", "TTEmbeddingBag"]
+
+_LOG = logging.getLogger(__name__)
+
+
+@unique
+class OptimType(Enum):
+    """Optimiser selector; value strings match the reference (tt_embeddings_ops.py:18-33).
+    SGD / EXACT_SGD run the fused in-backward SGD; everything else runs fused Adagrad,
+    exactly as the reference dispatches (:229-286)."""
+    SGD = "sgd"
+    EXACT_SGD = "exact_sgd"
+    LAMB = "lamb"
+    ADAM = "adam"
+    EXACT_ADAGRAD = "exact_adagrad"
+    EXACT_ROWWISE_ADAGRAD = "exact_row_wise_adagrad"
+    LARS_SGD = "lars_sgd"
+    PARTIAL_ROWWISE_ADAM = "partial_row_wise_adam"
+    PARTIAL_ROWWISE_LAMB = "partial_row_wise_lamb"
+
+    def __str__(self) -> str:
+        return self.value
+
+
+_SGD_LIKE = (OptimType.SGD, OptimType.EXACT_SGD)
+
+
+class BufferList(nn.Module):
+    """Ordered list of registered buffers named ``<name>0, <name>1, ...`` so that
+    state_dict keys read ``optimizer_state.optimizer_state0`` like the reference's
+    (tt_embeddings_ops.py:36-77)."""
+
+    def __init__(self, name: str, buffers: Optional[Sequence[torch.Tensor]] = None) -> None:
+        super().__init__()
+        self._name = name
+        self._length = 0
+        for b in buffers or ():
+            self.append(b)
+
+    def append(self, buffer: torch.Tensor) -> "BufferList":
+        self.register_buffer(f"{self._name}{self._length}", buffer)
+        self._length += 1
+        return self
+
+    def extend(self, buffers: Sequence[torch.Tensor]) -> "BufferList":
+        for b in buffers:
+            self.append(b)
+        return self
+
+    def __len__(self) -> int:
+        return self._length
+
+    def __getitem__(self, index: int) -> torch.Tensor:
+        if not -self._length <= index < self._length:
+            raise IndexError(index)
+        return getattr(self, f"{self._name}{index % self._length}")
+
+    def __iter__(self):
+        return (self[i] for i in range(self._length))
+
+
+def _pad_ranks(tt_ranks: Sequence[int], T: int) -> List[int]:
+    r = [int(x) for x in tt_ranks]
+    return [1] + r + [1] if len(r) == T - 1 else r
+
+
+def tt_matrix_to_full(tt_p_shapes: Sequence[int], tt_q_shapes: Sequence[int], tt_ranks: Sequence[int],
+                      tt_cores: Sequence[torch.Tensor],
+                      tt_permute: Optional[Sequence[int]] = None) -> torch.Tensor:
+    """Dense ``[prod(p), prod(q)]`` table of a TT matrix (differentiable, any device).
+
+    Same contract as the reference helper (tt_embeddings_ops.py:80-127): with
+    ``tt_permute=[1, 0, 2, 3]`` core ``t`` is stored ``[p_t, R_t, q_t, R_{t+1}]``
+    (the layer's layout); with ``None`` cores are already ``[R_t, p_t, q_t, R_{t+1}]``.
+    """
+    T = len(tt_p_shapes)
+    R = _pad_ranks(tt_ranks, T)
+    table = None
+    for t, core in enumerate(tt_cores):
+        dims = [R[t], int(tt_p_shapes[t]), int(tt_q_shapes[t]), R[t + 1]]
+        if tt_permute is not None:
+            stored = [dims[a] for a in tt_permute]
+            g = core.reshape(stored).permute(*tt_permute)
+        else:
+            g = core.reshape(dims)
+        # table: [P, Q, R_t] ; g: [R_t, p, q, R_{t+1}]  ->  [P, p, Q, q, R_{t+1}]
+        if table is None:
+            table = g.reshape(dims[1], dims[2], dims[3])
+        else:
+            P, Q = table.shape[0], table.shape[1]
+            nxt = torch.tensordot(table, g, dims=([2], [0]))  # [P, Q, p, q, R]
+            table = nxt.permute(0, 2, 1, 3, 4).reshape(P * dims[1], Q * dims[2], dims[3])
+    return table.reshape(table.shape[0], table.shape[1]).float()
+
+
+# --------------------------------------------------------------------------------------
+# shape suggestion (reference: tt_embeddings_ops.py:369-429; sympy-free re-derivation)
+# --------------------------------------------------------------------------------------
+def _prime_factors(n: int) -> List[int]:
+    out, f = [], 2
+    while f * f <= n:
+        while n % f == 0:
+            out.append(f)
+            n //= f
+        f += 1 if f == 2 else 2
+    if n > 1:
+        out.append(n)
+    return out
+
+
+def _unordered_factorisations(n: int, d: int, lo: int = 2):
+    """All non-decreasing d-tuples of integers >= lo with product n."""
+    if d == 1:
+        if n >= lo:
+            yield (n,)
+        return
+    f = lo
+    while f ** d <= n:
+        if n % f == 0:
+            for rest in _unordered_factorisations(n // f, d - 1, f):
+                yield (f,) + rest
+        f += 1
+
+
+def _shape_entropy(factors: Sequence[int]) -> float:
+    tot = float(sum(factors))
+    return -sum((f / tot) * math.log(f / tot) for f in factors)
+
+
+def _interleave(sorted_factors: Sequence[int]) -> List[int]:
+    half = len(sorted_factors) // 2
+    lo, hi = list(sorted_factors[:half]), list(sorted_factors[half:])
+    out = []
+    for i in range(len(hi)):
+        if i < len(lo):
+            out.append(lo[i])
+        out.append(hi[i])
+    return out
+
+
+def _most_even_shape(n: int, d: int) -> List[int]:
+    primes = _prime_factors(n)
+    if len(primes) <= d:
+        cands = [tuple(sorted(primes + [1] * (d - len(primes))))]
+    else:
+        cands = sorted(set(_unordered_factorisations(n, d)))
+    best = max(cands, key=_shape_entropy)
+    return _interleave(best)
+
+
+def suggested_tt_shapes(n: int, d: int = 3, allow_round_up: bool = True) -> List[int]:
+    """Factor ``n`` (optionally rounded up to a multiple of a power of ten) into ``d``
+    factors that are as even as possible (maximum entropy of the normalised factors)."""
+    n = int(n)
+    if not allow_round_up:
+        return _most_even_shape(n, d)
+    best, best_h = None, -1.0
+    for k in range(len(str(n))):
+        step = 10 ** k
+        shape = _most_even_shape(-(-n // step) * step, d)
+        h = _shape_entropy(shape)
+        if h > best_h + 1e-15:
+            best, best_h = shape, h
+    return best
+
+
+# --------------------------------------------------------------------------------------
+# autograd bridge
+# --------------------------------------------------------------------------------------
+class TTLookupFunction(torch.autograd.Function):
+    """forward = TT rows (+ cached rows) bag-summed; backward = fused optimiser step
+    (``sparse``) or dense core gradients.  Reference: tt_embeddings_ops.py:130-366."""
+
+    @staticmethod
+    def forward(ctx, module: "TableBatchedTTEmbeddingBag", table: int, B: int, indices: torch.Tensor,
+                rowidx: torch.Tensor, offsets: Optional[torch.Tensor], nnz_dev: Optional[torch.Tensor],
+                cache_loc: Optional[torch.Tensor], cache_weight: Optional[torch.Tensor],
+                *tt_cores: torch.Tensor) -> torch.Tensor:
+        ctx.module, ctx.table, ctx.B = module, table, B
+        ctx.live_cache = cache_loc is not None
+        ctx.save_for_backward(indices, rowidx, nnz_dev, cache_loc)
+        cores = _nat.core_views(tt_cores, table)
+        nnz = indices.numel()
+        out = torch.empty((B, module.embedding_dim), dtype=torch.float32, device=indices.device)
+        _nat.forward(module._shape, cores, indices, rowidx, offsets, nnz, nnz_dev, B, out, module._ws)
+        if ctx.live_cache and nnz > 0:
+            _nat.cache_forward(cache_loc, rowidx, 0, nnz_dev, nnz, cache_weight.data, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_output: torch.Tensor):
+        m, table, B = ctx.module, ctx.table, ctx.B
+        indices, rowidx, nnz_dev, cache_loc = ctx.saved_tensors
+        nnz = indices.numel()
+        d_output = d_output.contiguous().float()
+        cores = _nat.core_views(m.tt_cores, table)
+        n_fixed = 9
+        if m.sparse:
+            if m.optimizer in _SGD_LIKE:
+                _nat.backward_sgd(m._shape, cores, indices, rowidx, nnz, nnz_dev, B, d_output,
+                                  float(m.learning_rate), m._ws)
+                if ctx.live_cache and nnz > 0:
+                    _nat.cache_backward_sgd(cache_loc, rowidx, 0, nnz_dev, nnz, d_output,
+                                            float(m.learning_rate), m.cache_weight.data)
+            else:
+                state = _nat.core_views(list(m.optimizer_state), table)
+                _nat.backward_adagrad(m._shape, cores, state, indices, rowidx, nnz, nnz_dev, B, d_output,
+                                      float(m.learning_rate), float(m.eps), m._ws)
+                if ctx.live_cache and nnz > 0:
+                    _nat.cache_backward_rowwise_adagrad(cache_loc, rowidx, 0, nnz_dev, nnz, d_output,
+                                                        float(m.learning_rate), float(m.eps),
+                                                        m.cache_optimizer_state, m.cache_weight.data)
+            return (None,) * (n_fixed + len(cores))
+        grads = [torch.empty_like(c) for c in cores]
+        _nat.backward_dense(m._shape, cores, indices, rowidx, nnz, nnz_dev, B, d_output, grads, m._ws)
+        d_cache = None
+        if ctx.live_cache:
+            d_cache = torch.empty_like(m.cache_weight.data)
+            _nat.cache_backward_dense(cache_loc, rowidx, 0, nnz_dev, nnz, d_output, d_cache)
+        full = []
+        for t, g in enumerate(grads):
+            if m.num_tables == 1:
+                full.append(g.unsqueeze(0))
+            else:  # only this table's slice of the [num_tables, p, row] parameter gets gradient
+                z = torch.zeros_like(m.tt_cores[t].data)
+                z[table] = g
+                full.append(z)
+        return (None,) * (n_fixed - 1) + (d_cache,) + tuple(full)
+
+
+# --------------------------------------------------------------------------------------
+# the module
+# --------------------------------------------------------------------------------------
+class TableBatchedTTEmbeddingBag(nn.Module):
+    """``num_tables`` TT tables with identical shapes looked up in one call.
+
+    Constructor / attribute contract: reference tt_embeddings_ops.py:446-615.
+    ``forward(indices, offsets)`` returns ``[num_tables, B, D]`` sum-pooled bags with
+    ``include_last_offset`` semantics (``offsets`` has ``num_tables*B + 1`` entries).
+    """
+
+    __constants__ = ["num_tables", "num_embeddings", "embedding_dim", "tt_shape", "tt_rank"]
+
+    def __init__(self, num_tables: int, num_embeddings: int, embedding_dim: int, tt_ranks: List[int],
+                 tt_p_shapes: Optional[List[int]] = None, tt_q_shapes: Optional[List[int]] = None,
+                 optimizer: OptimType = OptimType.SGD, learning_rate: float = 0.1, eps: float = 1.0e-10,
+                 sparse: bool = True, use_cache: bool = False, cache_size: int = 0, hashtbl_size: int = 0,
+                 weight_dist: str = "approx-normal", enforce_embedding_dim: bool = False,
+                 batch_count: int = 1000) -> None:
+        super().__init__()
+        assert num_tables > 0 and num_embeddings > 0 and embedding_dim > 0
+        assert num_tables == 1 or not use_cache, "cannot use cache when num_tables != 1"
+        T = len(tt_ranks) + 1
+        self.batch_count = batch_count  # accepted for compatibility; the kernels do not chunk
+        self.tt_p_shapes: List[int] = (list(tt_p_shapes) if tt_p_shapes is not None
+                                       else suggested_tt_shapes(num_embeddings, T))
+        self.tt_q_shapes: List[int] = (list(tt_q_shapes) if tt_q_shapes is not None else
+                                       suggested_tt_shapes(embedding_dim, T,
+                                                           allow_round_up=not enforce_embedding_dim))
+        assert 2 <= len(self.tt_p_shapes) <= 4
+        assert len(self.tt_p_shapes) == T and len(self.tt_q_shapes) == T
+        assert all(v > 0 for v in self.tt_p_shapes) and all(v > 0 for v in self.tt_q_shapes)
+        assert all(v > 0 for v in tt_ranks)
+        assert int(np.prod(np.array(self.tt_p_shapes, dtype=np.int64))) >= num_embeddings
+        assert int(np.prod(np.array(self.tt_q_shapes, dtype=np.int64))) == embedding_dim
+        self.num_tables, self.tt_ndim = num_tables, T
+        self.num_embeddings, self.embedding_dim = num_embeddings, embedding_dim
+        self.tt_ranks = [1] + [int(r) for r in tt_ranks] + [1]
+        self.sparse, self.optimizer = sparse, optimizer
+        self.learning_rate, self.eps = learning_rate, eps
+        _LOG.info("TTEmbeddingBag p=%s q=%s R=%s sparse=%s optimizer=%s lr=%s eps=%s cache=%s/%s/%s",
+                  self.tt_p_shapes, self.tt_q_shapes, self.tt_ranks, sparse, optimizer, learning_rate, eps,
+                  use_cache, cache_size, hashtbl_size)
+        dev = (torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available()
+               else torch.device("cpu"))
+        strides = [1] * T
+        for t in range(T - 2, -1, -1):
+            strides[t] = strides[t + 1] * self.tt_p_shapes[t + 1]
+        self.register_buffer("L", torch.tensor(strides, dtype=torch.int64))
+        self.tt_cores = nn.ParameterList()
+        self.optimizer_state = BufferList("optimizer_state")
+        for t in range(T):
+            shape = [num_tables, self.tt_p_shapes[t],
+                     self.tt_ranks[t] * self.tt_q_shapes[t] * self.tt_ranks[t + 1]]
+            self.tt_cores.append(nn.Parameter(torch.empty(shape, device=dev, dtype=torch.float32)))
+            st_shape = shape if optimizer not in _SGD_LIKE else 0
+            self.optimizer_state.append(torch.zeros(st_shape, device=dev, dtype=torch.float32))
+        self.reset_parameters(weight_dist)
+        self.use_cache = use_cache
+        if use_cache:
+            if cache_size <= 0:
+                cache_size = int(0.1 * num_embeddings)
+            if hashtbl_size <= 0:
+                hashtbl_size = num_embeddings
+            assert hashtbl_size >= cache_size
+            self.register_buffer("hashtbl", torch.full((hashtbl_size,), -1, device=dev, dtype=torch.int64))
+            self.register_buffer("cache_freq", torch.zeros(hashtbl_size, device=dev, dtype=torch.int64))
+            self.register_buffer("cache_state", torch.full((hashtbl_size,), -1, device=dev, dtype=torch.int32))
+            self.cache_weight = nn.Parameter(torch.zeros((cache_size, embedding_dim), device=dev,
+                                                         dtype=torch.float32))
+            if sparse and optimizer not in _SGD_LIKE:
+                st = (cache_size, embedding_dim) if optimizer == OptimType.EXACT_ADAGRAD else (cache_size,)
+                self.register_buffer("cache_optimizer_state", torch.zeros(st, device=dev, dtype=torch.float32))
+            else:
+                self.cache_optimizer_state = None
+        else:
+            self.register_buffer("hashtbl", torch.empty(0, device=dev, dtype=torch.int64))
+            self.register_buffer("cache_state", torch.empty(0, device=dev, dtype=torch.int32))
+            self.cache_optimizer_state = None
+            self.cache_weight = None
+        self.warmup = True
+        self._shape = _nat.make_shape(self.tt_p_shapes, self.tt_q_shapes, self.tt_ranks)
+        self._ws = _nat.Workspace()
+
+    # ---- weights ------------------------------------------------------------------
+    def full_weight(self) -> torch.Tensor:
+        assert self.num_tables == 1, "full_weight() only supported for num_tables == 1 for now"
+        return tt_matrix_to_full(self.tt_p_shapes, self.tt_q_shapes, self.tt_ranks,
+                                 list(self.tt_cores), [1, 0, 2, 3])
+
+    def reset_parameters(self, weight_dist: str) -> None:
+        """Initialisers of the reference (tt_embeddings_ops.py:629-808), vectorised."""
+        from ttemb_init import init_cores
+        init_cores(self, weight_dist)
+
+    def set_learning_rate(self, lr: float) -> None:
+        self.learning_rate = lr
+
+    def get_params(self):
+        params = self.tt_cores
+        if self.use_cache:
+            params.append(self.cache_weight)
+        return params
+
+    # ---- cache --------------------------------------------------------------------
+    def reset_cache(self) -> None:
+        """Forget every tracked id (the reference's version is dead code: typo at :811)."""
+        if self.use_cache:
+            self.hashtbl.fill_(-1)
+            self.cache_freq.fill_(0)
+            self.cache_state.fill_(-1)
+            self.warmup = True
+
+    def update_cache(self, indices: torch.Tensor) -> None:
+        if self.use_cache:
+            _nat.cache_update(indices.long().contiguous(), self.hashtbl, self.cache_freq)
+
+    def cache_populate(self) -> None:
+        """Freeze the LFU statistics: the ``cache_size`` hottest ids get their rows
+        materialised in ``cache_weight``; ends the warm-up (reference :816-830)."""
+        if self.use_cache:
+            _nat.cache_populate(self._shape, _nat.core_views(self.tt_cores), self.hashtbl, self.cache_freq,
+                                self.cache_state, self.cache_weight.data, self._ws)
+            self.warmup = False
+
+    # ---- lookup -------------------------------------------------------------------
+    def _lookup_one_table(self, table: int, B: int, indices: torch.Tensor, offsets: torch.Tensor) -> torch.Tensor:
+        nnz = indices.numel()
+        dev = indices.device
+        live = self.use_cache and not self.warmup
+        rowidx = torch.empty(nnz, dtype=torch.int64, device=dev)
+        if not live:
+            _nat.preprocess(indices, offsets, B, True, None, None, None, rowidx, None, None, self._ws)
+            return TTLookupFunction.apply(self, table, B, indices, rowidx, offsets, None, None, None,
+                                          *self.tt_cores)
+        part = torch.empty_like(indices)
+        loc = torch.empty(nnz, dtype=torch.int32, device=dev)
+        nnz_tt = torch.empty(1, dtype=torch.int32, device=dev)
+        _nat.preprocess(indices, offsets, B, False, self.hashtbl, self.cache_state, part, rowidx, loc, nnz_tt,
+                        self._ws)
+        return TTLookupFunction.apply(self, table, B, part, rowidx, None, nnz_tt, loc, self.cache_weight,
+                                      *self.tt_cores)
+
+    def forward(self, indices: torch.Tensor, offsets: torch.Tensor, warmup: bool = True) -> torch.Tensor:
+        # `warmup` is accepted and ignored, like the reference (it reads self.warmup, :862)
+        if not indices.is_cuda:
+            raise RuntimeError("TTEmbeddingBag.forward needs tensors on a ROCm device; there is no CPU fallback")
+        indices, offsets = indices.long().contiguous(), offsets.long().contiguous()
+        assert (offsets.numel() - 1) % self.num_tables == 0
+        B = (offsets.numel() - 1) // self.num_tables
+        self.update_cache(indices)
+        if self.num_tables == 1:
+            return self._lookup_one_table(0, B, indices, offsets).unsqueeze(0)
+        bounds = offsets[:: B].tolist()  # host sync: only the multi-table path pays it
+        outs = []
+        for k in range(self.num_tables):
+            lo, hi = int(bounds[k]), int(bounds[k + 1])
+            offs_k = (offsets[k * B:(k + 1) * B + 1] - lo).contiguous()
+            outs.append(self._lookup_one_table(k, B, indices[lo:hi].contiguous(), offs_k))
+        return torch.stack(outs, 0)
+
+
+class TTEmbeddingBag(TableBatchedTTEmbeddingBag):
+    """TT embedding lookup for exactly one table; ``forward`` returns ``[B, D]``
+    (reference: tt_embeddings_ops.py:918-965)."""
+
+    def __init__(self, num_embeddings: int, embedding_dim: int, tt_ranks: List[int],
+                 tt_p_shapes: Optional[List[int]] = None, tt_q_shapes: Optional[List[int]] = None,
+                 optimizer: OptimType = OptimType.SGD, learning_rate: float = 0.1, eps: float = 1.0e-10,
+                 sparse: bool = True, use_cache: bool = True, cache_size: int = 0, hashtbl_size: int = 0,
+                 weight_dist: str = "approx-normal", enforce_embedding_dim: bool = False,
+                 batch_count: int = 1000) -> None:
+        super().__init__(1, num_embeddings, embedding_dim, tt_ranks, tt_p_shapes, tt_q_shapes, optimizer,
+                         learning_rate, eps, sparse, use_cache, cache_size, hashtbl_size, weight_dist,
+                         enforce_embedding_dim, batch_count)
+
+    def forward(self, indices: torch.Tensor, offsets: torch.Tensor, warmup: bool = True) -> torch.Tensor:
+        return super().forward(indices, offsets, warmup)[0]

@@ -1,0 +1,461 @@
+// extern "C" entry points of libttemb_hip.so (declared in include/ttemb.h).
+// Argument checking, workspace carving and kernel-family dispatch live here; the
+// kernels are in ttemb_generic.hip / ttemb_fast3.hip / ttemb_cache.hip.
+#include "ttemb_common.h"
+#include "ttemb_cache.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+namespace ttemb {
+
+static thread_local char g_err[512] = "";
+static thread_local int g_path = TTEMB_PATH_AUTO;
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int check_hip(hipError_t e, const char* what) {
+  if (e == hipSuccess) return TTEMB_OK;
+  return fail(TTEMB_E_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+int current_path() { return g_path; }
+
+static thread_local bool g_prof_on = false;
+static thread_local hipEvent_t g_prof_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+static thread_local bool g_prof_valid[2] = {false, false};
+
+void profile_begin(int which, hipStream_t st) {
+  if (!g_prof_on) return;
+  for (int i = 0; i < 2; ++i)
+    if (g_prof_ev[which][i] == nullptr && hipEventCreate(&g_prof_ev[which][i]) != hipSuccess) return;
+  g_prof_valid[which] = hipEventRecord(g_prof_ev[which][0], st) == hipSuccess;
+}
+
+void profile_end(int which, hipStream_t st) {
+  if (!g_prof_on || !g_prof_valid[which]) return;
+  g_prof_valid[which] = hipEventRecord(g_prof_ev[which][1], st) == hipSuccess;
+}
+
+int make_dev_shape(const ttemb_shape_t* s, DevShape* out) {
+  if (s == nullptr) return fail(TTEMB_E_BADARG, "shape is null");
+  if (s->T < 2 || s->T > TTEMB_MAX_CORES)
+    return fail(TTEMB_E_BADARG, "T=%d: the layer supports 2..4 cores", s->T);
+  DevShape d;
+  memset(&d, 0, sizeof(d));
+  d.T = s->T;
+  if (s->R[0] != 1 || s->R[s->T] != 1) return fail(TTEMB_E_BADARG, "R[0] and R[T] must be 1");
+  long long D = 1;
+  for (int t = 0; t < s->T; ++t) {
+    if (s->p[t] <= 0 || s->q[t] <= 0 || s->R[t] <= 0 || s->R[t + 1] <= 0)
+      return fail(TTEMB_E_BADARG, "non-positive factor at core %d", t);
+    d.p[t] = s->p[t];
+    d.q[t] = s->q[t];
+    d.R[t] = s->R[t];
+    D *= s->q[t];
+    if (D > (1 << 20)) return fail(TTEMB_E_BADARG, "embedding_dim too large");
+  }
+  d.R[s->T] = 1;
+  if (D % 4 != 0) return fail(TTEMB_E_BADARG, "embedding_dim %lld must be a multiple of 4", D);
+  d.D = (int)D;
+  long long L = 1;
+  for (int t = s->T - 1; t >= 0; --t) {
+    d.L[t] = L;
+    if (L > (1ll << 62) / d.p[t]) return fail(TTEMB_E_BADARG, "prod(p) overflows");
+    L *= d.p[t];
+  }
+  long long Q = 1;
+  int pm = 0;
+  for (int t = 0; t < s->T; ++t) {
+    Q *= d.q[t];
+    long long rl = (long long)d.R[t] * d.q[t] * d.R[t + 1];
+    long long pl = Q * d.R[t + 1];
+    if (rl > (1 << 24) || pl > (1 << 24)) return fail(TTEMB_E_BADARG, "core row too large");
+    d.row_len[t] = (int)rl;
+    d.part_len[t] = (int)pl;
+    if (t + 1 < s->T && d.part_len[t] > pm) pm = d.part_len[t];
+  }
+  d.part_max = pm;
+  *out = d;
+  return TTEMB_OK;
+}
+
+static int64_t grad_scratch_bytes(const DevShape& s) {
+  int64_t b = 0;
+  for (int t = 0; t < s.T; ++t) b += align256((int64_t)s.p[t] * s.row_len[t] * 4);
+  return b;
+}
+
+static bool use_fast3(const DevShape& s) {
+  const int path = current_path();
+  if (path == TTEMB_PATH_GENERIC) return false;
+  return fast3_supported(s);
+}
+
+// rows whose bag length is not 1 must be zero before the lookups accumulate into them
+__global__ void zero_rows_kernel(const int64_t* __restrict__ offsets, int64_t B, int D,
+                                 float* __restrict__ out) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  if (offsets[b + 1] - offsets[b] == 1) return;
+  float4* o = reinterpret_cast<float4*>(out + b * D);
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int c = 0; c * 4 < D; ++c) o[c] = z;
+}
+
+__global__ void sgd_step_kernel(float* __restrict__ w, const float* __restrict__ g, int64_t n, float lr) {
+  int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    float4 wv = *reinterpret_cast<float4*>(w + i);
+    const float4 gv = *reinterpret_cast<const float4*>(g + i);
+    wv.x -= lr * gv.x; wv.y -= lr * gv.y; wv.z -= lr * gv.z; wv.w -= lr * gv.w;
+    *reinterpret_cast<float4*>(w + i) = wv;
+  } else {
+    for (; i < n; ++i) w[i] -= lr * g[i];
+  }
+}
+
+__global__ void adagrad_step_kernel(float* __restrict__ w, float* __restrict__ st,
+                                    const float* __restrict__ g, int64_t n, float lr, float eps) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gv = g[i];
+  const float s2 = st[i] + gv * gv;
+  st[i] = s2;
+  w[i] -= lr * gv / (sqrtf(s2) + eps);
+}
+
+static int run_sgd(float* w, const float* g, int64_t n, float lr, hipStream_t st) {
+  if (n <= 0) return TTEMB_OK;
+  if ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(g)) & 15)
+    return fail(TTEMB_E_BADARG, "sgd_step: buffers must be 16-byte aligned");
+  const int threads = 256;
+  const int64_t blocks = ((n + 3) / 4 + threads - 1) / threads;
+  hipLaunchKernelGGL(sgd_step_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, w, g, n, lr);
+  return check_hip(hipGetLastError(), "sgd_step_kernel");
+}
+
+static int run_adagrad(float* w, float* state, const float* g, int64_t n, float lr, float eps, hipStream_t st) {
+  if (n <= 0) return TTEMB_OK;
+  const int threads = 256;
+  const int64_t blocks = (n + threads - 1) / threads;
+  hipLaunchKernelGGL(adagrad_step_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, w, state, g, n, lr, eps);
+  return check_hip(hipGetLastError(), "adagrad_step_kernel");
+}
+
+static int check_lookup_args(const void* cores, const void* indices, int64_t nnz, int64_t B) {
+  if (nnz < 0 || B < 0) return fail(TTEMB_E_BADARG, "negative size (nnz=%lld, B=%lld)", (long long)nnz, (long long)B);
+  if (nnz > 0x7fffffffll) return fail(TTEMB_E_BADARG, "nnz=%lld exceeds int32 range", (long long)nnz);
+  if (cores == nullptr) return fail(TTEMB_E_BADARG, "cores is null");
+  if (nnz > 0 && indices == nullptr) return fail(TTEMB_E_BADARG, "indices is null");
+  return TTEMB_OK;
+}
+
+// shared body of the three backward entry points: gradient of the live ids into `dst`
+static int backward_into(const DevShape& ds, const CorePtrs& cp, const int64_t* indices,
+                         const int64_t* rowidx, int64_t nnz, const int32_t* nnz_dev,
+                         const float* d_output, const CorePtrsMut& dst, void* ws, int64_t ws_bytes,
+                         hipStream_t st) {
+  if (use_fast3(ds))
+    return launch_backward_fast3(ds, cp, indices, rowidx, nnz, nnz_dev, d_output, dst, ws, ws_bytes, st);
+  if (current_path() == TTEMB_PATH_FAST3) return fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
+  for (int t = 0; t < ds.T; ++t) {
+    int rc = check_hip(hipMemsetAsync(dst.c[t], 0, (size_t)ds.p[t] * ds.row_len[t] * 4, st), "memset d_core");
+    if (rc) return rc;
+  }
+  return launch_backward_generic(ds, cp, indices, rowidx, nnz, nnz_dev, d_output, dst, st);
+}
+
+}  // namespace ttemb
+
+using namespace ttemb;
+
+extern "C" {
+
+int ttemb_abi_version(void) { return TTEMB_ABI_VERSION; }
+
+const char* ttemb_last_error(void) { return g_err; }
+
+int ttemb_set_path(int32_t path) {
+  if (path < TTEMB_PATH_AUTO || path > TTEMB_PATH_FAST3) return fail(TTEMB_E_BADARG, "unknown path %d", path);
+  g_path = path;
+  return TTEMB_OK;
+}
+
+int ttemb_profile_enable(int32_t on) {
+  g_prof_on = on != 0;
+  return TTEMB_OK;
+}
+
+int ttemb_profile_read(int32_t which, float* ms_host) {
+  if (which < 0 || which > 1 || ms_host == nullptr) return fail(TTEMB_E_BADARG, "bad profile slot");
+  if (!g_prof_valid[which]) return fail(TTEMB_E_BADARG, "no profiled launch recorded for slot %d", which);
+  int rc = check_hip(hipEventSynchronize(g_prof_ev[which][1]), "hipEventSynchronize");
+  if (rc) return rc;
+  return check_hip(hipEventElapsedTime(ms_host, g_prof_ev[which][0], g_prof_ev[which][1]), "hipEventElapsedTime");
+}
+
+int64_t ttemb_workspace_bytes(const ttemb_shape_t* shape, int32_t op, int64_t nnz, int64_t B) {
+  if (nnz < 0 || B < 0) return fail(TTEMB_E_BADARG, "negative size");
+  if (op == TTEMB_OP_PREPROCESS) return preprocess_workspace_bytes(nnz);
+  DevShape ds;
+  int rc = make_dev_shape(shape, &ds);
+  if (rc) return rc;
+  const bool f3 = use_fast3(ds);
+  switch (op) {
+    case TTEMB_OP_FORWARD:
+      return f3 ? fast3_workspace_bytes(ds, op, nnz, B) : 0;
+    case TTEMB_OP_BACKWARD:
+      return grad_scratch_bytes(ds) + (f3 ? fast3_workspace_bytes(ds, op, nnz, B) : 0);
+    case TTEMB_OP_CACHE_POPULATE: {
+      const int64_t sort = populate_workspace_bytes(nnz);
+      if (sort < 0) return fail(TTEMB_E_HIP, "rocprim size query failed");
+      return sort + (f3 ? fast3_workspace_bytes(ds, TTEMB_OP_FORWARD, B, B) : 0);
+    }
+    default:
+      return fail(TTEMB_E_BADARG, "unknown op %d", op);
+  }
+}
+
+int ttemb_forward(const ttemb_shape_t* shape, const float* const* cores, const int64_t* indices,
+                  const int64_t* rowidx, const int64_t* offsets, int64_t nnz,
+                  const int32_t* nnz_dev, int64_t B, float* output, void* workspace,
+                  int64_t workspace_bytes, void* stream) {
+  DevShape ds;
+  int rc = make_dev_shape(shape, &ds);
+  if (rc) return rc;
+  rc = check_lookup_args(cores, indices, nnz, B);
+  if (rc) return rc;
+  if (B == 0) return TTEMB_OK;
+  if (output == nullptr) return fail(TTEMB_E_BADARG, "output is null");
+  if (nnz > 0 && rowidx == nullptr) return fail(TTEMB_E_BADARG, "rowidx is null");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (offsets != nullptr && nnz_dev == nullptr && nnz > 0) {
+    const int threads = 256;
+    hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)((B + threads - 1) / threads)), dim3(threads), 0,
+                       st, offsets, B, ds.D, output);
+    rc = check_hip(hipGetLastError(), "zero_rows_kernel");
+  } else {
+    rc = check_hip(hipMemsetAsync(output, 0, (size_t)B * ds.D * 4, st), "memset output");
+  }
+  if (rc || nnz == 0) return rc;
+  CorePtrs cp;
+  for (int t = 0; t < TTEMB_MAX_CORES; ++t) cp.c[t] = t < ds.T ? cores[t] : nullptr;
+  if (use_fast3(ds))
+    return launch_forward_fast3(ds, cp, indices, rowidx, nnz, nnz_dev, output, workspace, workspace_bytes, st);
+  if (current_path() == TTEMB_PATH_FAST3) return fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
+  return launch_forward_generic(ds, cp, indices, rowidx, nnz, nnz_dev, output, st);
+}
+
+int ttemb_backward_dense(const ttemb_shape_t* shape, const float* const* cores,
+                         const int64_t* indices, const int64_t* rowidx, int64_t nnz,
+                         const int32_t* nnz_dev, int64_t B, const float* d_output,
+                         float* const* d_cores, void* workspace, int64_t workspace_bytes,
+                         void* stream) {
+  DevShape ds;
+  int rc = make_dev_shape(shape, &ds);
+  if (rc) return rc;
+  rc = check_lookup_args(cores, indices, nnz, B);
+  if (rc) return rc;
+  if (d_cores == nullptr) return fail(TTEMB_E_BADARG, "d_cores is null");
+  if (nnz > 0 && (rowidx == nullptr || d_output == nullptr)) return fail(TTEMB_E_BADARG, "rowidx/d_output is null");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  CorePtrs cp;
+  CorePtrsMut dp;
+  for (int t = 0; t < TTEMB_MAX_CORES; ++t) {
+    cp.c[t] = t < ds.T ? cores[t] : nullptr;
+    dp.c[t] = t < ds.T ? d_cores[t] : nullptr;
+  }
+  // the gradient scratch region at the head of the workspace is unused in dense mode
+  const int64_t skip = grad_scratch_bytes(ds);
+  char* ws = reinterpret_cast<char*>(workspace);
+  const int64_t rest = workspace_bytes > skip ? workspace_bytes - skip : 0;
+  return backward_into(ds, cp, indices, rowidx, nnz, nnz_dev, d_output, dp, ws ? ws + skip : nullptr, rest, st);
+}
+
+static int fused_backward(const ttemb_shape_t* shape, float* const* cores, float* const* opt_state,
+                          const int64_t* indices, const int64_t* rowidx, int64_t nnz,
+                          const int32_t* nnz_dev, int64_t B, const float* d_output, float lr, float eps,
+                          void* workspace, int64_t workspace_bytes, void* stream) {
+  DevShape ds;
+  int rc = make_dev_shape(shape, &ds);
+  if (rc) return rc;
+  rc = check_lookup_args(cores, indices, nnz, B);
+  if (rc) return rc;
+  if (nnz == 0) return TTEMB_OK;  // zero gradient: SGD is a no-op, Adagrad adds 0 and divides 0
+  if (rowidx == nullptr || d_output == nullptr) return fail(TTEMB_E_BADARG, "rowidx/d_output is null");
+  const int64_t need = grad_scratch_bytes(ds);
+  if (workspace == nullptr || workspace_bytes < need)
+    return fail(TTEMB_E_WORKSPACE, "backward needs %lld workspace bytes, got %lld", (long long)need, (long long)workspace_bytes);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  CorePtrs cp;
+  CorePtrsMut gp;
+  char* ws = reinterpret_cast<char*>(workspace);
+  int64_t off = 0;
+  for (int t = 0; t < TTEMB_MAX_CORES; ++t) {
+    cp.c[t] = t < ds.T ? cores[t] : nullptr;
+    gp.c[t] = nullptr;
+    if (t < ds.T) {
+      gp.c[t] = reinterpret_cast<float*>(ws + off);
+      off += align256((int64_t)ds.p[t] * ds.row_len[t] * 4);
+    }
+  }
+  rc = backward_into(ds, cp, indices, rowidx, nnz, nnz_dev, d_output, gp, ws + off, workspace_bytes - off, st);
+  if (rc) return rc;
+  for (int t = 0; t < ds.T; ++t) {
+    const int64_t n = (int64_t)ds.p[t] * ds.row_len[t];
+    rc = opt_state ? run_adagrad(cores[t], opt_state[t], gp.c[t], n, lr, eps, st)
+                   : run_sgd(cores[t], gp.c[t], n, lr, st);
+    if (rc) return rc;
+  }
+  return TTEMB_OK;
+}
+
+int ttemb_backward_sgd(const ttemb_shape_t* shape, float* const* cores, const int64_t* indices,
+                       const int64_t* rowidx, int64_t nnz, const int32_t* nnz_dev, int64_t B,
+                       const float* d_output, float lr, void* workspace, int64_t workspace_bytes,
+                       void* stream) {
+  return fused_backward(shape, cores, nullptr, indices, rowidx, nnz, nnz_dev, B, d_output, lr, 0.f,
+                        workspace, workspace_bytes, stream);
+}
+
+int ttemb_backward_adagrad(const ttemb_shape_t* shape, float* const* cores, float* const* opt_state,
+                           const int64_t* indices, const int64_t* rowidx, int64_t nnz,
+                           const int32_t* nnz_dev, int64_t B, const float* d_output, float lr,
+                           float eps, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (opt_state == nullptr) return fail(TTEMB_E_BADARG, "opt_state is null");
+  return fused_backward(shape, cores, opt_state, indices, rowidx, nnz, nnz_dev, B, d_output, lr, eps,
+                        workspace, workspace_bytes, stream);
+}
+
+int ttemb_sgd_step(float* weights, const float* grads, int64_t n, float lr, void* stream) {
+  if (n > 0 && (weights == nullptr || grads == nullptr)) return fail(TTEMB_E_BADARG, "null buffer");
+  return run_sgd(weights, grads, n, lr, reinterpret_cast<hipStream_t>(stream));
+}
+
+int ttemb_adagrad_step(float* weights, float* state, const float* grads, int64_t n, float lr,
+                       float eps, void* stream) {
+  if (n > 0 && (weights == nullptr || grads == nullptr || state == nullptr)) return fail(TTEMB_E_BADARG, "null buffer");
+  return run_adagrad(weights, state, grads, n, lr, eps, reinterpret_cast<hipStream_t>(stream));
+}
+
+int ttemb_cache_update(const int64_t* indices, int64_t nnz, int64_t* hashtbl, int64_t* cache_freq,
+                       int64_t H, void* stream) {
+  if (nnz < 0) return fail(TTEMB_E_BADARG, "negative nnz");
+  if (nnz == 0) return TTEMB_OK;
+  if (H <= 0 || H > 0x7fffffffll) return fail(TTEMB_E_BADARG, "hashtbl_size %lld out of range", (long long)H);
+  if (!indices || !hashtbl || !cache_freq) return fail(TTEMB_E_BADARG, "null buffer");
+  return launch_cache_update(indices, nnz, hashtbl, cache_freq, H, reinterpret_cast<hipStream_t>(stream));
+}
+
+int ttemb_cache_populate(const ttemb_shape_t* shape, const float* const* cores, int64_t* hashtbl,
+                         int64_t* cache_freq, int32_t* cache_state, int64_t H, float* cache_weight,
+                         int64_t C, void* workspace, int64_t workspace_bytes, void* stream) {
+  DevShape ds;
+  int rc = make_dev_shape(shape, &ds);
+  if (rc) return rc;
+  if (H <= 0 || H > 0x7fffffffll) return fail(TTEMB_E_BADARG, "hashtbl_size %lld out of range", (long long)H);
+  if (C < 0 || C > H) return fail(TTEMB_E_BADARG, "cache rows %lld must be within [0, hashtbl_size]", (long long)C);
+  if (!cores || !hashtbl || !cache_freq || !cache_state || (C > 0 && !cache_weight) || !workspace)
+    return fail(TTEMB_E_BADARG, "null buffer");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int64_t* sorted_keys = nullptr;
+  rc = launch_cache_populate_rank(hashtbl, cache_freq, cache_state, H, C, workspace, workspace_bytes,
+                                  &sorted_keys, st);
+  if (rc || C == 0) return rc;
+  CorePtrs cp;
+  for (int t = 0; t < TTEMB_MAX_CORES; ++t) cp.c[t] = t < ds.T ? cores[t] : nullptr;
+  // rows of the C hottest ids straight into cache_weight (reference: prefetch in chunks of 200)
+  return launch_forward_generic(ds, cp, sorted_keys, nullptr, C, nullptr, cache_weight, st);
+}
+
+int ttemb_preprocess(const int64_t* indices, const int64_t* offsets, int64_t nnz, int64_t B,
+                     int32_t warmup, const int64_t* hashtbl, const int32_t* cache_state, int64_t H,
+                     int64_t* indices_out, int64_t* rowidx_out, int32_t* cache_loc_out,
+                     int32_t* nnz_tt_dev, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (nnz < 0 || B < 0) return fail(TTEMB_E_BADARG, "negative size");
+  if (nnz > 0x7fffffffll) return fail(TTEMB_E_BADARG, "nnz exceeds int32 range");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const bool passthrough = warmup != 0 || H == 0;
+  if (nnz == 0) return nnz_tt_dev ? launch_set_count(nnz_tt_dev, 0, st) : TTEMB_OK;
+  if (!indices || !offsets || !rowidx_out) return fail(TTEMB_E_BADARG, "null buffer");
+  if (passthrough) {
+    int rc = launch_rowidx(offsets, B, nnz, rowidx_out, st);
+    if (rc) return rc;
+    if (indices_out != nullptr && indices_out != indices) {
+      rc = check_hip(hipMemcpyAsync(indices_out, indices, (size_t)nnz * 8, hipMemcpyDeviceToDevice, st), "copy indices");
+      if (rc) return rc;
+    }
+    return nnz_tt_dev ? launch_set_count(nnz_tt_dev, (int32_t)nnz, st) : TTEMB_OK;
+  }
+  if (H > 0x7fffffffll) return fail(TTEMB_E_BADARG, "hashtbl_size out of range");
+  if (!hashtbl || !cache_state || !indices_out || !cache_loc_out || !nnz_tt_dev || !workspace)
+    return fail(TTEMB_E_BADARG, "null buffer");
+  if (indices_out == indices) return fail(TTEMB_E_BADARG, "partition cannot run in place");
+  return launch_partition(indices, offsets, nnz, B, hashtbl, cache_state, H, indices_out, rowidx_out,
+                          cache_loc_out, nnz_tt_dev, workspace, workspace_bytes, st);
+}
+
+static int check_cache_args(const void* loc, const void* rowidx, int64_t start, int64_t nnz, int64_t D) {
+  if (nnz < 0 || start < 0) return fail(TTEMB_E_BADARG, "negative size");
+  if (D <= 0 || D % 4 != 0) return fail(TTEMB_E_BADARG, "embedding_dim %lld must be a positive multiple of 4", (long long)D);
+  if (nnz > 0 && (!loc || !rowidx)) return fail(TTEMB_E_BADARG, "null buffer");
+  return TTEMB_OK;
+}
+
+int ttemb_cache_forward(const int32_t* cache_loc, const int64_t* rowidx, int64_t start,
+                        const int32_t* start_dev, int64_t nnz, const float* cache_weight, int64_t D,
+                        float* output, void* stream) {
+  int rc = check_cache_args(cache_loc, rowidx, start, nnz, D);
+  if (rc) return rc;
+  if (nnz > 0 && (!cache_weight || !output)) return fail(TTEMB_E_BADARG, "null buffer");
+  return launch_cache_forward(cache_loc, rowidx, start, start_dev, nnz, cache_weight, D, output,
+                              reinterpret_cast<hipStream_t>(stream));
+}
+
+int ttemb_cache_backward_sgd(const int32_t* cache_loc, const int64_t* rowidx, int64_t start,
+                             const int32_t* start_dev, int64_t nnz, const float* d_output, int64_t D,
+                             float lr, float* cache_weight, void* stream) {
+  int rc = check_cache_args(cache_loc, rowidx, start, nnz, D);
+  if (rc) return rc;
+  if (nnz > 0 && (!cache_weight || !d_output)) return fail(TTEMB_E_BADARG, "null buffer");
+  return launch_cache_scatter_add(cache_loc, rowidx, start, start_dev, nnz, d_output, D, -lr,
+                                  cache_weight, reinterpret_cast<hipStream_t>(stream));
+}
+
+int ttemb_cache_backward_dense(const int32_t* cache_loc, const int64_t* rowidx, int64_t start,
+                               const int32_t* start_dev, int64_t nnz, const float* d_output, int64_t D,
+                               int64_t C, float* d_cache_weight, void* stream) {
+  int rc = check_cache_args(cache_loc, rowidx, start, nnz, D);
+  if (rc) return rc;
+  if (C < 0) return fail(TTEMB_E_BADARG, "negative cache rows");
+  if (C > 0 && !d_cache_weight) return fail(TTEMB_E_BADARG, "null buffer");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (C > 0) {
+    rc = check_hip(hipMemsetAsync(d_cache_weight, 0, (size_t)C * D * 4, st), "memset d_cache_weight");
+    if (rc) return rc;
+  }
+  if (nnz > 0 && !d_output) return fail(TTEMB_E_BADARG, "null buffer");
+  return launch_cache_scatter_add(cache_loc, rowidx, start, start_dev, nnz, d_output, D, 1.0f,
+                                  d_cache_weight, st);
+}
+
+int ttemb_cache_backward_rowwise_adagrad(const int32_t* cache_loc, const int64_t* rowidx, int64_t start,
+                                         const int32_t* start_dev, int64_t nnz, const float* d_output,
+                                         int64_t D, float lr, float eps, float* cache_state_sum,
+                                         float* cache_weight, void* stream) {
+  int rc = check_cache_args(cache_loc, rowidx, start, nnz, D);
+  if (rc) return rc;
+  if (nnz > 0 && (!cache_weight || !d_output || !cache_state_sum)) return fail(TTEMB_E_BADARG, "null buffer");
+  return launch_cache_rowwise_adagrad(cache_loc, rowidx, start, start_dev, nnz, d_output, D, lr, eps,
+                                      cache_state_sum, cache_weight, reinterpret_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,385 @@
+// LFU hash-table row cache + index preprocessing (HBM-bound integer / gather work).
+//
+// Reference counterparts: FBTT/hashtbl_cuda_utils.cuh (hash, probe),
+// FBTT/tt_embeddings_cuda.cu:1083-1847 (cache kernels, preprocess).  Geometry is
+// re-derived for 64-lane wavefronts: one wavefront owns one id and its D-float row
+// (float4 per lane), instead of the reference's 32-lane "warp per id" blocks.
+#include "ttemb_common.h"
+#include "ttemb_cache.h"
+
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+namespace ttemb {
+
+// ---------------------------------------------------------------------------------
+// hash (bit-exact with FBTT/hashtbl_cuda_utils.cuh:48-76 so that saved
+// (hashtbl, cache_state, cache_weight) triples stay consistent across backends)
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+
+__device__ __forceinline__ uint32_t hash_slot(int64_t key, uint32_t H) {
+  const uint64_t u = (uint64_t)key;
+  uint32_t h = 0;
+  uint32_t k = (uint32_t)u;
+  k *= 0xcc9e2d51u;
+  k = rotl32(k, 15);
+  k *= 0x1b873593u;
+  h ^= k;
+  h = rotl32(h, 13);
+  h = h * 5u + 0xe6546b64u;
+  k = (uint32_t)(u >> 32);
+  k *= 0xcc9e2d51u;
+  k = rotl32(k, 15);
+  k *= 0x1b873593u;
+  h ^= k;
+  h = rotl32(h, 13);
+  h = h * 5u + 0xe6546b64u;
+  h ^= 2u;
+  h ^= h >> 16;
+  h *= 0x85ebca6bu;
+  h ^= h >> 13;
+  h *= 0xc2b2ae35u;
+  h ^= h >> 16;
+  return (uint32_t)(((uint64_t)h * (uint64_t)H) >> 32);
+}
+
+// slot of `key`, or -1.  Like the reference it does not stop at empty slots
+// (hashtbl_cuda_utils.cuh:135-154), so evictions never hide a displaced key.
+__device__ __forceinline__ int32_t table_find(int64_t key, const int64_t* __restrict__ keys, uint32_t H) {
+  if (key == kEmptyKey) return -1;
+  uint32_t s = hash_slot(key, H);
+#pragma unroll
+  for (int probe = 0; probe < kMaxProbes; ++probe) {
+    if (keys[s] == key) return (int32_t)s;
+    s = (s + 1 == H) ? 0 : s + 1;
+  }
+  return -1;
+}
+
+__global__ void cache_update_kernel(const int64_t* __restrict__ indices, int64_t nnz,
+                                    int64_t* __restrict__ keys, int64_t* __restrict__ freq,
+                                    uint32_t H) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= nnz) return;
+  const int64_t key = indices[n];
+  uint32_t s = hash_slot(key, H);
+  for (int probe = 0; probe < kMaxProbes; ++probe) {
+    const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[s]),
+                                             (unsigned long long)kEmptyKey, (unsigned long long)key);
+    if (old == (unsigned long long)kEmptyKey || old == (unsigned long long)key) {
+      atomicAdd(reinterpret_cast<unsigned long long*>(&freq[s]), 1ull);
+      return;
+    }
+    s = (s + 1 == H) ? 0 : s + 1;
+  }
+  // three occupied probes: the id is simply not tracked (reference returns -1 and moves on)
+}
+
+int launch_cache_update(const int64_t* indices, int64_t nnz, int64_t* hashtbl, int64_t* freq,
+                        int64_t H, hipStream_t st) {
+  if (nnz <= 0) return TTEMB_OK;
+  const int threads = 256;
+  const int64_t blocks = (nnz + threads - 1) / threads;
+  hipLaunchKernelGGL(cache_update_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, indices,
+                     nnz, hashtbl, freq, (uint32_t)H);
+  return check_hip(hipGetLastError(), "cache_update_kernel");
+}
+
+// ---------------------------------------------------------------------------------
+// cache_populate
+// ---------------------------------------------------------------------------------
+__global__ void mark_popular_kernel(int64_t H, int64_t C, int64_t* __restrict__ sorted_keys,
+                                    int64_t* __restrict__ keys, int64_t* __restrict__ freq,
+                                    int32_t* __restrict__ state) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= H) return;
+  const int64_t key = sorted_keys[n];
+  if (key != kEmptyKey) {
+    const int32_t slot = table_find(key, keys, (uint32_t)H);
+    if (slot < 0) return;  // cannot happen for a key read out of the table itself
+    if (n < C) {
+      state[slot] = (int32_t)n;
+    } else {
+      keys[slot] = kEmptyKey;
+      freq[slot] = 0;
+    }
+  } else if (n < C) {
+    sorted_keys[n] = 0;  // unused rank: its cache row holds the row of id 0 (reference :1144-1147)
+  }
+}
+
+int64_t populate_workspace_bytes(int64_t H) {
+  size_t tmp = 0;
+  int64_t* nul = nullptr;
+  hipError_t e = rocprim::radix_sort_pairs_desc(nullptr, tmp, nul, nul, nul, nul, (size_t)H, 0, 64,
+                                                (hipStream_t)0, false);
+  if (e != hipSuccess) return -1;
+  return align256(H * 8) * 2 + align256((int64_t)tmp) + 256;
+}
+
+int launch_cache_populate_rank(int64_t* hashtbl, int64_t* freq, int32_t* state, int64_t H, int64_t C,
+                               void* ws, int64_t ws_bytes, int64_t** sorted_keys_out, hipStream_t st) {
+  char* base = reinterpret_cast<char*>(ws);
+  int64_t* sorted_freq = reinterpret_cast<int64_t*>(base);
+  int64_t* sorted_keys = reinterpret_cast<int64_t*>(base + align256(H * 8));
+  char* tmp = base + 2 * align256(H * 8);
+  size_t tmp_bytes = 0;
+  hipError_t e = rocprim::radix_sort_pairs_desc(nullptr, tmp_bytes, freq, sorted_freq, hashtbl,
+                                                sorted_keys, (size_t)H, 0, 64, st, false);
+  if (e != hipSuccess) return check_hip(e, "radix_sort_pairs_desc(size)");
+  if (2 * align256(H * 8) + (int64_t)tmp_bytes > ws_bytes)
+    return fail(TTEMB_E_WORKSPACE, "cache_populate needs %lld workspace bytes, got %lld",
+                (long long)(2 * align256(H * 8) + tmp_bytes), (long long)ws_bytes);
+  // stable: equal frequencies keep slot order, like cub::DeviceRadixSort (reference :1292-1318)
+  e = rocprim::radix_sort_pairs_desc(tmp, tmp_bytes, freq, sorted_freq, hashtbl, sorted_keys,
+                                     (size_t)H, 0, 64, st, false);
+  if (e != hipSuccess) return check_hip(e, "radix_sort_pairs_desc");
+  const int threads = 256;
+  const int64_t blocks = (H + threads - 1) / threads;
+  hipLaunchKernelGGL(mark_popular_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, H, C,
+                     sorted_keys, hashtbl, freq, state);
+  *sorted_keys_out = sorted_keys;
+  return check_hip(hipGetLastError(), "mark_popular_kernel");
+}
+
+// ---------------------------------------------------------------------------------
+// preprocess: rowidx expansion, cache lookup, stable partition
+// ---------------------------------------------------------------------------------
+__global__ void rowidx_kernel(const int64_t* __restrict__ offsets, int64_t B, int64_t nnz,
+                              int64_t* __restrict__ rowidx) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int64_t lo = offsets[b];
+  int64_t hi = offsets[b + 1];
+  lo = lo < 0 ? 0 : lo;
+  hi = hi > nnz ? nnz : hi;
+  for (int64_t l = lo; l < hi; ++l) rowidx[l] = b;
+}
+
+__global__ void cache_lookup_kernel(const int64_t* __restrict__ indices, int64_t nnz,
+                                    const int64_t* __restrict__ keys,
+                                    const int32_t* __restrict__ state, uint32_t H,
+                                    int32_t* __restrict__ is_tt, int32_t* __restrict__ loc) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= nnz) return;
+  const int32_t slot = table_find(indices[n], keys, H);
+  int32_t where = -1;
+  if (slot >= 0) where = state[slot];
+  is_tt[n] = where < 0 ? 1 : 0;
+  loc[n] = where;
+}
+
+// selected (TT) items keep input order at the front; rejected (cached) items fill the
+// tail from the end backwards -- the order cub::DevicePartition::Flagged produces and
+// the reference's cache kernels therefore see (tt_embeddings_cuda.cu:1448-1490).
+__global__ void partition_scatter_kernel(int64_t nnz, const int32_t* __restrict__ is_tt,
+                                         const int32_t* __restrict__ pos,
+                                         const int64_t* __restrict__ indices,
+                                         const int64_t* __restrict__ rowidx,
+                                         const int32_t* __restrict__ loc,
+                                         int64_t* __restrict__ indices_out,
+                                         int64_t* __restrict__ rowidx_out,
+                                         int32_t* __restrict__ loc_out,
+                                         int32_t* __restrict__ nnz_tt) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= nnz) return;
+  const int32_t f = is_tt[n];
+  const int64_t before = pos[n];
+  const int64_t dst = f ? before : (nnz - 1 - (n - before));
+  indices_out[dst] = indices[n];
+  rowidx_out[dst] = rowidx[n];
+  loc_out[dst] = loc[n];
+  if (n == nnz - 1) *nnz_tt = (int32_t)(before + f);
+}
+
+__global__ void set_count_kernel(int32_t* dst, int32_t v) { *dst = v; }
+
+int64_t preprocess_workspace_bytes(int64_t nnz) {
+  size_t tmp = 0;
+  int32_t* nul = nullptr;
+  hipError_t e = rocprim::exclusive_scan(nullptr, tmp, nul, nul, 0, (size_t)(nnz > 0 ? nnz : 1),
+                                         rocprim::plus<int32_t>(), (hipStream_t)0, false);
+  if (e != hipSuccess) return -1;
+  return align256(nnz * 8) + 3 * align256(nnz * 4) + align256((int64_t)tmp) + 256;
+}
+
+int launch_rowidx(const int64_t* offsets, int64_t B, int64_t nnz, int64_t* rowidx, hipStream_t st) {
+  if (B <= 0 || nnz <= 0) return TTEMB_OK;
+  const int threads = 256;
+  const int64_t blocks = (B + threads - 1) / threads;
+  hipLaunchKernelGGL(rowidx_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, offsets, B, nnz, rowidx);
+  return check_hip(hipGetLastError(), "rowidx_kernel");
+}
+
+int launch_set_count(int32_t* dst, int32_t v, hipStream_t st) {
+  hipLaunchKernelGGL(set_count_kernel, dim3(1), dim3(1), 0, st, dst, v);
+  return check_hip(hipGetLastError(), "set_count_kernel");
+}
+
+int launch_partition(const int64_t* indices, const int64_t* offsets, int64_t nnz, int64_t B,
+                     const int64_t* hashtbl, const int32_t* state, int64_t H, int64_t* indices_out,
+                     int64_t* rowidx_out, int32_t* loc_out, int32_t* nnz_tt_dev, void* ws,
+                     int64_t ws_bytes, hipStream_t st) {
+  char* base = reinterpret_cast<char*>(ws);
+  int64_t* rowidx_tmp = reinterpret_cast<int64_t*>(base);
+  base += align256(nnz * 8);
+  int32_t* is_tt = reinterpret_cast<int32_t*>(base);
+  base += align256(nnz * 4);
+  int32_t* pos = reinterpret_cast<int32_t*>(base);
+  base += align256(nnz * 4);
+  int32_t* loc = reinterpret_cast<int32_t*>(base);
+  base += align256(nnz * 4);
+  size_t tmp_bytes = 0;
+  hipError_t e = rocprim::exclusive_scan(nullptr, tmp_bytes, is_tt, pos, 0, (size_t)nnz,
+                                         rocprim::plus<int32_t>(), st, false);
+  if (e != hipSuccess) return check_hip(e, "exclusive_scan(size)");
+  const int64_t need = (base - reinterpret_cast<char*>(ws)) + (int64_t)tmp_bytes;
+  if (need > ws_bytes)
+    return fail(TTEMB_E_WORKSPACE, "preprocess needs %lld workspace bytes, got %lld", (long long)need,
+                (long long)ws_bytes);
+  int rc = launch_rowidx(offsets, B, nnz, rowidx_tmp, st);
+  if (rc) return rc;
+  const int threads = 256;
+  const int64_t blocks = (nnz + threads - 1) / threads;
+  hipLaunchKernelGGL(cache_lookup_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, indices, nnz,
+                     hashtbl, state, (uint32_t)H, is_tt, loc);
+  rc = check_hip(hipGetLastError(), "cache_lookup_kernel");
+  if (rc) return rc;
+  e = rocprim::exclusive_scan(base, tmp_bytes, is_tt, pos, 0, (size_t)nnz, rocprim::plus<int32_t>(),
+                              st, false);
+  if (e != hipSuccess) return check_hip(e, "exclusive_scan");
+  hipLaunchKernelGGL(partition_scatter_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, nnz, is_tt,
+                     pos, indices, rowidx_tmp, loc, indices_out, rowidx_out, loc_out, nnz_tt_dev);
+  return check_hip(hipGetLastError(), "partition_scatter_kernel");
+}
+
+// ---------------------------------------------------------------------------------
+// cached-row forward / backward: one wavefront per id, float4 per lane.
+// A bag with one cached id is updated with plain loads/stores, otherwise atomics.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t live_start(int64_t start, const int32_t* start_dev, int64_t nnz) {
+  if (start_dev != nullptr) start = *start_dev;
+  if (start < 0) start = 0;
+  return start > nnz ? nnz : start;
+}
+
+__global__ __launch_bounds__(256) void cache_forward_kernel(const int32_t* __restrict__ loc,
+                                                            const int64_t* __restrict__ rowidx,
+                                                            int64_t start, const int32_t* start_dev,
+                                                            int64_t nnz,
+                                                            const float* __restrict__ weight, int D,
+                                                            float* __restrict__ out) {
+  const int64_t s0 = live_start(start, start_dev, nnz);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t n = s0 + (int64_t)blockIdx.x * 4 + wave;
+  if (n >= nnz) return;
+  const int64_t row = rowidx[n];
+  const bool single = (n == s0 || rowidx[n - 1] != row) && (n + 1 >= nnz || rowidx[n + 1] != row);
+  const float4* w = reinterpret_cast<const float4*>(weight + (int64_t)loc[n] * D);
+  float* o = out + row * D;
+  for (int c = lane; c * 4 < D; c += kWave) {
+    const float4 v = w[c];
+    if (single) {
+      float4 cur = reinterpret_cast<float4*>(o)[c];
+      cur.x += v.x; cur.y += v.y; cur.z += v.z; cur.w += v.w;
+      reinterpret_cast<float4*>(o)[c] = cur;
+    } else {
+      atomicAdd(&o[4 * c + 0], v.x);
+      atomicAdd(&o[4 * c + 1], v.y);
+      atomicAdd(&o[4 * c + 2], v.z);
+      atomicAdd(&o[4 * c + 3], v.w);
+    }
+  }
+}
+
+// scale == -lr : cache_backward_sgd ; scale == 1 : cache_backward_dense (target pre-zeroed)
+__global__ __launch_bounds__(256) void cache_scatter_add_kernel(const int32_t* __restrict__ loc,
+                                                                const int64_t* __restrict__ rowidx,
+                                                                int64_t start, const int32_t* start_dev,
+                                                                int64_t nnz,
+                                                                const float* __restrict__ grad, int D,
+                                                                float scale, float* __restrict__ target) {
+  const int64_t s0 = live_start(start, start_dev, nnz);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t n = s0 + (int64_t)blockIdx.x * 4 + wave;
+  if (n >= nnz) return;
+  const float4* g = reinterpret_cast<const float4*>(grad + rowidx[n] * D);
+  float* t = target + (int64_t)loc[n] * D;
+  for (int c = lane; c * 4 < D; c += kWave) {
+    const float4 v = g[c];
+    atomicAdd(&t[4 * c + 0], v.x * scale);
+    atomicAdd(&t[4 * c + 1], v.y * scale);
+    atomicAdd(&t[4 * c + 2], v.z * scale);
+    atomicAdd(&t[4 * c + 3], v.w * scale);
+  }
+}
+
+__global__ __launch_bounds__(256) void cache_rowwise_adagrad_kernel(
+    const int32_t* __restrict__ loc, const int64_t* __restrict__ rowidx, int64_t start,
+    const int32_t* start_dev, int64_t nnz, const float* __restrict__ grad, int D, float lr, float eps,
+    float* __restrict__ state_sum, float* __restrict__ weight) {
+  const int64_t s0 = live_start(start, start_dev, nnz);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t n = s0 + (int64_t)blockIdx.x * 4 + wave;
+  if (n >= nnz) return;
+  const float4* g = reinterpret_cast<const float4*>(grad + rowidx[n] * D);
+  float sq = 0.f;
+  for (int c = lane; c * 4 < D; c += kWave) {
+    const float4 v = g[c];
+    sq += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) sq += __shfl_xor(sq, m, kWave);  // all 64 lanes, not 32
+  const float g2 = sq / (float)D;
+  const int32_t l = loc[n];
+  float mult = 0.f;
+  if (lane == 0) {
+    const float old = atomicAdd(&state_sum[l], g2);
+    mult = lr * (1.0f / (sqrtf(old + g2) + eps));
+  }
+  mult = __shfl(mult, 0, kWave);
+  float4* w = reinterpret_cast<float4*>(weight + (int64_t)l * D);
+  for (int c = lane; c * 4 < D; c += kWave) {
+    const float4 v = g[c];
+    float4 cur = w[c];
+    cur.x -= v.x * mult; cur.y -= v.y * mult; cur.z -= v.z * mult; cur.w -= v.w * mult;
+    w[c] = cur;
+  }
+}
+
+static inline unsigned wave_blocks(int64_t nnz) { return (unsigned)((nnz + 3) / 4); }
+
+int launch_cache_forward(const int32_t* loc, const int64_t* rowidx, int64_t start,
+                         const int32_t* start_dev, int64_t nnz, const float* weight, int64_t D,
+                         float* out, hipStream_t st) {
+  const int64_t span = start_dev ? nnz : nnz - start;
+  if (span <= 0) return TTEMB_OK;
+  hipLaunchKernelGGL(cache_forward_kernel, dim3(wave_blocks(span)), dim3(256), 0, st, loc, rowidx, start,
+                     start_dev, nnz, weight, (int)D, out);
+  return check_hip(hipGetLastError(), "cache_forward_kernel");
+}
+
+int launch_cache_scatter_add(const int32_t* loc, const int64_t* rowidx, int64_t start,
+                             const int32_t* start_dev, int64_t nnz, const float* grad, int64_t D,
+                             float scale, float* target, hipStream_t st) {
+  const int64_t span = start_dev ? nnz : nnz - start;
+  if (span <= 0) return TTEMB_OK;
+  hipLaunchKernelGGL(cache_scatter_add_kernel, dim3(wave_blocks(span)), dim3(256), 0, st, loc, rowidx,
+                     start, start_dev, nnz, grad, (int)D, scale, target);
+  return check_hip(hipGetLastError(), "cache_scatter_add_kernel");
+}
+
+int launch_cache_rowwise_adagrad(const int32_t* loc, const int64_t* rowidx, int64_t start,
+                                 const int32_t* start_dev, int64_t nnz, const float* grad, int64_t D,
+                                 float lr, float eps, float* state_sum, float* weight, hipStream_t st) {
+  const int64_t span = start_dev ? nnz : nnz - start;
+  if (span <= 0) return TTEMB_OK;
+  hipLaunchKernelGGL(cache_rowwise_adagrad_kernel, dim3(wave_blocks(span)), dim3(256), 0, st, loc,
+                     rowidx, start, start_dev, nnz, grad, (int)D, lr, eps, state_sum, weight);
+  return check_hip(hipGetLastError(), "cache_rowwise_adagrad_kernel");
+}
+
+}  // namespace ttemb

@@ -1,0 +1,89 @@
+// Shared declarations for the libttemb_hip.so translation units (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ttemb.h"
+
+namespace ttemb {
+
+constexpr int kWave = 64;          // CDNA wavefront
+constexpr int kMaxProbes = 3;      // reference MAX_PROBES, FBTT/tt_embeddings_cuda.cu:31
+constexpr int64_t kEmptyKey = -1;  // reference UNUSED_KEY, FBTT/hashtbl_cuda_utils.cuh:100
+
+// Device-side view of one table's factorisation (passed to kernels by value).
+struct DevShape {
+  int T;
+  int p[TTEMB_MAX_CORES];
+  int q[TTEMB_MAX_CORES];
+  int R[TTEMB_MAX_CORES + 1];
+  long long L[TTEMB_MAX_CORES];   // L[t] = prod(p[t+1:])
+  int D;                          // prod(q)
+  int row_len[TTEMB_MAX_CORES];   // floats per core row: R[t]*q[t]*R[t+1]
+  int part_len[TTEMB_MAX_CORES];  // floats of the partial product after core t: q0..qt * R[t+1]
+  int part_max;                   // max part_len over t < T-1 (and q0*R1)
+};
+
+struct CorePtrs {
+  const float* c[TTEMB_MAX_CORES];
+};
+struct CorePtrsMut {
+  float* c[TTEMB_MAX_CORES];
+};
+
+// host helpers (ttemb_api.hip)
+int fail(int code, const char* fmt, ...);
+int check_hip(hipError_t e, const char* what);
+int make_dev_shape(const ttemb_shape_t* s, DevShape* out);
+int current_path();
+// measurement hook: bracket the main chain kernel with events when profiling is on
+void profile_begin(int which, hipStream_t st);
+void profile_end(int which, hipStream_t st);
+
+// generic kernels (ttemb_generic.hip)
+int64_t generic_fwd_lds_bytes(const DevShape& s);
+int64_t generic_bwd_lds_bytes(const DevShape& s);
+int launch_forward_generic(const DevShape& s, const CorePtrs& cores, const int64_t* indices,
+                           const int64_t* rowidx, int64_t nnz, const int32_t* nnz_dev,
+                           float* output, hipStream_t st);
+int launch_backward_generic(const DevShape& s, const CorePtrs& cores, const int64_t* indices,
+                            const int64_t* rowidx, int64_t nnz, const int32_t* nnz_dev,
+                            const float* d_output, const CorePtrsMut& d_cores, hipStream_t st);
+
+// fast 3-core path (ttemb_fast3.hip)
+bool fast3_supported(const DevShape& s);
+int64_t fast3_workspace_bytes(const DevShape& s, int32_t op, int64_t nnz, int64_t B);
+int launch_forward_fast3(const DevShape& s, const CorePtrs& cores, const int64_t* indices,
+                         const int64_t* rowidx, int64_t nnz, const int32_t* nnz_dev,
+                         float* output, void* ws, int64_t ws_bytes, hipStream_t st);
+int launch_backward_fast3(const DevShape& s, const CorePtrs& cores, const int64_t* indices,
+                          const int64_t* rowidx, int64_t nnz, const int32_t* nnz_dev,
+                          const float* d_output, const CorePtrsMut& d_cores, void* ws,
+                          int64_t ws_bytes, hipStream_t st);
+
+// ---------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t live_count(int64_t nnz, const int32_t* nnz_dev) {
+  if (nnz_dev == nullptr) return nnz;
+  int64_t c = *nnz_dev;
+  return c < nnz ? (c < 0 ? 0 : c) : nnz;
+}
+
+// id -> per-core row numbers (reference: FBTT/tt_embeddings_cuda.cu:796-802).
+__device__ __forceinline__ void split_index(const DevShape& s, int64_t idx, int (&i)[TTEMB_MAX_CORES]) {
+#pragma unroll
+  for (int t = 0; t < TTEMB_MAX_CORES; ++t) {
+    if (t < s.T) {
+      int64_t d = idx / s.L[t];
+      idx -= d * s.L[t];
+      // ids beyond prod(p) would index past core 0; clamp so a bad id cannot fault
+      i[t] = (int)(d < s.p[t] ? (d < 0 ? 0 : d) : s.p[t] - 1);
+    } else {
+      i[t] = 0;
+    }
+  }
+}
+
+}  // namespace ttemb

@@ -1,0 +1,290 @@
+"""ctypes binding of ``libttemb_hip.so`` (the C ABI declared in ``include/ttemb.h``).
+
+This is the only place Python touches the native library.  Everything here takes
+``torch`` tensors living on a ROCm device, passes raw ``data_ptr()`` values and the
+current HIP stream, and raises ``RuntimeError`` with the library's message on a
+non-zero status -- the same error convention as the reference's pybind module
+(``c10::Error`` -> ``RuntimeError``; FBTT/tt_embeddings.cpp:131-161).
+
+There is no CPU fallback: if the shared library is missing the import of this
+module fails, and CPU tensors are rejected.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import List, Optional, Sequence
+
+import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first, so we share one HIP runtime)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libttemb_hip.so")
+
+MAX_CORES = 4
+OP_FORWARD, OP_BACKWARD, OP_PREPROCESS, OP_CACHE_POPULATE = 0, 1, 2, 3
+PATH_AUTO, PATH_GENERIC, PATH_FAST3 = 0, 1, 2
+
+# every symbol include/ttemb.h declares (tests check the library exports all of them)
+EXPORTED_SYMBOLS = (
+    "ttemb_abi_version", "ttemb_last_error", "ttemb_workspace_bytes", "ttemb_set_path",
+    "ttemb_profile_enable", "ttemb_profile_read",
+    "ttemb_forward", "ttemb_backward_dense", "ttemb_backward_sgd", "ttemb_backward_adagrad",
+    "ttemb_sgd_step", "ttemb_adagrad_step", "ttemb_cache_update", "ttemb_cache_populate",
+    "ttemb_preprocess", "ttemb_cache_forward", "ttemb_cache_backward_sgd",
+    "ttemb_cache_backward_dense", "ttemb_cache_backward_rowwise_adagrad",
+)
+
+
+class Shape(ctypes.Structure):
+    """Mirror of ``ttemb_shape_t``."""
+    _fields_ = [("T", ctypes.c_int32), ("p", ctypes.c_int32 * MAX_CORES),
+                ("q", ctypes.c_int32 * MAX_CORES), ("R", ctypes.c_int32 * (MAX_CORES + 1))]
+
+
+def make_shape(p: Sequence[int], q: Sequence[int], ranks: Sequence[int]) -> Shape:
+    """``ranks`` may be the inner ranks (T-1 values) or the padded list (T+1 values)."""
+    T = len(p)
+    r = [int(x) for x in ranks]
+    if len(r) == T - 1:
+        r = [1] + r + [1]
+    if len(q) != T or len(r) != T + 1 or not (2 <= T <= MAX_CORES):
+        raise RuntimeError(f"inconsistent TT shape: p={list(p)} q={list(q)} ranks={list(ranks)}")
+    s = Shape()
+    s.T = T
+    for t in range(T):
+        s.p[t], s.q[t] = int(p[t]), int(q[t])
+    for t in range(T + 1):
+        s.R[t] = r[t]
+    return s
+
+
+def _load() -> ctypes.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C falcon-ttdforgnns_amd/csrc`.  There is no CPU fallback for the TT embedding path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i64, i32, f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_float
+    shp = ctypes.POINTER(Shape)
+    lib.ttemb_abi_version.restype = ctypes.c_int
+    lib.ttemb_last_error.restype = ctypes.c_char_p
+    lib.ttemb_workspace_bytes.restype = i64
+    lib.ttemb_workspace_bytes.argtypes = [shp, i32, i64, i64]
+    lib.ttemb_set_path.argtypes = [i32]
+    lib.ttemb_profile_enable.argtypes = [i32]
+    lib.ttemb_profile_read.argtypes = [i32, ctypes.POINTER(ctypes.c_float)]
+    lib.ttemb_forward.argtypes = [shp, vp, vp, vp, vp, i64, vp, i64, vp, vp, i64, vp]
+    lib.ttemb_backward_dense.argtypes = [shp, vp, vp, vp, i64, vp, i64, vp, vp, vp, i64, vp]
+    lib.ttemb_backward_sgd.argtypes = [shp, vp, vp, vp, i64, vp, i64, vp, f32, vp, i64, vp]
+    lib.ttemb_backward_adagrad.argtypes = [shp, vp, vp, vp, vp, i64, vp, i64, vp, f32, f32, vp, i64, vp]
+    lib.ttemb_sgd_step.argtypes = [vp, vp, i64, f32, vp]
+    lib.ttemb_adagrad_step.argtypes = [vp, vp, vp, i64, f32, f32, vp]
+    lib.ttemb_cache_update.argtypes = [vp, i64, vp, vp, i64, vp]
+    lib.ttemb_cache_populate.argtypes = [shp, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp]
+    lib.ttemb_preprocess.argtypes = [vp, vp, i64, i64, i32, vp, vp, i64, vp, vp, vp, vp, vp, i64, vp]
+    lib.ttemb_cache_forward.argtypes = [vp, vp, i64, vp, i64, vp, i64, vp, vp]
+    lib.ttemb_cache_backward_sgd.argtypes = [vp, vp, i64, vp, i64, vp, i64, f32, vp, vp]
+    lib.ttemb_cache_backward_dense.argtypes = [vp, vp, i64, vp, i64, vp, i64, i64, vp, vp]
+    lib.ttemb_cache_backward_rowwise_adagrad.argtypes = [vp, vp, i64, vp, i64, vp, i64, f32, f32, vp, vp, vp]
+    for name in EXPORTED_SYMBOLS:
+        fn = getattr(lib, name)
+        if name not in ("ttemb_last_error", "ttemb_workspace_bytes"):
+            fn.restype = ctypes.c_int
+    if lib.ttemb_abi_version() != 1:
+        raise ImportError("libttemb_hip.so ABI version mismatch")
+    return lib
+
+
+LIB = _load()
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        raise RuntimeError(f"libttemb_hip: {LIB.ttemb_last_error().decode()} (status {rc})")
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("TT embedding kernels need tensors on a ROCm device; there is no CPU fallback")
+    if not t.is_contiguous():
+        raise RuntimeError("TT embedding kernels need contiguous tensors")
+    return t.data_ptr() if t.numel() > 0 else None
+
+
+def _ptr_array(ts: Sequence[torch.Tensor]):
+    arr = (ctypes.c_void_p * MAX_CORES)()
+    for i, t in enumerate(ts):
+        if t.dtype != torch.float32:
+            raise RuntimeError("TT cores must be float32")
+        arr[i] = _ptr(t)
+    return arr
+
+
+def _stream(ref: torch.Tensor) -> int:
+    return torch.cuda.current_stream(ref.device).cuda_stream
+
+
+class Workspace:
+    """Grow-only scratch buffer owned by the caller (the library never allocates)."""
+
+    def __init__(self) -> None:
+        self.buf: Optional[torch.Tensor] = None
+
+    def get(self, nbytes: int, device: torch.device) -> torch.Tensor:
+        nbytes = max(int(nbytes), 256)
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = torch.empty(nbytes + nbytes // 4, dtype=torch.uint8, device=device)
+        return self.buf
+
+
+def set_path(path: int) -> None:
+    _check(LIB.ttemb_set_path(path))
+
+
+def profile_enable(on: bool) -> None:
+    _check(LIB.ttemb_profile_enable(1 if on else 0))
+
+
+def profile_read(which: int) -> float:
+    """Milliseconds of the most recent forward (0) / backward (1) chain kernel."""
+    ms = ctypes.c_float(0.0)
+    _check(LIB.ttemb_profile_read(which, ctypes.byref(ms)))
+    return float(ms.value)
+
+
+def workspace_bytes(shape: Optional[Shape], op: int, nnz: int, B: int) -> int:
+    n = LIB.ttemb_workspace_bytes(ctypes.byref(shape) if shape is not None else None, op, nnz, B)
+    if n < 0:
+        _check(int(n))
+    return int(n)
+
+
+def forward(shape: Shape, cores: Sequence[torch.Tensor], indices: torch.Tensor, rowidx: torch.Tensor,
+            offsets: Optional[torch.Tensor], nnz: int, nnz_dev: Optional[torch.Tensor], B: int,
+            output: torch.Tensor, ws: Workspace) -> None:
+    dev = output.device
+    w = ws.get(workspace_bytes(shape, OP_FORWARD, nnz, B), dev)
+    with torch.cuda.device(dev):
+        _check(LIB.ttemb_forward(ctypes.byref(shape), _ptr_array(cores), _ptr(indices), _ptr(rowidx),
+                                 _ptr(offsets), nnz, _ptr(nnz_dev), B, _ptr(output), _ptr(w), w.numel(),
+                                 _stream(output)))
+
+
+def backward_dense(shape: Shape, cores: Sequence[torch.Tensor], indices, rowidx, nnz: int, nnz_dev, B: int,
+                   d_output: torch.Tensor, d_cores: Sequence[torch.Tensor], ws: Workspace) -> None:
+    dev = d_output.device
+    w = ws.get(workspace_bytes(shape, OP_BACKWARD, nnz, B), dev)
+    with torch.cuda.device(dev):
+        _check(LIB.ttemb_backward_dense(ctypes.byref(shape), _ptr_array(cores), _ptr(indices), _ptr(rowidx),
+                                        nnz, _ptr(nnz_dev), B, _ptr(d_output), _ptr_array(d_cores), _ptr(w),
+                                        w.numel(), _stream(d_output)))
+
+
+def backward_sgd(shape: Shape, cores, indices, rowidx, nnz: int, nnz_dev, B: int, d_output, lr: float,
+                 ws: Workspace) -> None:
+    dev = d_output.device
+    w = ws.get(workspace_bytes(shape, OP_BACKWARD, nnz, B), dev)
+    with torch.cuda.device(dev):
+        _check(LIB.ttemb_backward_sgd(ctypes.byref(shape), _ptr_array(cores), _ptr(indices), _ptr(rowidx), nnz,
+                                      _ptr(nnz_dev), B, _ptr(d_output), lr, _ptr(w), w.numel(),
+                                      _stream(d_output)))
+
+
+def backward_adagrad(shape: Shape, cores, opt_state, indices, rowidx, nnz: int, nnz_dev, B: int, d_output,
+                     lr: float, eps: float, ws: Workspace) -> None:
+    dev = d_output.device
+    w = ws.get(workspace_bytes(shape, OP_BACKWARD, nnz, B), dev)
+    with torch.cuda.device(dev):
+        _check(LIB.ttemb_backward_adagrad(ctypes.byref(shape), _ptr_array(cores), _ptr_array(opt_state),
+                                          _ptr(indices), _ptr(rowidx), nnz, _ptr(nnz_dev), B, _ptr(d_output),
+                                          lr, eps, _ptr(w), w.numel(), _stream(d_output)))
+
+
+def sgd_step(weights: torch.Tensor, grads: torch.Tensor, lr: float) -> None:
+    with torch.cuda.device(weights.device):
+        _check(LIB.ttemb_sgd_step(_ptr(weights), _ptr(grads), weights.numel(), lr, _stream(weights)))
+
+
+def adagrad_step(weights, state, grads, lr: float, eps: float) -> None:
+    with torch.cuda.device(weights.device):
+        _check(LIB.ttemb_adagrad_step(_ptr(weights), _ptr(state), _ptr(grads), weights.numel(), lr, eps,
+                                      _stream(weights)))
+
+
+def cache_update(indices: torch.Tensor, hashtbl: torch.Tensor, cache_freq: torch.Tensor) -> None:
+    if indices.numel() == 0:
+        return
+    with torch.cuda.device(indices.device):
+        _check(LIB.ttemb_cache_update(_ptr(indices), indices.numel(), _ptr(hashtbl), _ptr(cache_freq),
+                                      hashtbl.numel(), _stream(indices)))
+
+
+def cache_populate(shape: Shape, cores, hashtbl, cache_freq, cache_state, cache_weight, ws: Workspace) -> None:
+    dev = hashtbl.device
+    H, C = hashtbl.numel(), cache_weight.shape[0]
+    w = ws.get(workspace_bytes(shape, OP_CACHE_POPULATE, H, C), dev)
+    with torch.cuda.device(dev):
+        _check(LIB.ttemb_cache_populate(ctypes.byref(shape), _ptr_array(cores), _ptr(hashtbl), _ptr(cache_freq),
+                                        _ptr(cache_state), H, _ptr(cache_weight), C, _ptr(w), w.numel(),
+                                        _stream(hashtbl)))
+
+
+def preprocess(indices, offsets, B: int, warmup: bool, hashtbl, cache_state, indices_out, rowidx_out,
+               cache_loc_out, nnz_tt_dev, ws: Workspace) -> None:
+    dev = indices.device
+    nnz = indices.numel()
+    H = 0 if hashtbl is None else hashtbl.numel()
+    need = 0 if (warmup or H == 0) else workspace_bytes(None, OP_PREPROCESS, nnz, B)
+    w = ws.get(need, dev)
+    with torch.cuda.device(dev):
+        _check(LIB.ttemb_preprocess(_ptr(indices), _ptr(offsets), nnz, B, 1 if warmup else 0, _ptr(hashtbl),
+                                    _ptr(cache_state), H, _ptr(indices_out), _ptr(rowidx_out),
+                                    _ptr(cache_loc_out), _ptr(nnz_tt_dev), _ptr(w), w.numel(),
+                                    _stream(indices)))
+
+
+def cache_forward(cache_loc, rowidx, start: int, start_dev, nnz: int, cache_weight, output) -> None:
+    with torch.cuda.device(output.device):
+        _check(LIB.ttemb_cache_forward(_ptr(cache_loc), _ptr(rowidx), start, _ptr(start_dev), nnz,
+                                       _ptr(cache_weight), cache_weight.shape[1], _ptr(output),
+                                       _stream(output)))
+
+
+def cache_backward_sgd(cache_loc, rowidx, start: int, start_dev, nnz: int, d_output, lr: float,
+                       cache_weight) -> None:
+    with torch.cuda.device(d_output.device):
+        _check(LIB.ttemb_cache_backward_sgd(_ptr(cache_loc), _ptr(rowidx), start, _ptr(start_dev), nnz,
+                                            _ptr(d_output), cache_weight.shape[1], lr, _ptr(cache_weight),
+                                            _stream(d_output)))
+
+
+def cache_backward_dense(cache_loc, rowidx, start: int, start_dev, nnz: int, d_output,
+                         d_cache_weight) -> None:
+    with torch.cuda.device(d_output.device):
+        _check(LIB.ttemb_cache_backward_dense(_ptr(cache_loc), _ptr(rowidx), start, _ptr(start_dev), nnz,
+                                              _ptr(d_output), d_cache_weight.shape[1],
+                                              d_cache_weight.shape[0], _ptr(d_cache_weight),
+                                              _stream(d_output)))
+
+
+def cache_backward_rowwise_adagrad(cache_loc, rowidx, start: int, start_dev, nnz: int, d_output, lr: float,
+                                   eps: float, state_sum, cache_weight) -> None:
+    with torch.cuda.device(d_output.device):
+        _check(LIB.ttemb_cache_backward_rowwise_adagrad(_ptr(cache_loc), _ptr(rowidx), start, _ptr(start_dev),
+                                                        nnz, _ptr(d_output), cache_weight.shape[1], lr, eps,
+                                                        _ptr(state_sum), _ptr(cache_weight),
+                                                        _stream(d_output)))
+
+
+def core_views(tt_cores: Sequence[torch.Tensor], table: int = 0) -> List[torch.Tensor]:
+    """[num_tables, p_t, row] parameters -> contiguous per-table [p_t, row] views."""
+    out = []
+    for c in tt_cores:
+        v = c.data if isinstance(c, torch.nn.Parameter) else c
+        v = v[table] if v.dim() == 3 else v
+        if not v.is_contiguous():
+            raise RuntimeError("tt_cores must be contiguous")
+        out.append(v)
+    return out

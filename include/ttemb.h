@@ -1,0 +1,195 @@
+/*
+ * ttemb.h -- C ABI of libttemb_hip.so: the MI355X (gfx950) Tensor-Train embedding
+ * hot path.
+ *
+ * Every entry point replaces one function of the reference's pybind module
+ * `tt_embeddings` (FBTT/tt_embeddings.cpp:131-161); the replaced interface is cited
+ * per function.  The boundary is plain C: raw device pointers, explicit sizes, an
+ * opaque `hipStream_t` passed as `void*`, a caller-provided workspace.  No global
+ * state, no allocation, no host synchronisation unless a function says so.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless the name ends in `_host`;
+ *   - cores[t] is float32 [p_t][R_t*q_t*R_{t+1}] row-major, a core row being a
+ *     row-major [R_t][q_t][R_{t+1}] block (FBTT/tt_embeddings_ops.py:528-545);
+ *   - ids are int64, decomposed with L = [p1*p2.., .., 1] by repeated div/mod
+ *     (FBTT/tt_embeddings_cuda.cu:796-802);
+ *   - `rowidx[n]` is the bag (output row) of position n, non-decreasing inside the
+ *     TT part and inside the cached part (what preprocess produces);
+ *   - return value: 0 = ok, <0 = error (TTEMB_E_*), text via ttemb_last_error().
+ */
+#ifndef TTEMB_H_
+#define TTEMB_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TTEMB_ABI_VERSION 1
+#define TTEMB_MAX_CORES 4
+
+enum {
+  TTEMB_OK = 0,
+  TTEMB_E_BADARG = -1,     /* shape / size / null-pointer check failed            */
+  TTEMB_E_WORKSPACE = -2,  /* workspace too small (see ttemb_workspace_bytes)      */
+  TTEMB_E_UNSUPPORTED = -3,/* shape outside what the kernels support               */
+  TTEMB_E_HIP = -4         /* a HIP runtime call failed (message has the detail)   */
+};
+
+/* TT factorisation of one table.  R has T+1 entries with R[0] = R[T] = 1. */
+typedef struct ttemb_shape {
+  int32_t T;                    /* number of cores, 2..4                          */
+  int32_t p[TTEMB_MAX_CORES];   /* row factors,    prod(p) >= num_embeddings       */
+  int32_t q[TTEMB_MAX_CORES];   /* column factors, prod(q) == D, D % 4 == 0        */
+  int32_t R[TTEMB_MAX_CORES + 1];
+} ttemb_shape_t;
+
+/* Which computation a workspace is being sized for. */
+enum {
+  TTEMB_OP_FORWARD = 0,
+  TTEMB_OP_BACKWARD = 1,        /* dense / sgd / adagrad all use the same size    */
+  TTEMB_OP_PREPROCESS = 2,
+  TTEMB_OP_CACHE_POPULATE = 3   /* nnz = hashtbl_size, B = cache rows              */
+};
+
+/* Kernel-selection knob for forward/backward (tests drive both; 0 is the default). */
+enum {
+  TTEMB_PATH_AUTO = 0,          /* fastest path the shape supports                 */
+  TTEMB_PATH_GENERIC = 1,       /* shape-generic wave-per-id kernels (T = 2..4)    */
+  TTEMB_PATH_FAST3 = 2          /* sorted / grouped MFMA path, T == 3 only         */
+};
+
+int ttemb_abi_version(void);
+const char* ttemb_last_error(void);   /* thread-local, valid until the next call  */
+
+/* Bytes of scratch the op needs for `nnz` ids and `B` bags (0 is a valid answer). */
+int64_t ttemb_workspace_bytes(const ttemb_shape_t* shape, int32_t op, int64_t nnz, int64_t B);
+
+/* Select the kernel family used by the calling thread's later calls (TTEMB_PATH_*). */
+int ttemb_set_path(int32_t path);
+
+/* Measurement hook (bench.py's roofline leg).  While enabled for the calling thread, the
+ * main chain kernel of every ttemb_forward / ttemb_backward_* call is bracketed by
+ * hipEvents on the call's stream.  ttemb_profile_read waits for the most recent bracket of
+ * `which` (0 = forward chain kernel, 1 = backward chain kernel) and returns its
+ * duration in milliseconds.  Off by default; costs two event records per call when on. */
+int ttemb_profile_enable(int32_t on);
+int ttemb_profile_read(int32_t which, float* ms_host);
+
+/* ---------------------------------------------------------------------------------
+ * tt_forward  (replaces tt_embeddings.tt_forward -- FBTT/tt_embeddings.cpp:132,
+ * tt_embeddings_forward_cuda FBTT/tt_embeddings_cuda.cu:967-1081).
+ * output[B][D] is fully written: bag sums of the TT rows of indices[0:nnz], zeros
+ * for bags with no id in that range.  `nnz_dev`, when non-null, points at a device
+ * int32 holding the live count (<= nnz); the launch is sized by nnz and the kernels
+ * read the count themselves, so no host sync is needed after ttemb_preprocess.
+ * `offsets` (int64[B+1]) may be passed when indices[0:nnz] are exactly the concatenated
+ * bags (no cache partition): then only bags whose length is not 1 are zero-filled before
+ * the lookups; with offsets == NULL the whole output is zero-filled first.
+ * There is no batch_count chunking: intermediates never leave the chip.
+ * ------------------------------------------------------------------------------- */
+int ttemb_forward(const ttemb_shape_t* shape, const float* const* cores,
+                  const int64_t* indices, const int64_t* rowidx, const int64_t* offsets,
+                  int64_t nnz, const int32_t* nnz_dev, int64_t B, float* output,
+                  void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * tt_dense_backward  (tt_embeddings.tt_dense_backward -- tt_embeddings.cpp:133-136,
+ * tt_embeddings_cuda.cu:656-686, 421-654).  d_cores[t] (same shape as cores[t]) is
+ * overwritten with the gradient of sum(output * d_output) w.r.t. cores[t].
+ * ------------------------------------------------------------------------------- */
+int ttemb_backward_dense(const ttemb_shape_t* shape, const float* const* cores,
+                         const int64_t* indices, const int64_t* rowidx, int64_t nnz,
+                         const int32_t* nnz_dev, int64_t B, const float* d_output,
+                         float* const* d_cores,
+                         void* workspace, int64_t workspace_bytes, void* stream);
+
+/* tt_sgd_backward (tt_embeddings.cpp:137-138, tt_embeddings_cuda.cu:688-719):
+ * cores[t] -= lr * d_core_t, every row (the reference's grid defect at :633-651 is
+ * not reproduced).  The gradient lives in the workspace only. */
+int ttemb_backward_sgd(const ttemb_shape_t* shape, float* const* cores,
+                       const int64_t* indices, const int64_t* rowidx, int64_t nnz,
+                       const int32_t* nnz_dev, int64_t B, const float* d_output, float lr,
+                       void* workspace, int64_t workspace_bytes, void* stream);
+
+/* tt_adagrad_backward (tt_embeddings.cpp:139-142, tt_embeddings_cuda.cu:721-754,
+ * 399-419): state += g*g ; core -= lr * g / (sqrt(state) + eps). */
+int ttemb_backward_adagrad(const ttemb_shape_t* shape, float* const* cores,
+                           float* const* opt_state,
+                           const int64_t* indices, const int64_t* rowidx, int64_t nnz,
+                           const int32_t* nnz_dev, int64_t B, const float* d_output,
+                           float lr, float eps,
+                           void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Flat optimiser epilogues over n floats (used after the data-parallel all-reduce of
+ * the flattened core gradients; same arithmetic as tt_embeddings_cuda.cu:381-419). */
+int ttemb_sgd_step(float* weights, const float* grads, int64_t n, float lr, void* stream);
+int ttemb_adagrad_step(float* weights, float* state, const float* grads, int64_t n,
+                       float lr, float eps, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * LFU hash-table cache.
+ * update_cache_state (tt_embeddings.cpp:144, tt_embeddings_cuda.cu:1083-1119):
+ * insert every id with count+1 (Murmur3-style hash, <=3 linear probes, 64-bit CAS;
+ * hashtbl_cuda_utils.cuh:48-133).  hashtbl/cache_freq are int64[H].
+ * ------------------------------------------------------------------------------- */
+int ttemb_cache_update(const int64_t* indices, int64_t nnz, int64_t* hashtbl,
+                       int64_t* cache_freq, int64_t H, void* stream);
+
+/* cache_populate (tt_embeddings.cpp:145, tt_embeddings_cuda.cu:1270-1347): stable
+ * descending sort of the H slots by frequency, keep ranks < C (cache_state[slot] =
+ * rank), evict the rest, fill cache_weight[C][D] with the TT rows of the kept ids
+ * (empty ranks stand for id 0, as in the reference). */
+int ttemb_cache_populate(const ttemb_shape_t* shape, const float* const* cores,
+                         int64_t* hashtbl, int64_t* cache_freq, int32_t* cache_state,
+                         int64_t H, float* cache_weight, int64_t C,
+                         void* workspace, int64_t workspace_bytes, void* stream);
+
+/* preprocess_indices_sync (tt_embeddings.cpp:146-149, tt_embeddings_cuda.cu:1388-1507),
+ * single table.  Always writes rowidx_out[nnz] from offsets[B+1].  With warmup != 0
+ * (or H == 0) indices are passed through (indices_out may alias indices or be null) and
+ * *nnz_tt_dev = nnz.  Otherwise ids are looked up in the cache and (indices, rowidx,
+ * cache_loc) are partitioned: TT ids first in input order, cached ids from the end
+ * backwards (the CUB DevicePartition::Flagged order); *nnz_tt_dev = #TT ids.
+ * Does NOT synchronise: the count stays on the device (pass it to the other entry
+ * points as nnz_dev, or copy it back yourself). */
+int ttemb_preprocess(const int64_t* indices, const int64_t* offsets, int64_t nnz, int64_t B,
+                     int32_t warmup, const int64_t* hashtbl, const int32_t* cache_state,
+                     int64_t H, int64_t* indices_out, int64_t* rowidx_out,
+                     int32_t* cache_loc_out, int32_t* nnz_tt_dev,
+                     void* workspace, int64_t workspace_bytes, void* stream);
+
+/* cache_forward (tt_embeddings.cpp:151, tt_embeddings_cuda.cu:1509-1583):
+ * output[rowidx[n]] += cache_weight[cache_loc[n]] for n in [start, nnz).  `start` is
+ * the host value, or *start_dev when start_dev is non-null. */
+int ttemb_cache_forward(const int32_t* cache_loc, const int64_t* rowidx, int64_t start,
+                        const int32_t* start_dev, int64_t nnz, const float* cache_weight,
+                        int64_t D, float* output, void* stream);
+
+/* cache_backward_sgd (tt_embeddings.cpp:152, tt_embeddings_cuda.cu:1585-1668):
+ * cache_weight[loc] -= lr * d_output[row]. */
+int ttemb_cache_backward_sgd(const int32_t* cache_loc, const int64_t* rowidx, int64_t start,
+                             const int32_t* start_dev, int64_t nnz, const float* d_output,
+                             int64_t D, float lr, float* cache_weight, void* stream);
+
+/* cache_backward_dense (tt_embeddings.cpp:153-156, tt_embeddings_cuda.cu:1670-1744):
+ * d_cache_weight[C][D] is zero-filled, then d_cache_weight[loc] += d_output[row]. */
+int ttemb_cache_backward_dense(const int32_t* cache_loc, const int64_t* rowidx, int64_t start,
+                               const int32_t* start_dev, int64_t nnz, const float* d_output,
+                               int64_t D, int64_t C, float* d_cache_weight, void* stream);
+
+/* cache_backward_rowwise_adagrad_approx (tt_embeddings.cpp:157-160,
+ * tt_embeddings_cuda.cu:1746-1846): per id, g2 = mean(d_output[row]^2);
+ * old = atomic_add(state[loc], g2); cache_weight[loc] -= lr/(sqrt(old+g2)+eps) * d_output[row]. */
+int ttemb_cache_backward_rowwise_adagrad(const int32_t* cache_loc, const int64_t* rowidx,
+                                         int64_t start, const int32_t* start_dev, int64_t nnz,
+                                         const float* d_output, int64_t D, float lr, float eps,
+                                         float* cache_state_sum, float* cache_weight,
+                                         void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TTEMB_H_ */

@@ -1,0 +1,47 @@
+"""Shared test plumbing: path setup, the `gpu` marker, golden-vector loading."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "falcon-ttdforgnns_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+TINY_CASES = ["tt_tiny_T2", "tt_tiny_T3", "tt_tiny_T4", "tt_small_prodshape", "tt_small_arxivshape",
+              "tt_small_papershape"]
+ROW_CASES = ["rows_arxiv", "rows_products", "rows_papers"]
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+
+
+def golden_cores(g):
+    T = len(g["p"])
+    return [g[f"core{t}"] for t in range(T)]
+
+
+def seeded_cores(p, q, R, seed, scale):
+    """Same generator as tests/golden/make_golden.py::seeded_cores."""
+    rng = np.random.default_rng(int(seed))
+    cores = []
+    for t in range(len(p)):
+        c = rng.standard_normal((int(p[t]), int(R[t] * q[t] * R[t + 1]))).astype(np.float32)
+        cores.append(c * np.float32(scale))
+    return cores
+
+
+@pytest.fixture(scope="session")
+def has_gpu():
+    import torch
+    return torch.cuda.is_available()

@@ -1,0 +1,298 @@
+"""GPU: the drop-in module (FBTT.tt_embeddings_ops.TTEmbeddingBag), the `tt_embeddings`
+extension shim and the LFU cache, following the recipe of the reference's (gutted) unit
+tests: forward == EmbeddingBag(sum) over full_weight(); dense grads == autograd through
+tt_matrix_to_full; fused SGD/Adagrad == closed form (sage_profiler.py:262-500)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available()
+    import FBTT.tt_embeddings_ops as m
+    return m
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import tt_oracle
+    return tt_oracle
+
+
+def ragged(rng, B, n_emb, mean_len):
+    lens = np.clip(np.round(rng.normal(mean_len, mean_len, B)), 0, None).astype(np.int64)
+    idx = rng.integers(0, n_emb, size=int(lens.sum()), dtype=np.int64)
+    return torch.tensor(idx).cuda(), torch.tensor(np.concatenate([[0], np.cumsum(lens)])).cuda()
+
+
+def reference_bag(full, idx, offs):
+    return torch.nn.functional.embedding_bag(idx, full, offs, mode="sum", include_last_offset=True)
+
+
+SHAPES = [
+    ([7, 9, 11], [4, 5, 5], [16, 16]),
+    ([7, 9, 11, 5], [2, 2, 5, 4], [5, 6, 3]),
+    ([40, 50], [4, 8], [12]),
+    ([10, 12, 9], [4, 4, 8], [8, 8]),
+]
+
+
+@pytest.mark.parametrize("p,q,r", SHAPES)
+def test_forward_equals_embedding_bag_over_full_weight(ops, p, q, r):
+    torch.manual_seed(1)
+    n, D = int(np.prod(p)), int(np.prod(q))
+    emb = ops.TTEmbeddingBag(n, D, r, p, q, sparse=False, use_cache=False, weight_dist="uniform")
+    for c in emb.tt_cores:
+        c.data.mul_(3.0)
+    idx, offs = ragged(np.random.default_rng(0), 97, n, 5.0)
+    out = emb(idx, offs)
+    want = reference_bag(emb.full_weight(), idx, offs)
+    assert out.shape == want.shape
+    torch.testing.assert_close(out, want, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("p,q,r", SHAPES)
+def test_backward_dense_equals_autograd_through_full_weight(ops, p, q, r):
+    torch.manual_seed(2)
+    n, D = int(np.prod(p)), int(np.prod(q))
+    emb = ops.TTEmbeddingBag(n, D, r, p, q, sparse=False, use_cache=False, weight_dist="uniform")
+    for c in emb.tt_cores:
+        c.data.mul_(3.0)
+    idx, offs = ragged(np.random.default_rng(1), 97, n, 5.0)
+    clones = [c.detach().clone().requires_grad_(True) for c in emb.tt_cores]
+    full = ops.tt_matrix_to_full(p, q, r, clones, [1, 0, 2, 3])
+    out = emb(idx, offs)
+    d_out = torch.rand_like(out) * 0.1
+    out.backward(d_out)
+    reference_bag(full, idx, offs).backward(d_out)
+    for a, b in zip(emb.tt_cores, clones):
+        assert a.grad.shape == a.shape
+        torch.testing.assert_close(a.grad, b.grad, rtol=1e-3, atol=1e-4 * float(b.grad.abs().max()))
+
+
+@pytest.mark.parametrize("optimizer", ["SGD", "EXACT_ADAGRAD"])
+def test_sparse_mode_updates_in_backward(ops, optimizer):
+    torch.manual_seed(3)
+    p, q, r = [7, 9, 11], [4, 5, 5], [16, 16]
+    n, D = int(np.prod(p)), int(np.prod(q))
+    lr, eps = 0.05, 1e-10
+    emb = ops.TTEmbeddingBag(n, D, r, p, q, sparse=True, use_cache=False, weight_dist="uniform",
+                             optimizer=getattr(ops.OptimType, optimizer), learning_rate=lr, eps=eps)
+    for c in emb.tt_cores:
+        c.data.mul_(3.0)
+    before = [c.detach().clone() for c in emb.tt_cores]
+    clones = [c.detach().clone().requires_grad_(True) for c in emb.tt_cores]
+    idx, offs = ragged(np.random.default_rng(2), 64, n, 4.0)
+    out = emb(idx, offs)
+    d_out = torch.rand_like(out) * 0.1
+    out.backward(d_out)
+    reference_bag(ops.tt_matrix_to_full(p, q, r, clones, [1, 0, 2, 3]), idx, offs).backward(d_out)
+    for t, (c, b, ref) in enumerate(zip(emb.tt_cores, before, clones)):
+        assert c.grad is None  # autograd sees no gradient in sparse mode
+        if optimizer == "SGD":
+            torch.testing.assert_close(c.data, b - lr * ref.grad, rtol=0, atol=1e-5)
+        else:
+            st = emb.optimizer_state[t]
+            torch.testing.assert_close(st, ref.grad ** 2, rtol=2e-3, atol=1e-4 * float((ref.grad ** 2).max()))
+            big = ref.grad.abs() > 1e-3 * ref.grad.abs().max()
+            want = b - lr * ref.grad / (ref.grad.abs() + eps)
+            torch.testing.assert_close(c.data[big], want[big], rtol=0, atol=1e-5)
+            assert torch.equal(c.data[ref.grad == 0], b[ref.grad == 0])
+
+
+def test_table_batched(ops):
+    torch.manual_seed(4)
+    p, q, r = [10, 12, 9], [4, 4, 8], [8, 8]
+    n, D, Tn, B = int(np.prod(p)), int(np.prod(q)), 3, 20
+    emb = ops.TableBatchedTTEmbeddingBag(Tn, n, D, r, p, q, sparse=False, use_cache=False, weight_dist="normal")
+    for c in emb.tt_cores:
+        c.data.mul_(50.0)
+    idx, offs = ragged(np.random.default_rng(3), Tn * B, n, 3.0)
+    out = emb(idx, offs)
+    assert tuple(out.shape) == (Tn, B, D)
+    d_out = torch.rand_like(out)
+    out.backward(d_out)
+    bounds = offs[::B].tolist()
+    for k in range(Tn):
+        clones = [c.detach()[k:k + 1].clone().requires_grad_(True) for c in emb.tt_cores]
+        full = ops.tt_matrix_to_full(p, q, r, clones, [1, 0, 2, 3])
+        o = reference_bag(full, idx[bounds[k]:bounds[k + 1]], offs[k * B:(k + 1) * B + 1] - bounds[k])
+        torch.testing.assert_close(out[k], o, rtol=1e-4, atol=1e-5)
+        o.backward(d_out[k])
+        for a, b in zip(emb.tt_cores, clones):
+            torch.testing.assert_close(a.grad[k:k + 1], b.grad, rtol=1e-3, atol=1e-4 * float(b.grad.abs().max()))
+
+
+def test_extension_shim_signatures(ops, orc):
+    import tt_embeddings as ext
+    torch.manual_seed(5)
+    p, q, r = [7, 9, 11], [4, 5, 5], [1, 16, 16, 1]
+    n, D = int(np.prod(p)), 100
+    cores = [torch.randn(1, p[t], r[t] * q[t] * r[t + 1], device="cuda") * 0.3 for t in range(3)]
+    L = torch.tensor([99, 11, 1], device="cuda")
+    idx, offs = ragged(np.random.default_rng(4), 50, n, 3.0)
+    B = offs.numel() - 1
+    hashtbl = torch.empty(0, dtype=torch.int64, device="cuda")
+    state = torch.empty(0, dtype=torch.int32, device="cuda")
+    i2, rowidx, tableidx, ntt, loc = ext.preprocess_indices_sync(idx, offs, 1, True, hashtbl, state)
+    assert ntt == idx.numel() and loc is None and (tableidx == 0).all()
+    out = ext.tt_forward(1000, 1, B, D, p, q, r, L, ntt, i2, rowidx, tableidx, cores)
+    np_cores = [c[0].cpu().numpy() for c in cores]
+    want = orc.tt_forward(idx.cpu().numpy(), offs.cpu().numpy(), np_cores, p, q, r)
+    np.testing.assert_allclose(out[0].cpu().numpy(), want, rtol=1e-5, atol=1e-4)
+    d_out = torch.rand(1, B, D, device="cuda") * 0.1
+    grads = ext.tt_dense_backward(1000, D, p, q, r, L, ntt, i2, rowidx, tableidx, d_out, cores)
+    want_g = orc.tt_dense_backward(idx.cpu().numpy(), offs.cpu().numpy(), d_out[0].cpu().numpy(), np_cores, p, q, r)
+    for a, b in zip(grads, want_g):
+        assert tuple(a.shape) == (1,) + b.shape
+        np.testing.assert_allclose(a[0].cpu().numpy(), b, rtol=1e-3, atol=1e-4 * np.abs(b).max())
+    before = [c.clone() for c in cores]
+    ext.tt_sgd_backward(1000, D, 0.1, p, q, r, L, ntt, i2, rowidx, tableidx, d_out, cores)
+    for c, b, g in zip(cores, before, grads):
+        torch.testing.assert_close(c, b - 0.1 * g, rtol=0, atol=1e-5)
+    with pytest.raises(RuntimeError):
+        ext.tt_forward(0, 1, B, D, p, q, r, L, ntt, i2, rowidx, tableidx, cores)  # batch_count <= 0
+    with pytest.raises(RuntimeError):
+        ext.tt_forward(10, 1, B, 98, p, [2, 7, 7], r, L, ntt, i2, rowidx, tableidx, cores)  # D % 4 != 0
+
+
+# ---------------------------------------------------------------------------------------
+# LFU cache
+# ---------------------------------------------------------------------------------------
+def test_hash_table_matches_oracle_bit_exactly(ops, orc):
+    import ttemb_native as nat
+    rng = np.random.default_rng(6)
+    H = 4099
+    ids = rng.choice(10 ** 7, size=600, replace=False).astype(np.int64)
+    ids = np.concatenate([ids, np.array([2 ** 40 + 5, 2 ** 31, 2 ** 32 + 1], dtype=np.int64)])
+    # keep only ids whose probe windows are disjoint, so the final table is order-independent
+    used, keep = set(), []
+    for k in ids.tolist():
+        s = orc.murmur_slot(k, H)
+        win = {(s + j) % H for j in range(-3, 4)}
+        if not (win & used):
+            used |= win
+            keep.append(k)
+    keep = np.array(keep, dtype=np.int64)
+    stream = np.repeat(keep, rng.integers(1, 6, size=keep.shape[0]))
+    rng.shuffle(stream)
+    keys = torch.full((H,), -1, dtype=torch.int64, device="cuda")
+    freq = torch.zeros(H, dtype=torch.int64, device="cuda")
+    nat.cache_update(torch.tensor(stream).cuda(), keys, freq)
+    o_keys, o_freq = np.full(H, -1, dtype=np.int64), np.zeros(H, dtype=np.int64)
+    assert orc.update_cache_state(stream, o_keys, o_freq) == 0
+    assert np.array_equal(keys.cpu().numpy(), o_keys) and np.array_equal(freq.cpu().numpy(), o_freq)
+    # populate + lookup + partition, all integer: bit-exact against the oracle
+    p, q, R = [125, 140, 140], [4, 5, 5], [1, 16, 16, 1]
+    cores_np = [(rng.standard_normal((p[t], R[t] * q[t] * R[t + 1])) * 0.3).astype(np.float32) for t in range(3)]
+    cores = [torch.tensor(c).cuda() for c in cores_np]
+    C = 64
+    state = torch.full((H,), -1, dtype=torch.int32, device="cuda")
+    weight = torch.zeros(C, 100, device="cuda")
+    ws = nat.Workspace()
+    nat.cache_populate(nat.make_shape(p, q, R), cores, keys, freq, state, weight, ws)
+    o_state = np.full(H, -1, dtype=np.int32)
+    kept = orc.cache_populate(o_keys, o_freq, o_state, C)
+    assert np.array_equal(keys.cpu().numpy(), o_keys)
+    assert np.array_equal(freq.cpu().numpy(), o_freq)
+    assert np.array_equal(state.cpu().numpy(), o_state)
+    valid = kept < 125 * 140 * 140  # ids past prod(p) are outside the table (the kernels clamp them)
+    np.testing.assert_allclose(weight.cpu().numpy()[valid], orc.tt_rows(kept[valid], cores_np, p, q, R),
+                               rtol=1e-5, atol=1e-4)
+    probe = np.concatenate([kept[:20], keep[-20:], np.array([1, 2, 3], dtype=np.int64)])
+    rng.shuffle(probe)
+    lens = rng.integers(0, 4, size=30)
+    lens[-1] += probe.shape[0] - lens.sum() if lens.sum() <= probe.shape[0] else 0
+    if lens.sum() != probe.shape[0]:
+        lens = np.ones(probe.shape[0], dtype=np.int64)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    B = offs.shape[0] - 1
+    out_idx = torch.empty(probe.shape[0], dtype=torch.int64, device="cuda")
+    out_row = torch.empty_like(out_idx)
+    out_loc = torch.empty(probe.shape[0], dtype=torch.int32, device="cuda")
+    count = torch.zeros(1, dtype=torch.int32, device="cuda")
+    nat.preprocess(torch.tensor(probe).cuda(), torch.tensor(offs).cuda(), B, False, keys, state, out_idx,
+                   out_row, out_loc, count, ws)
+    pi, pr, ntt, ploc = orc.preprocess_indices(probe, offs, False, o_keys, o_state)
+    assert int(count.item()) == ntt
+    assert np.array_equal(out_idx.cpu().numpy(), pi) and np.array_equal(out_row.cpu().numpy(), pr)
+    assert np.array_equal(out_loc.cpu().numpy()[ntt:], ploc[ntt:])
+
+
+@pytest.mark.parametrize("sparse", [False, True])
+def test_cache_lifecycle_keeps_forward_and_trains(ops, orc, sparse):
+    torch.manual_seed(7)
+    rng = np.random.default_rng(7)
+    p, q, r = [20, 25, 30], [4, 5, 5], [16, 16]
+    n, D = int(np.prod(p)), 100
+    lr = 0.1
+    emb = ops.TTEmbeddingBag(n, D, r, p, q, sparse=sparse, use_cache=True, cache_size=200, hashtbl_size=n,
+                             weight_dist="normal", learning_rate=lr)
+    for c in emb.tt_cores:
+        c.data.mul_(40.0)
+    hot = rng.choice(n, size=150, replace=False)
+    for _ in range(5):  # warm-up epoch: everything goes the TT way, frequencies accumulate
+        batch = np.concatenate([rng.choice(hot, size=300), rng.integers(0, n, size=100)])
+        idx = torch.tensor(batch).cuda()
+        out = emb(idx, torch.arange(idx.numel() + 1).cuda())
+        assert emb.warmup
+    emb.cache_populate()
+    assert not emb.warmup
+    cached = emb.hashtbl[emb.cache_state >= 0]
+    assert 0 < cached.numel() <= 200
+    seen_hot = set(hot.tolist())
+    # the hottest ids are the cached ones (up to hash-insert failures)
+    assert len(seen_hot & set(cached.tolist())) >= 140
+    # forward is unchanged by switching the cache on (cache rows == TT rows at populate time)
+    batch = np.concatenate([rng.choice(hot, size=200), rng.integers(0, n, size=200)])
+    lens = rng.integers(0, 4, size=250)
+    lens = lens[np.cumsum(lens) <= batch.shape[0]]
+    batch = batch[: int(lens.sum())]
+    idx = torch.tensor(batch).cuda()
+    offs = torch.tensor(np.concatenate([[0], np.cumsum(lens)])).cuda()
+    cores_np = [c.detach()[0].cpu().numpy() for c in emb.tt_cores]
+    want = orc.tt_forward(batch, offs.cpu().numpy(), cores_np, p, q, [1] + r + [1])
+    cache_before = emb.cache_weight.detach().clone()
+    cores_before = [c.detach().clone() for c in emb.tt_cores]
+    out = emb(idx, offs)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), want, rtol=1e-5, atol=1e-4)
+    # backward: cached ids train cache_weight, the rest train the cores
+    d_out = (torch.rand_like(out) - 0.5) * 0.1
+    out.backward(d_out)
+    is_tt, loc = orc.cache_lookup(batch, emb.hashtbl.cpu().numpy(), emb.cache_state.cpu().numpy())
+    assert (~is_tt).sum() > 50 and is_tt.sum() > 50
+    rowidx = orc.rowidx_from_offsets(offs.cpu().numpy(), batch.shape[0])
+    g_cache = orc.cache_backward_dense(d_out.cpu().numpy(), loc[~is_tt], rowidx[~is_tt], 200, D)
+    # core grads come only from the TT part: rebuild that sub-batch for the oracle
+    tt_ids, tt_rows_ = batch[is_tt], rowidx[is_tt]
+    sub_offs = np.concatenate([[0], np.cumsum(np.bincount(tt_rows_, minlength=offs.numel() - 1))])
+    g_cores = orc.tt_dense_backward(tt_ids, sub_offs, d_out.cpu().numpy(), cores_np, p, q, [1] + r + [1])
+    if sparse:
+        np.testing.assert_allclose(emb.cache_weight.detach().cpu().numpy(),
+                                   cache_before.cpu().numpy() - lr * g_cache, rtol=0, atol=1e-5)
+        for c, b, g in zip(emb.tt_cores, cores_before, g_cores):
+            np.testing.assert_allclose(c.detach()[0].cpu().numpy(), b[0].cpu().numpy() - lr * g, rtol=0, atol=2e-5)
+    else:
+        np.testing.assert_allclose(emb.cache_weight.grad.cpu().numpy(), g_cache, rtol=1e-4, atol=1e-6)
+        for c, g in zip(emb.tt_cores, g_cores):
+            np.testing.assert_allclose(c.grad[0].cpu().numpy(), g, rtol=1e-3, atol=1e-4 * np.abs(g).max())
+
+
+def test_cache_rowwise_adagrad(ops, orc):
+    import ttemb_native as nat
+    rng = np.random.default_rng(8)
+    C, D, B = 50, 100, 40
+    w = rng.standard_normal((C, D)).astype(np.float32)
+    st = rng.random(C).astype(np.float32)
+    g = ((rng.random((B, D)) - 0.5) * 0.2).astype(np.float32)
+    loc = rng.choice(C, size=B, replace=False).astype(np.int32)  # distinct rows: the update is race-free
+    rowidx = np.arange(B, dtype=np.int64)
+    wt, stt = torch.tensor(w).cuda(), torch.tensor(st).cuda()
+    nat.cache_backward_rowwise_adagrad(torch.tensor(loc).cuda(), torch.tensor(rowidx).cuda(), 0, None, B,
+                                       torch.tensor(g).cuda(), 0.05, 1e-10, stt, wt)
+    w2, st2 = orc.cache_backward_rowwise_adagrad(g, loc, rowidx, 0.05, 1e-10, st, w)
+    np.testing.assert_allclose(stt.cpu().numpy(), st2, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(wt.cpu().numpy(), w2, rtol=1e-5, atol=1e-6)

@@ -1,0 +1,271 @@
+"""GPU parity: the HIP path (through the C ABI, via ttemb_native) against the golden
+vectors generated from the reference and against the CPU oracle on seeded inputs.
+
+Tolerances (north-star: forward within 1e-4 in fp32):
+  forward      atol 1e-4 (+ rtol 1e-5 for the O(10) magnitudes of the golden cores)
+  dense grads  rtol 1e-4 of the gradient's max magnitude (summation order differs)
+  fused steps  atol 1e-5 on the updated cores
+Integer work (index split, partition, hash) is compared bit-exactly.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROW_CASES, TINY_CASES, golden_cores, load_golden, seeded_cores
+
+pytestmark = pytest.mark.gpu
+
+PATHS = ["generic", "auto"]
+
+
+@pytest.fixture(scope="module")
+def nat():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    import ttemb_native
+    return ttemb_native
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import tt_oracle
+    return tt_oracle
+
+
+def dev(x, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(x))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def set_path(nat, path):
+    nat.set_path({"auto": nat.PATH_AUTO, "generic": nat.PATH_GENERIC, "fast3": nat.PATH_FAST3}[path])
+
+
+def run_forward(nat, p, q, R, cores, indices, offsets):
+    shape = nat.make_shape(p, q, R)
+    ws = nat.Workspace()
+    c = [dev(x) for x in cores]
+    idx, offs = dev(indices, torch.int64), dev(offsets, torch.int64)
+    B, nnz = offs.numel() - 1, idx.numel()
+    rowidx = torch.empty(nnz, dtype=torch.int64, device="cuda")
+    nat.preprocess(idx, offs, B, True, None, None, None, rowidx, None, None, ws)
+    out = torch.full((B, int(np.prod(q))), float("nan"), device="cuda")
+    nat.forward(shape, c, idx, rowidx, offs, nnz, None, B, out, ws)
+    torch.cuda.synchronize()
+    return out.cpu().numpy(), rowidx
+
+
+def run_backward_dense(nat, p, q, R, cores, indices, offsets, d_output):
+    shape = nat.make_shape(p, q, R)
+    ws = nat.Workspace()
+    c = [dev(x) for x in cores]
+    idx, offs = dev(indices, torch.int64), dev(offsets, torch.int64)
+    B, nnz = offs.numel() - 1, idx.numel()
+    rowidx = torch.empty(nnz, dtype=torch.int64, device="cuda")
+    nat.preprocess(idx, offs, B, True, None, None, None, rowidx, None, None, ws)
+    grads = [torch.full_like(x, float("nan")) for x in c]
+    nat.backward_dense(shape, c, idx, rowidx, nnz, None, B, dev(d_output), grads, ws)
+    torch.cuda.synchronize()
+    return [g.cpu().numpy() for g in grads]
+
+
+def assert_grads_close(got, want, rel=1e-4):
+    for t, (a, b) in enumerate(zip(got, want)):
+        scale = max(float(np.abs(b).max()), 1e-6)
+        err = float(np.abs(a - b).max())
+        assert err <= rel * scale + 1e-6, f"core {t}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+# ---------------------------------------------------------------------------------------
+# golden vectors (reference tt_matrix_to_full / autograd)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("name", TINY_CASES)
+def test_forward_golden(nat, name, path):
+    g = load_golden(name)
+    set_path(nat, path)
+    out, rowidx = run_forward(nat, g["p"], g["q"], g["R"], golden_cores(g), g["indices"], g["offsets"])
+    np.testing.assert_allclose(out, g["out"], rtol=1e-5, atol=1e-4)
+    from oracle import tt_oracle
+    assert (rowidx.cpu().numpy() == tt_oracle.rowidx_from_offsets(g["offsets"], g["indices"].shape[0])).all()
+
+
+@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("name", ROW_CASES)
+def test_rows_of_baseline_configs(nat, name, path):
+    g = load_golden(name)
+    set_path(nat, path)
+    cores = seeded_cores(g["p"], g["q"], g["R"], g["seed"], g["core_scale"])
+    n = g["indices"].shape[0]
+    out, _ = run_forward(nat, g["p"], g["q"], g["R"], cores, g["indices"], np.arange(n + 1))
+    np.testing.assert_allclose(out, g["rows"], rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("name", TINY_CASES)
+def test_backward_dense_golden(nat, name, path):
+    g = load_golden(name)
+    set_path(nat, path)
+    grads = run_backward_dense(nat, g["p"], g["q"], g["R"], golden_cores(g), g["indices"], g["offsets"],
+                               g["d_output"])
+    assert_grads_close(grads, [g[f"grad{t}"] for t in range(len(grads))])
+
+
+@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("name", TINY_CASES)
+def test_fused_sgd_and_adagrad_golden(nat, name, path):
+    g = load_golden(name)
+    set_path(nat, path)
+    p, q, R = g["p"], g["q"], g["R"]
+    shape = nat.make_shape(p, q, R)
+    ws = nat.Workspace()
+    idx, offs = dev(g["indices"], torch.int64), dev(g["offsets"], torch.int64)
+    B, nnz = offs.numel() - 1, idx.numel()
+    rowidx = torch.empty(nnz, dtype=torch.int64, device="cuda")
+    nat.preprocess(idx, offs, B, True, None, None, None, rowidx, None, None, ws)
+    d_out = dev(g["d_output"])
+    c = [dev(x) for x in golden_cores(g)]
+    nat.backward_sgd(shape, c, idx, rowidx, nnz, None, B, d_out, float(g["lr"]), ws)
+    for t in range(len(c)):
+        np.testing.assert_allclose(c[t].cpu().numpy(), g[f"sgd{t}"], rtol=0, atol=1e-5)
+    c = [dev(x) for x in golden_cores(g)]
+    st = [torch.zeros_like(x) for x in c]
+    nat.backward_adagrad(shape, c, st, idx, rowidx, nnz, None, B, d_out, float(g["lr"]), float(g["eps"]), ws)
+    for t in range(len(c)):
+        want_state = g[f"ada_state{t}"]
+        np.testing.assert_allclose(st[t].cpu().numpy(), want_state, rtol=2e-4,
+                                   atol=1e-4 * float(np.abs(want_state).max()))
+        # rows the batch never touched have g == 0 exactly -> unchanged; touched entries move by
+        # lr * sign(g) on the first step (state == g^2), up to rounding of tiny gradients
+        got, want = c[t].cpu().numpy(), g[f"ada{t}"]
+        big = np.abs(g[f"grad{t}"]) > 1e-3 * np.abs(g[f"grad{t}"]).max()
+        np.testing.assert_allclose(got[big], want[big], rtol=0, atol=1e-5)
+        untouched = g[f"grad{t}"] == 0
+        assert (got[untouched] == golden_cores(g)[t][untouched]).all()
+
+
+# ---------------------------------------------------------------------------------------
+# seeded random inputs vs the CPU oracle
+# ---------------------------------------------------------------------------------------
+CONFIGS = {
+    "arxiv": ([56, 60, 51], [4, 4, 8], [1, 8, 8, 1], 169343),
+    "products": ([125, 140, 140], [4, 5, 5], [1, 16, 16, 1], 2449029),
+    "papers": ([500, 560, 400], [8, 4, 4], [1, 32, 32, 1], 111059956),
+    "two_core": ([300, 400], [8, 8], [1, 12, 1], 120000),
+    "four_core": ([20, 25, 30, 10], [2, 4, 4, 2], [1, 6, 10, 4, 1], 150000),
+}
+
+
+def random_case(cfg, n_bags, mean_len, seed, unique=False):
+    p, q, R, n_emb = CONFIGS[cfg]
+    rng = np.random.default_rng(seed)
+    cores = [(rng.standard_normal((p[t], R[t] * q[t] * R[t + 1])) * 0.3).astype(np.float32)
+             for t in range(len(p))]
+    if mean_len is None:
+        lens = np.ones(n_bags, dtype=np.int64)
+    else:
+        lens = np.clip(np.round(rng.normal(mean_len, mean_len, n_bags)), 0, None).astype(np.int64)
+    nnz = int(lens.sum())
+    if unique:
+        idx = rng.choice(n_emb, size=nnz, replace=False).astype(np.int64)
+    else:
+        idx = rng.integers(0, n_emb, size=nnz, dtype=np.int64)
+        if nnz > 10:  # force duplicates and the two extreme ids
+            idx[1] = idx[0]
+            idx[2] = 0
+            idx[3] = n_emb - 1
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    D = int(np.prod(q))
+    d_out = (rng.random((n_bags, D)).astype(np.float32) - 0.5) * 0.2
+    return p, q, R, cores, idx, offsets, d_out
+
+
+@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("cfg,n_bags,mean_len", [
+    ("arxiv", 256, None), ("products", 2048, None), ("products", 700, 4.0), ("papers", 512, None),
+    ("papers", 300, 3.0), ("two_core", 500, 2.0), ("four_core", 500, 2.0), ("products", 1, None),
+    ("products", 63, None), ("products", 65, 1.0),
+])
+def test_forward_backward_vs_oracle(nat, orc, cfg, n_bags, mean_len, path):
+    set_path(nat, path)
+    p, q, R, cores, idx, offsets, d_out = random_case(cfg, n_bags, mean_len, seed=sum(map(ord, cfg)) + n_bags)
+    out, _ = run_forward(nat, p, q, R, cores, idx, offsets)
+    want = orc.tt_forward(idx, offsets, cores, p, q, R)
+    np.testing.assert_allclose(out, want, rtol=1e-5, atol=1e-4)
+    grads = run_backward_dense(nat, p, q, R, cores, idx, offsets, d_out)
+    assert_grads_close(grads, orc.tt_dense_backward(idx, offsets, d_out, cores, p, q, R))
+
+
+@pytest.mark.parametrize("path", PATHS)
+def test_empty_and_degenerate_inputs(nat, orc, path):
+    set_path(nat, path)
+    p, q, R, _ = CONFIGS["products"]
+    _, _, _, cores, _, _, _ = random_case("products", 4, None, seed=5)
+    # no ids at all: output is all zeros, grads are all zeros
+    out, _ = run_forward(nat, p, q, R, cores, np.zeros(0, np.int64), np.zeros(6, np.int64))
+    assert out.shape == (5, 100) and (out == 0).all()
+    grads = run_backward_dense(nat, p, q, R, cores, np.zeros(0, np.int64), np.zeros(6, np.int64),
+                               np.ones((5, 100), np.float32))
+    assert all((g == 0).all() for g in grads)
+    # one bag holding every id, surrounded by empty bags
+    idx = np.array([7, 7, 7, 2449028, 0, 19600], dtype=np.int64)
+    offsets = np.array([0, 0, 6, 6], dtype=np.int64)
+    out, _ = run_forward(nat, p, q, R, cores, idx, offsets)
+    np.testing.assert_allclose(out, orc.tt_forward(idx, offsets, cores, p, q, R), rtol=1e-5, atol=1e-4)
+    assert (out[0] == 0).all() and (out[2] == 0).all()
+
+
+def test_flat_optimizer_steps(nat):
+    rng = np.random.default_rng(0)
+    for n in (1, 3, 4, 1000, 198400, 198403):
+        w = rng.standard_normal(n).astype(np.float32)
+        g = rng.standard_normal(n).astype(np.float32)
+        s = rng.random(n).astype(np.float32)
+        wt, gt = dev(w), dev(g)
+        nat.sgd_step(wt, gt, 0.05)
+        np.testing.assert_allclose(wt.cpu().numpy(), w - np.float32(0.05) * g, rtol=0, atol=1e-6)
+        wt, st = dev(w), dev(s)
+        nat.adagrad_step(wt, st, gt, 0.05, 1e-10)
+        s2 = s + g * g
+        np.testing.assert_allclose(st.cpu().numpy(), s2, rtol=1e-6)
+        np.testing.assert_allclose(wt.cpu().numpy(), w - np.float32(0.05) * g / (np.sqrt(s2) + np.float32(1e-10)),
+                                   rtol=1e-5, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------
+# full-size properties (BASELINE.json sizes; the oracle is too slow / big here)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("path", ["auto"])
+def test_full_size_properties_products(nat, orc, path):
+    set_path(nat, path)
+    p, q, R, n_emb = CONFIGS["products"]
+    rng = np.random.default_rng(77)
+    cores = [(rng.standard_normal((p[t], R[t] * q[t] * R[t + 1])) * 0.3).astype(np.float32) for t in range(3)]
+    N = 409600
+    idx = rng.choice(n_emb, size=N, replace=False).astype(np.int64)
+    out, _ = run_forward(nat, p, q, R, cores, idx, np.arange(N + 1))
+    # spot rows against the oracle
+    pick = rng.choice(N, size=512, replace=False)
+    np.testing.assert_allclose(out[pick], orc.tt_rows(idx[pick], cores, p, q, R), rtol=1e-5, atol=1e-4)
+    # permutation equivariance: looking ids up in another order permutes the rows, bit for bit
+    perm = rng.permutation(N)
+    out_p, _ = run_forward(nat, p, q, R, cores, idx[perm], np.arange(N + 1))
+    assert np.array_equal(out_p, out[perm])
+    # bag additivity: bags of 4 equal the sum of the 4 single rows
+    out4, _ = run_forward(nat, p, q, R, cores, idx, np.arange(0, N + 1, 4))
+    np.testing.assert_allclose(out4, out.reshape(-1, 4, 100).sum(1), rtol=1e-5, atol=2e-4)
+    # backward: linear in d_output, and consistent with a directional derivative of the forward
+    d1 = ((rng.random((N, 100)) - 0.5) * 0.1).astype(np.float32)
+    d2 = ((rng.random((N, 100)) - 0.5) * 0.1).astype(np.float32)
+    g1 = run_backward_dense(nat, p, q, R, cores, idx, np.arange(N + 1), d1)
+    g2 = run_backward_dense(nat, p, q, R, cores, idx, np.arange(N + 1), d2)
+    g12 = run_backward_dense(nat, p, q, R, cores, idx, np.arange(N + 1), d1 + d2)
+    assert_grads_close(g12, [a + b for a, b in zip(g1, g2)], rel=2e-4)
+    eps = 3e-3
+    direction = [rng.standard_normal(c.shape).astype(np.float32) for c in cores]
+    plus, _ = run_forward(nat, p, q, R, [c + eps * d for c, d in zip(cores, direction)], idx, np.arange(N + 1))
+    minus, _ = run_forward(nat, p, q, R, [c - eps * d for c, d in zip(cores, direction)], idx, np.arange(N + 1))
+    fd = float(((plus.astype(np.float64) - minus) * d1).sum() / (2 * eps))
+    an = float(sum((g.astype(np.float64) * d).sum() for g, d in zip(g1, direction)))
+    assert abs(fd - an) <= 2e-3 * max(abs(an), 1.0), (fd, an)

@@ -1,0 +1,154 @@
+"""CPU: host-side logic of the drop-in layer and the C-ABI library surface
+(no kernel is launched here; GPU parity lives in test_gpu_*.py)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+
+import ttemb_native as nat
+from FBTT.tt_embeddings_ops import (BufferList, OptimType, TableBatchedTTEmbeddingBag, TTEmbeddingBag,
+                                    suggested_tt_shapes, tt_matrix_to_full)
+from oracle import tt_oracle as orc
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "ttemb.h")).read()
+    declared = set(re.findall(r"\b(ttemb_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"ttemb_workspace_bytes"} - set(nat.EXPORTED_SYMBOLS)
+    assert declared == set(nat.EXPORTED_SYMBOLS)
+    lib = ctypes.CDLL(nat.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.ttemb_abi_version() == 1
+
+
+def test_abi_argument_validation_without_gpu():
+    lib = nat.LIB
+    s = nat.make_shape([3, 4, 5], [2, 3, 2], [4, 3])
+    s.T = 7
+    assert lib.ttemb_workspace_bytes(ctypes.byref(s), nat.OP_FORWARD, 10, 10) == -1
+    assert b"2..4" in lib.ttemb_last_error()
+    s = nat.make_shape([3, 4, 5], [2, 3, 3], [4, 3])  # D = 18, not a multiple of 4
+    assert lib.ttemb_workspace_bytes(ctypes.byref(s), nat.OP_BACKWARD, 10, 10) == -1
+    assert b"multiple of 4" in lib.ttemb_last_error()
+    s = nat.make_shape([125, 140, 140], [4, 5, 5], [16, 16])
+    assert lib.ttemb_workspace_bytes(ctypes.byref(s), nat.OP_BACKWARD, 2048, 2048) >= 198400 * 4
+    assert lib.ttemb_set_path(9) == -1
+    with pytest.raises(RuntimeError):
+        nat.make_shape([3, 4], [2, 2, 2], [4])
+
+
+def test_suggested_shapes_match_reference_answers():
+    t = load_golden("suggest_kat")["table"]
+    for row in t.tolist():
+        n, d, up = row[:3]
+        assert suggested_tt_shapes(n, d, allow_round_up=bool(up)) == row[3:3 + d]
+    assert suggested_tt_shapes(2449029, 3) == [125, 140, 140]
+    assert suggested_tt_shapes(100, 3) == [4, 5, 5]
+
+
+def test_tt_matrix_to_full_matches_oracle_and_is_differentiable():
+    g = load_golden("tt_tiny_T3")
+    cores = [torch.tensor(g[f"core{t}"]).unsqueeze(0).requires_grad_(True) for t in range(3)]
+    full = tt_matrix_to_full(g["p"].tolist(), g["q"].tolist(), g["R"].tolist(), cores, [1, 0, 2, 3])
+    ref = orc.tt_full_table([g[f"core{t}"] for t in range(3)], g["p"], g["q"], g["R"])
+    np.testing.assert_allclose(full.detach().numpy(), ref, rtol=1e-5, atol=1e-5)
+    out = torch.nn.functional.embedding_bag(torch.tensor(g["indices"]), full, torch.tensor(g["offsets"]),
+                                            mode="sum", include_last_offset=True)
+    out.backward(torch.tensor(g["d_output"]))
+    for t in range(3):
+        np.testing.assert_allclose(cores[t].grad[0].numpy(), g[f"grad{t}"], rtol=1e-4, atol=1e-5)
+    # un-permuted layout ([R, p, q, R'])
+    c2 = [torch.tensor(g[f"core{t}"]).reshape(g["p"][t], g["R"][t], g["q"][t], g["R"][t + 1]).permute(1, 0, 2, 3)
+          .contiguous() for t in range(3)]
+    full2 = tt_matrix_to_full(g["p"].tolist(), g["q"].tolist(), g["R"].tolist()[1:-1], c2)
+    np.testing.assert_allclose(full2.numpy(), ref, rtol=1e-5, atol=1e-5)
+
+
+def test_module_state_layout_matches_reference_contract():
+    m = TTEmbeddingBag(169343, 128, [8, 8], [56, 60, 51], [4, 4, 8], sparse=False, use_cache=True,
+                       cache_size=1000, hashtbl_size=5000, weight_dist="normal")
+    sd = m.state_dict()
+    assert sd["L"].tolist() == [60 * 51, 51, 1] and sd["L"].dtype == torch.int64
+    assert tuple(sd["tt_cores.0"].shape) == (1, 56, 32)
+    assert tuple(sd["tt_cores.1"].shape) == (1, 60, 8 * 4 * 8)
+    assert tuple(sd["tt_cores.2"].shape) == (1, 51, 64)
+    assert tuple(sd["optimizer_state.optimizer_state0"].shape) == (0,)
+    assert sd["hashtbl"].dtype == torch.int64 and sd["hashtbl"].numel() == 5000 and (sd["hashtbl"] == -1).all()
+    assert sd["cache_freq"].dtype == torch.int64 and (sd["cache_freq"] == 0).all()
+    assert sd["cache_state"].dtype == torch.int32 and (sd["cache_state"] == -1).all()
+    assert tuple(sd["cache_weight"].shape) == (1000, 128)
+    assert m.warmup is True and m.tt_ranks == [1, 8, 8, 1] and m.tt_ndim == 3
+    assert isinstance(m.tt_cores, torch.nn.ParameterList) and isinstance(m.optimizer_state, BufferList)
+    m2 = TTEmbeddingBag(1000, 16, [4, 4], optimizer=OptimType.EXACT_ADAGRAD, use_cache=True, weight_dist="uniform")
+    assert m2.tt_p_shapes == [10, 10, 10] and np.prod(m2.tt_q_shapes) == 16
+    assert tuple(m2.optimizer_state[1].shape) == tuple(m2.tt_cores[1].shape)
+    assert m2.cache_weight.shape[0] == 100 and m2.hashtbl.numel() == 1000  # defaults: 10 % / num_embeddings
+    assert tuple(m2.cache_optimizer_state.shape) == (100, 16)
+    m3 = TTEmbeddingBag(1000, 16, [4, 4], optimizer=OptimType.EXACT_ROWWISE_ADAGRAD, use_cache=True,
+                        weight_dist="uniform")
+    assert tuple(m3.cache_optimizer_state.shape) == (100,)
+    m4 = TableBatchedTTEmbeddingBag(3, 1000, 16, [4], [25, 40], [4, 4], weight_dist="naive-uniform")
+    assert tuple(m4.tt_cores[0].shape) == (3, 25, 16) and m4.cache_weight is None and m4.hashtbl.numel() == 0
+    # round trip
+    m5 = TTEmbeddingBag(169343, 128, [8, 8], [56, 60, 51], [4, 4, 8], sparse=False, use_cache=True,
+                        cache_size=1000, hashtbl_size=5000, weight_dist="normal")
+    m5.load_state_dict(sd)
+    assert torch.equal(m5.tt_cores[1].data, m.tt_cores[1].data)
+
+
+def test_constructor_asserts_like_reference():
+    with pytest.raises(AssertionError):
+        TTEmbeddingBag(1000, 16, [4, 4], [5, 5, 5], [2, 2, 4], weight_dist="normal")  # prod(p) < n
+    with pytest.raises(AssertionError):
+        TTEmbeddingBag(1000, 16, [4, 4], [10, 10, 10], [2, 2, 5], weight_dist="normal")  # prod(q) != D
+    with pytest.raises(AssertionError):
+        TTEmbeddingBag(1000, 16, [4], [10, 10, 10], [2, 2, 4], weight_dist="normal")  # rank count
+    with pytest.raises(AssertionError):
+        TableBatchedTTEmbeddingBag(2, 1000, 16, [4], [25, 40], [4, 4], use_cache=True, weight_dist="normal")
+    with pytest.raises(AssertionError):
+        TTEmbeddingBag(1000, 16, [4, 4], [10, 10, 10], [2, 2, 4], weight_dist="bogus")
+
+
+@pytest.mark.parametrize("dist", ["uniform", "naive-uniform", "normal", "approx-normal", "approx-uniform"])
+def test_initialisers(dist):
+    np.random.seed(0)
+    torch.manual_seed(0)
+    n = 27000
+    m = TTEmbeddingBag(n, 64, [8, 8], [30, 30, 30], [4, 4, 4], use_cache=False, weight_dist=dist)
+    cores = [c.detach().numpy() for c in m.tt_cores]
+    assert all(np.isfinite(c).all() for c in cores)
+    if dist == "normal":
+        for c in cores:
+            assert abs(c.std() - 1 / np.sqrt(n)) < 0.1 / np.sqrt(n) and abs(c.mean()) < 3e-4
+    elif dist == "naive-uniform":
+        for c in cores:
+            assert c.min() >= 0 and c.max() <= 1 / np.sqrt(n) and abs(c.mean() - 0.5 / np.sqrt(n)) < 1e-4
+    elif dist == "uniform":
+        hi = np.sqrt(2.0 / (n + 64)) ** (1 / 3) * np.prod(np.array([1, 8, 8, 1.0]) ** (-1 / 6))
+        for c in cores:
+            assert c.min() >= 0 and c.max() <= hi and c.max() > 0.95 * hi
+    elif dist == "approx-normal":
+        s = (1 / np.sqrt(3 * n)) ** (1 / 3)
+        for c in cores:
+            assert np.abs(c).min() >= 2 * s * (1 - 1e-6)
+    else:
+        # the product table should look roughly uniform on (-1, 1) / sqrt(n): mean |x| ~ 0.5 / sqrt(n)
+        full = m.full_weight().detach().numpy()
+        assert np.isfinite(full).all() and 0.3 < np.abs(full).mean() * np.sqrt(n) < 0.7
+
+
+def test_no_cpu_fallback():
+    m = TTEmbeddingBag(1000, 16, [4, 4], [10, 10, 10], [2, 2, 4], use_cache=False, weight_dist="normal")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.arange(4), torch.arange(5))
+
+
+def test_optimtype_values():
+    assert str(OptimType.SGD) == "sgd" and OptimType("exact_row_wise_adagrad") is OptimType.EXACT_ROWWISE_ADAGRAD
+    assert len(OptimType) == 9
