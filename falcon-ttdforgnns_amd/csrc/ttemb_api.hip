@@ -4,6 +4,7 @@
 #include "ttemb_common.h"
 #include "ttemb_cache.h"
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -11,7 +12,8 @@
 namespace ttemb {
 
 static thread_local char g_err[512] = "";
-static thread_local int g_path = TTEMB_PATH_AUTO;
+// process-wide on purpose: autograd runs backward on its own thread
+static std::atomic<int> g_path{TTEMB_PATH_AUTO};
 
 int fail(int code, const char* fmt, ...) {
   va_list ap;
@@ -26,11 +28,11 @@ int check_hip(hipError_t e, const char* what) {
   return fail(TTEMB_E_HIP, "%s: %s", what, hipGetErrorString(e));
 }
 
-int current_path() { return g_path; }
+int current_path() { return g_path.load(); }
 
-static thread_local bool g_prof_on = false;
-static thread_local hipEvent_t g_prof_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
-static thread_local bool g_prof_valid[2] = {false, false};
+static std::atomic<bool> g_prof_on{false};
+static hipEvent_t g_prof_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+static std::atomic<bool> g_prof_valid[2] = {{false}, {false}};
 
 void profile_begin(int which, hipStream_t st) {
   if (!g_prof_on) return;
@@ -185,12 +187,12 @@ const char* ttemb_last_error(void) { return g_err; }
 
 int ttemb_set_path(int32_t path) {
   if (path < TTEMB_PATH_AUTO || path > TTEMB_PATH_FAST3) return fail(TTEMB_E_BADARG, "unknown path %d", path);
-  g_path = path;
+  g_path.store(path);
   return TTEMB_OK;
 }
 
 int ttemb_profile_enable(int32_t on) {
-  g_prof_on = on != 0;
+  g_prof_on.store(on != 0);
   return TTEMB_OK;
 }
 

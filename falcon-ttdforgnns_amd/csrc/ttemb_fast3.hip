@@ -1,17 +1,372 @@
-// Sorted / grouped MFMA path for 3-core tables (placeholder: not yet enabled).
+// Sorted / grouped MFMA path for 3-core tables (the configuration every driver of the
+// reference uses: T == 3).
+//
+// Idea (prefix reuse, cf. the reference's unwired Efficient_TT/efficient_tt_cuda.cu:159-377,
+// done here without its global prefix cache, pointer arrays or host round trips):
+//   * ids are radix-sorted once per call, so ids that share (i0, i1) -- a "group" -- sit
+//     next to each other;
+//   * one wavefront walks a contiguous range of the sorted ids in chunks of <= 16 ids of one
+//     group.  Per group it forms the prefix product P = G0[i0] . G1[i1]  (q0 x q1 r2) with
+//     fp32 MFMA (v_mfma_f32_16x16x4_f32) and keeps it in LDS; per chunk it multiplies P
+//     (as a q0q1 x r2 matrix) with the chunk's stacked G2 rows (r2 x 16 q2) -- again fp32
+//     MFMA -- and writes whole D-float rows with 16-byte stores.
+// Stage 1 is therefore paid once per group instead of once per id, stage 2 runs as a real
+// GEMM (M = q0q1, K = r2, N = 16 q2), and partial products never touch HBM.
+//
+// fp32 MFMA is bit-for-bit a k-ordered fmaf chain (cdna_hip_programming.md §3), so results
+// agree with the generic kernel / the reference's fp32 GEMMs to rounding.
 #include "ttemb_common.h"
+#include "ttemb_cache.h"
+
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
 
 namespace ttemb {
 
-bool fast3_supported(const DevShape&) { return false; }
-int64_t fast3_workspace_bytes(const DevShape&, int32_t, int64_t, int64_t) { return 0; }
-int launch_forward_fast3(const DevShape&, const CorePtrs&, const int64_t*, const int64_t*, int64_t,
-                         const int32_t*, float*, void*, int64_t, hipStream_t) {
-  return fail(TTEMB_E_UNSUPPORTED, "fast3 path not built");
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kChunk = 16;        // ids per stage-2 GEMM (N = 16 * q2 columns)
+constexpr int kRange = 64;        // sorted ids walked by one wavefront
+constexpr uint32_t kMultiBit = 0x80000000u;
+
+template <int Q0, int Q1, int Q2, int R1, int R2>
+struct Cfg {
+  static constexpr int M2 = Q0 * Q1;             // rows of the stage-2 GEMM
+  static constexpr int MT2 = (M2 + 15) / 16;     // 16-row MFMA tiles of it
+  static constexpr int KS1 = R1 / 4;             // k-steps (K = 4 per MFMA)
+  static constexpr int KS2 = R2 / 4;
+  static constexpr int N1 = Q1 * R2;             // columns of the prefix product
+  static constexpr int NT1 = N1 / 16;
+  static constexpr int NT2 = Q2;                 // (16 ids * Q2 columns) / 16
+  static constexpr int D = Q0 * Q1 * Q2;
+  static constexpr int ROW0 = Q0 * R1;           // floats per core row
+  static constexpr int ROW1 = R1 * Q1 * R2;
+  static constexpr int ROW2 = R2 * Q2;
+  static constexpr int LDA = R2 + 1;             // P rows padded: conflict-free A-operand reads
+  static constexpr int LDB = ROW2 + 4;           // staged G2 rows (16-byte aligned rows)
+  static constexpr int LDO = D + 4;              // staged output rows
+  static constexpr int P_FLOATS = ((MT2 * 16 * LDA + 3) / 4) * 4;
+  static constexpr int B_FLOATS = kChunk * LDB;
+  static constexpr int O_FLOATS = kChunk * LDO;
+  // the output rows reuse the staged-G2 region (every G2 read precedes every row write)
+  static constexpr int BO_FLOATS = B_FLOATS > O_FLOATS ? B_FLOATS : O_FLOATS;
+  static constexpr int WAVE_FLOATS = P_FLOATS + BO_FLOATS;
+  static_assert(Q0 <= 16, "stage 1 pads q0 to one 16-row tile");
+  static_assert(R1 % 4 == 0 && R2 % 4 == 0, "ranks must be multiples of the MFMA K");
+  static_assert(N1 % 16 == 0, "q1*r2 must tile by 16");
+  static_assert(D % 4 == 0 && ROW2 % 4 == 0, "rows move as float4");
+};
+
+// ---------------------------------------------------------------------------------
+// key / value preparation for the sort.  key = id (uint32; dead slots get `sentinel`
+// = prod(p), which sorts last); value = output row | kMultiBit when the bag holds several ids.
+// ---------------------------------------------------------------------------------
+__global__ void fast3_keys_kernel(const int64_t* __restrict__ indices,
+                                  const int64_t* __restrict__ rowidx, int64_t nnz,
+                                  const int32_t* __restrict__ nnz_dev, uint32_t sentinel,
+                                  uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= nnz) return;
+  const int64_t cnt = live_count(nnz, nnz_dev);
+  if (n >= cnt) {
+    keys[n] = sentinel;
+    vals[n] = 0;
+    return;
+  }
+  int64_t id = indices[n];
+  id = id < 0 ? 0 : (id >= (int64_t)sentinel ? (int64_t)sentinel - 1 : id);
+  const int64_t row = rowidx[n];
+  const bool multi = (n > 0 && rowidx[n - 1] == row) || (n + 1 < cnt && rowidx[n + 1] == row);
+  keys[n] = (uint32_t)id;
+  vals[n] = (uint32_t)row | (multi ? kMultiBit : 0u);
 }
-int launch_backward_fast3(const DevShape&, const CorePtrs&, const int64_t*, const int64_t*, int64_t,
-                          const int32_t*, const float*, const CorePtrsMut&, void*, int64_t, hipStream_t) {
-  return fail(TTEMB_E_UNSUPPORTED, "fast3 path not built");
+
+// ---------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------
+template <int Q0, int Q1, int Q2, int R1, int R2>
+__global__ __launch_bounds__(256) void fast3_forward_kernel(
+    const float* __restrict__ G0, const float* __restrict__ G1, const float* __restrict__ G2,
+    const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, int64_t nnz,
+    uint32_t sentinel, uint32_t p1, uint32_t p2, float* __restrict__ out) {
+  using C = Cfg<Q0, Q1, Q2, R1, R2>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int hi = lane >> 4, lo = lane & 15;
+  float* pbuf = smem + wave * C::WAVE_FLOATS;
+  float* bbuf = pbuf + C::P_FLOATS;
+  float* obuf = bbuf;
+
+  const int64_t begin = ((int64_t)blockIdx.x * 4 + wave) * kRange;
+  if (begin >= nnz) return;
+  const int64_t end = begin + kRange < nnz ? begin + kRange : nnz;
+
+  uint32_t cur_group = 0xffffffffu;
+  int64_t pos = begin;
+  while (pos < end) {
+    // ---- chunk discovery: lanes 0..15 look at the next 16 sorted ids ----
+    uint32_t key = sentinel, val = 0;
+    if (lo + pos < end && hi == 0) {
+      key = keys[pos + lo];
+      val = vals[pos + lo];
+    }
+    const uint32_t key0 = __shfl(key, 0, kWave);
+    if (key0 >= sentinel) break;  // only dead slots remain (they sort last)
+    const uint32_t group0 = key0 / p2;
+    const uint32_t my_group = key / p2;
+    const unsigned long long same = __ballot(hi == 0 && key < sentinel && my_group == group0);
+    // ids of the chunk are the leading run of lanes that share group0
+    const int len = __builtin_ctzll(~same);
+    const uint32_t i2 = (lo < len && hi == 0) ? key - my_group * p2 : 0u;
+
+    // ---- stage 1 (once per group): P = G0[i0] . G1[i1] -> LDS ----
+    if (group0 != cur_group) {
+      cur_group = group0;
+      const uint32_t i0 = group0 / p1;
+      const uint32_t i1 = group0 - i0 * p1;
+      const float* g0 = G0 + (size_t)i0 * C::ROW0;
+      const float* g1 = G1 + (size_t)i1 * C::ROW1;
+      f32x4 acc[C::NT1];
+#pragma unroll
+      for (int nt = 0; nt < C::NT1; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < C::KS1; ++s) {
+        const int k = 4 * s + hi;
+        const float a = lo < Q0 ? g0[lo * R1 + k] : 0.f;
+#pragma unroll
+        for (int nt = 0; nt < C::NT1; ++nt) {
+          const float b = g1[k * C::N1 + 16 * nt + lo];
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[nt], 0, 0, 0);
+        }
+      }
+      // accumulator (row 4*hi + r, col 16*nt + lo) -> P as a (q0 q1) x r2 matrix
+#pragma unroll
+      for (int nt = 0; nt < C::NT1; ++nt) {
+        const int n = 16 * nt + lo;
+        const int j = n / R2, c2 = n % R2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int a = 4 * hi + r;
+          if (a < Q0) pbuf[(a * Q1 + j) * C::LDA + c2] = acc[nt][r];
+        }
+      }
+    }
+
+    // ---- stage the chunk's G2 rows (dummy row 0 for the unused slots) ----
+    {
+      constexpr int F4 = C::ROW2 / 4;  // float4 per row
+#pragma unroll
+      for (int it = 0; it < (kChunk * F4 + kWave - 1) / kWave; ++it) {
+        const int f = it * kWave + lane;
+        const int b = f / F4, c4 = f - b * F4;
+        const uint32_t row2 = __shfl(i2, b < kChunk ? b : 0, kWave);
+        if (f < kChunk * F4) {
+          const float4 v = *reinterpret_cast<const float4*>(G2 + (size_t)row2 * C::ROW2 + 4 * c4);
+          *reinterpret_cast<float4*>(bbuf + b * C::LDB + 4 * c4) = v;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- stage 2: (q0 q1 x r2) . (r2 x 16 q2) ----
+    f32x4 c2acc[C::MT2][C::NT2];
+#pragma unroll
+    for (int mt = 0; mt < C::MT2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < C::NT2; ++nt) c2acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < C::KS2; ++s) {
+      const int k = 4 * s + hi;
+      float a[C::MT2];
+#pragma unroll
+      for (int mt = 0; mt < C::MT2; ++mt) a[mt] = pbuf[(16 * mt + lo) * C::LDA + k];
+#pragma unroll
+      for (int nt = 0; nt < C::NT2; ++nt) {
+        const int n = 16 * nt + lo;
+        const int b = n / Q2, kk = n % Q2;
+        const float bv = bbuf[b * C::LDB + k * Q2 + kk];
+#pragma unroll
+        for (int mt = 0; mt < C::MT2; ++mt)
+          c2acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], bv, c2acc[mt][nt], 0, 0, 0);
+      }
+    }
+
+    // ---- rows -> LDS (id-major) -> 16-byte global stores ----
+#pragma unroll
+    for (int mt = 0; mt < C::MT2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < C::NT2; ++nt) {
+        const int n = 16 * nt + lo;
+        const int b = n / Q2, kk = n % Q2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = 16 * mt + 4 * hi + r;
+          if (m < C::M2) obuf[b * C::LDO + m * Q2 + kk] = c2acc[mt][nt][r];
+        }
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {
+      constexpr int D4 = C::D / 4;
+#pragma unroll
+      for (int it = 0; it < (kChunk * D4 + kWave - 1) / kWave; ++it) {
+        const int f = it * kWave + lane;
+        const int b = f / D4, c4 = f - b * D4;
+        const uint32_t v = __shfl(val, b < kChunk ? b : 0, kWave);
+        if (f < kChunk * D4 && b < len) {
+          const float4 x = *reinterpret_cast<const float4*>(obuf + b * C::LDO + 4 * c4);
+          float* dst = out + (size_t)(v & ~kMultiBit) * C::D + 4 * c4;
+          if (v & kMultiBit) {
+            atomicAdd(dst + 0, x.x);
+            atomicAdd(dst + 1, x.y);
+            atomicAdd(dst + 2, x.z);
+            atomicAdd(dst + 3, x.w);
+          } else {
+            *reinterpret_cast<float4*>(dst) = x;
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    pos += len;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------
+enum Fast3Kind { kNone = 0, kProducts, kArxiv, kPapers };
+
+static Fast3Kind classify(const DevShape& s) {
+  if (s.T != 3) return kNone;
+  if ((long long)s.L[0] * s.p[0] >= 0x7fffffffll) return kNone;  // ids must fit the uint32 sort key
+  auto is = [&](int q0, int q1, int q2, int r1, int r2) {
+    return s.q[0] == q0 && s.q[1] == q1 && s.q[2] == q2 && s.R[1] == r1 && s.R[2] == r2;
+  };
+  if (is(4, 5, 5, 16, 16)) return kProducts;
+  if (is(4, 4, 8, 8, 8)) return kArxiv;
+  if (is(8, 4, 4, 32, 32)) return kPapers;
+  return kNone;
+}
+
+bool fast3_supported(const DevShape& s) { return classify(s) != kNone; }
+
+static int key_bits(const DevShape& s) {
+  const unsigned long long sentinel = (unsigned long long)s.L[0] * s.p[0];
+  int bits = 1;
+  while ((1ull << bits) <= sentinel) ++bits;
+  return bits;
+}
+
+static int64_t sort_temp_bytes(int64_t nnz, int bits) {
+  size_t tmp = 0;
+  uint32_t* nul = nullptr;
+  hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, nul, nul, nul, nul, (size_t)(nnz > 0 ? nnz : 1), 0,
+                                           bits, (hipStream_t)0, false);
+  return e == hipSuccess ? (int64_t)tmp : -1;
+}
+
+int64_t fast3_workspace_bytes(const DevShape& s, int32_t op, int64_t nnz, int64_t B) {
+  (void)op;
+  (void)B;
+  const int64_t tmp = sort_temp_bytes(nnz, key_bits(s));
+  if (tmp < 0) return fail(TTEMB_E_HIP, "rocprim size query failed");
+  return 4 * align256(nnz * 4) + align256(tmp) + 256;
+}
+
+struct SortedIds {
+  uint32_t* keys;
+  uint32_t* vals;
+  uint32_t sentinel;
+};
+
+static int sort_ids(const DevShape& s, const int64_t* indices, const int64_t* rowidx, int64_t nnz,
+                    const int32_t* nnz_dev, void* ws, int64_t ws_bytes, SortedIds* out, hipStream_t st) {
+  if (ws == nullptr) return fail(TTEMB_E_WORKSPACE, "fast path needs a workspace");
+  char* base = reinterpret_cast<char*>(ws);
+  const int64_t seg = align256(nnz * 4);
+  uint32_t* k_in = reinterpret_cast<uint32_t*>(base);
+  uint32_t* v_in = reinterpret_cast<uint32_t*>(base + seg);
+  uint32_t* k_out = reinterpret_cast<uint32_t*>(base + 2 * seg);
+  uint32_t* v_out = reinterpret_cast<uint32_t*>(base + 3 * seg);
+  char* tmp = base + 4 * seg;
+  const int bits = key_bits(s);
+  size_t tmp_bytes = 0;
+  hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_in, k_out, v_in, v_out, (size_t)nnz, 0, bits, st, false);
+  if (e != hipSuccess) return check_hip(e, "radix_sort_pairs(size)");
+  if (4 * seg + (int64_t)tmp_bytes > ws_bytes)
+    return fail(TTEMB_E_WORKSPACE, "fast path needs %lld workspace bytes, got %lld",
+                (long long)(4 * seg + tmp_bytes), (long long)ws_bytes);
+  const uint32_t sentinel = (uint32_t)((unsigned long long)s.L[0] * s.p[0]);
+  const int threads = 256;
+  hipLaunchKernelGGL(fast3_keys_kernel, dim3((unsigned)((nnz + threads - 1) / threads)), dim3(threads), 0, st,
+                     indices, rowidx, nnz, nnz_dev, sentinel, k_in, v_in);
+  int rc = check_hip(hipGetLastError(), "fast3_keys_kernel");
+  if (rc) return rc;
+  e = rocprim::radix_sort_pairs(tmp, tmp_bytes, k_in, k_out, v_in, v_out, (size_t)nnz, 0, bits, st, false);
+  if (e != hipSuccess) return check_hip(e, "radix_sort_pairs");
+  out->keys = k_out;
+  out->vals = v_out;
+  out->sentinel = sentinel;
+  return TTEMB_OK;
+}
+
+template <int Q0, int Q1, int Q2, int R1, int R2>
+static int run_forward(const DevShape& s, const CorePtrs& cores, const SortedIds& ids, int64_t nnz,
+                       float* output, hipStream_t st) {
+  using C = Cfg<Q0, Q1, Q2, R1, R2>;
+  const size_t lds = 4 * C::WAVE_FLOATS * sizeof(float);
+  const int64_t waves = (nnz + kRange - 1) / kRange;
+  const unsigned blocks = (unsigned)((waves + 3) / 4);
+  static bool attr_set = false;
+  if (!attr_set) {
+    int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&fast3_forward_kernel<Q0, Q1, Q2, R1, R2>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                       "hipFuncSetAttribute");
+    if (rc) return rc;
+    attr_set = true;
+  }
+  profile_begin(0, st);
+  hipLaunchKernelGGL((fast3_forward_kernel<Q0, Q1, Q2, R1, R2>), dim3(blocks), dim3(256), lds, st, cores.c[0],
+                     cores.c[1], cores.c[2], ids.keys, ids.vals, nnz, ids.sentinel, (uint32_t)s.p[1],
+                     (uint32_t)s.p[2], output);
+  profile_end(0, st);
+  return check_hip(hipGetLastError(), "fast3_forward_kernel");
+}
+
+int launch_forward_fast3(const DevShape& s, const CorePtrs& cores, const int64_t* indices,
+                         const int64_t* rowidx, int64_t nnz, const int32_t* nnz_dev, float* output,
+                         void* ws, int64_t ws_bytes, hipStream_t st) {
+  if (nnz <= 0) return TTEMB_OK;
+  SortedIds ids;
+  int rc = sort_ids(s, indices, rowidx, nnz, nnz_dev, ws, ws_bytes, &ids, st);
+  if (rc) return rc;
+  switch (classify(s)) {
+    case kProducts: return run_forward<4, 5, 5, 16, 16>(s, cores, ids, nnz, output, st);
+    case kArxiv: return run_forward<4, 4, 8, 8, 8>(s, cores, ids, nnz, output, st);
+    case kPapers: return run_forward<8, 4, 4, 32, 32>(s, cores, ids, nnz, output, st);
+    default: return fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
+  }
+}
+
+int launch_backward_fast3(const DevShape& s, const CorePtrs& cores, const int64_t* indices,
+                          const int64_t* rowidx, int64_t nnz, const int32_t* nnz_dev,
+                          const float* d_output, const CorePtrsMut& d_cores, void* ws, int64_t ws_bytes,
+                          hipStream_t st) {
+  // backward still runs the generic kernels until its grouped version lands
+  (void)ws;
+  (void)ws_bytes;
+  for (int t = 0; t < s.T; ++t) {
+    int rc = check_hip(hipMemsetAsync(d_cores.c[t], 0, (size_t)s.p[t] * s.row_len[t] * 4, st), "memset d_core");
+    if (rc) return rc;
+  }
+  return launch_backward_generic(s, cores, indices, rowidx, nnz, nnz_dev, d_output, d_cores, st);
 }
 
 }  // namespace ttemb

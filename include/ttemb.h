@@ -67,10 +67,10 @@ const char* ttemb_last_error(void);   /* thread-local, valid until the next call
 /* Bytes of scratch the op needs for `nnz` ids and `B` bags (0 is a valid answer). */
 int64_t ttemb_workspace_bytes(const ttemb_shape_t* shape, int32_t op, int64_t nnz, int64_t B);
 
-/* Select the kernel family used by the calling thread's later calls (TTEMB_PATH_*). */
+/* Select the kernel family used by later calls, process-wide (TTEMB_PATH_*). */
 int ttemb_set_path(int32_t path);
 
-/* Measurement hook (bench.py's roofline leg).  While enabled for the calling thread, the
+/* Measurement hook (bench.py's roofline leg).  While enabled (process-wide), the
  * main chain kernel of every ttemb_forward / ttemb_backward_* call is bracketed by
  * hipEvents on the call's stream.  ttemb_profile_read waits for the most recent bracket of
  * `which` (0 = forward chain kernel, 1 = backward chain kernel) and returns its
