@@ -52,6 +52,14 @@ struct Cfg {
   // the output rows reuse the staged-G2 region (every G2 read precedes every row write)
   static constexpr int BO_FLOATS = B_FLOATS > O_FLOATS ? B_FLOATS : O_FLOATS;
   static constexpr int WAVE_FLOATS = P_FLOATS + BO_FLOATS;
+  // backward: [P | staged G2 rows, later dP | staged d_output rows, later G1[i1]]
+  static constexpr int RT1 = (R1 + 15) / 16;     // 16-wide tiles over the ranks
+  static constexpr int RT2 = (R2 + 15) / 16;
+  static constexpr int LDG = N1 + 1;             // staged G1 row stride (conflict-free column reads)
+  static constexpr int BB_FLOATS = B_FLOATS > P_FLOATS ? B_FLOATS : P_FLOATS;
+  static constexpr int DB_FLOATS = ((O_FLOATS > R1 * LDG ? O_FLOATS : R1 * LDG) + 3) / 4 * 4;
+  static constexpr int BWD_WAVE_FLOATS = P_FLOATS + BB_FLOATS + DB_FLOATS;
+  static_assert(M2 % 4 == 0, "q0*q1 must be a multiple of the MFMA K");
   static_assert(Q0 <= 16, "stage 1 pads q0 to one 16-row tile");
   static_assert(R1 % 4 == 0 && R2 % 4 == 0, "ranks must be multiples of the MFMA K");
   static_assert(N1 % 16 == 0, "q1*r2 must tile by 16");
@@ -59,12 +67,14 @@ struct Cfg {
 };
 
 // ---------------------------------------------------------------------------------
-// key / value preparation for the sort.  key = id (uint32; dead slots get `sentinel`
-// = prod(p), which sorts last); value = output row | kMultiBit when the bag holds several ids.
+// key / value preparation for the sort.  key = the id with its digits reordered to
+// (i1, i0, i2) (uint32; dead slots get `sentinel` = prod(p), which sorts last);
+// value = output row | kMultiBit when the bag holds several ids.
 // ---------------------------------------------------------------------------------
 __global__ void fast3_keys_kernel(const int64_t* __restrict__ indices,
                                   const int64_t* __restrict__ rowidx, int64_t nnz,
                                   const int32_t* __restrict__ nnz_dev, uint32_t sentinel,
+                                  uint32_t p0, uint32_t p1, uint32_t p2,
                                   uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
   const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= nnz) return;
@@ -78,7 +88,14 @@ __global__ void fast3_keys_kernel(const int64_t* __restrict__ indices,
   id = id < 0 ? 0 : (id >= (int64_t)sentinel ? (int64_t)sentinel - 1 : id);
   const int64_t row = rowidx[n];
   const bool multi = (n > 0 && rowidx[n - 1] == row) || (n + 1 < cnt && rowidx[n + 1] == row);
-  keys[n] = (uint32_t)id;
+  // sort key = (i1, i0, i2): ids of one (i0, i1) group stay adjacent, and consecutive groups
+  // share i1 -- which is what lets the backward kernel keep dG1[i1] in registers
+  const uint32_t u = (uint32_t)id;
+  const uint32_t i0 = u / (p1 * p2);
+  const uint32_t rem = u - i0 * (p1 * p2);
+  const uint32_t i1 = rem / p2;
+  const uint32_t i2 = rem - i1 * p2;
+  keys[n] = (i1 * p0 + i0) * p2 + i2;
   vals[n] = (uint32_t)row | (multi ? kMultiBit : 0u);
 }
 
@@ -89,7 +106,7 @@ template <int Q0, int Q1, int Q2, int R1, int R2>
 __global__ __launch_bounds__(256) void fast3_forward_kernel(
     const float* __restrict__ G0, const float* __restrict__ G1, const float* __restrict__ G2,
     const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, int64_t nnz,
-    uint32_t sentinel, uint32_t p1, uint32_t p2, float* __restrict__ out) {
+    uint32_t sentinel, uint32_t p0, uint32_t p2, float* __restrict__ out) {
   using C = Cfg<Q0, Q1, Q2, R1, R2>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int wave = threadIdx.x >> 6;
@@ -124,8 +141,8 @@ __global__ __launch_bounds__(256) void fast3_forward_kernel(
     // ---- stage 1 (once per group): P = G0[i0] . G1[i1] -> LDS ----
     if (group0 != cur_group) {
       cur_group = group0;
-      const uint32_t i0 = group0 / p1;
-      const uint32_t i1 = group0 - i0 * p1;
+      const uint32_t i1 = group0 / p0;
+      const uint32_t i0 = group0 - i1 * p0;
       const float* g0 = G0 + (size_t)i0 * C::ROW0;
       const float* g1 = G1 + (size_t)i1 * C::ROW1;
       f32x4 acc[C::NT1];
@@ -238,6 +255,310 @@ __global__ __launch_bounds__(256) void fast3_forward_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------------
+// backward (dense core gradients; the fused optimiser epilogue runs afterwards)
+//
+// Same walk as the forward.  Per chunk of <= 16 ids of one (i0, i1) group, with dO the
+// chunk's gradient rows viewed as a (q0 q1) x (16 q2) matrix and G2s the stacked G2 rows:
+//     dP   += dO . G2s^T                 (q0 q1 x r2, accumulated over the group's chunks)
+//     dG2s  = P^T . dO                   (r2 x 16 q2, scattered to dG2[i2] of each id)
+// per group, once its chunks are done:
+//     dG1[i1] += G0[i0]^T . dP           (r1 x q1 r2; stays in registers while i1 repeats)
+//     dG0[i0] += dP . G1[i1]^T           (q0 x r1)
+// All four are fp32 MFMA.  dG2 is accumulated in an LDS copy per workgroup (when the core
+// fits) and flushed once with 256-byte atomic rows; dG1 is flushed when the wave's i1
+// changes; dG0 is flushed per group (64 floats).  The reference issues 1424 global float
+// atomics PER ID (FBTT/tt_embeddings_cuda.cu:364-379); here it is a few per id.
+// ---------------------------------------------------------------------------------
+template <int Q0, int Q1, int Q2, int R1, int R2, int NW, bool G2LDS>
+__global__ __launch_bounds__(NW * 64) void fast3_backward_kernel(
+    const float* __restrict__ G0, const float* __restrict__ G1, const float* __restrict__ G2,
+    const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, int64_t nnz,
+    uint32_t sentinel, uint32_t p0, uint32_t p2, int64_t ids_per_wave,
+    const float* __restrict__ d_out, float* __restrict__ dG0, float* __restrict__ dG1,
+    float* __restrict__ dG2, int g2_floats) {
+  using C = Cfg<Q0, Q1, Q2, R1, R2>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int hi = lane >> 4, lo = lane & 15;
+  float* g2acc = smem;
+  const int g2_region = G2LDS ? ((g2_floats + 3) & ~3) : 0;
+  float* pbuf = smem + g2_region + wave * C::BWD_WAVE_FLOATS;
+  float* bbuf = pbuf + C::P_FLOATS;   // staged G2 rows; reused for dP at group end
+  float* dbuf = bbuf + C::BB_FLOATS;  // staged d_output rows; reused for G1[i1] at group end
+
+  if (G2LDS) {
+    for (int e = threadIdx.x; e < g2_floats; e += NW * 64) g2acc[e] = 0.f;
+    __syncthreads();
+  }
+
+  const int64_t begin = ((int64_t)blockIdx.x * NW + wave) * ids_per_wave;
+  const int64_t end = begin + ids_per_wave < nnz ? begin + ids_per_wave : nnz;
+
+  f32x4 dp[C::MT2][C::RT2];     // dP of the current group
+  f32x4 g1acc[C::RT1][C::NT1];  // dG1[i1] of the current i1
+#pragma unroll
+  for (int t = 0; t < C::RT1; ++t)
+#pragma unroll
+    for (int nt = 0; nt < C::NT1; ++nt) g1acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int mt = 0; mt < C::MT2; ++mt)
+#pragma unroll
+    for (int t = 0; t < C::RT2; ++t) dp[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  uint32_t cur_group = 0xffffffffu, cur_i1 = 0xffffffffu, cur_i0 = 0;
+
+  // dG1[i1] += accumulators ; accumulators = 0
+  auto flush_g1 = [&]() {
+    float* dst = dG1 + (size_t)cur_i1 * C::ROW1;
+#pragma unroll
+    for (int t = 0; t < C::RT1; ++t)
+#pragma unroll
+      for (int nt = 0; nt < C::NT1; ++nt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 16 * t + 4 * hi + r;
+          if (c < R1) atomicAdd(dst + c * C::N1 + 16 * nt + lo, g1acc[t][nt][r]);
+        }
+        g1acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+  };
+
+  // group epilogue: fold the group's dP into dG1 (registers) and dG0 (atomics)
+  auto flush_group = [&]() {
+    float* dpbuf = bbuf;
+    float* g1buf = dbuf;
+    // dP accumulators (row 16 mt + 4 hi + r, col 16 t + lo) -> LDS matrix [m2][c2]
+#pragma unroll
+    for (int mt = 0; mt < C::MT2; ++mt)
+#pragma unroll
+      for (int t = 0; t < C::RT2; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = 16 * mt + 4 * hi + r;
+          const int c2 = 16 * t + lo;
+          if (m < C::M2 && c2 < R2) dpbuf[m * C::LDA + c2] = dp[mt][t][r];
+        }
+        dp[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    // G1[i1] (r1 x q1 r2) -> LDS with a padded row stride, coalesced reads
+    const float* g1 = G1 + (size_t)cur_i1 * C::ROW1;
+#pragma unroll
+    for (int it = 0; it < (C::ROW1 + kWave - 1) / kWave; ++it) {
+      const int e = it * kWave + lane;
+      if (e < C::ROW1) {
+        const int c = e / C::N1, n = e - c * C::N1;
+        g1buf[c * C::LDG + n] = g1[e];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // dG1[i1] += G0[i0]^T (r1 x q0) . dP (q0 x q1 r2)
+    const float* g0 = G0 + (size_t)cur_i0 * C::ROW0;
+#pragma unroll
+    for (int s = 0; s < (Q0 + 3) / 4; ++s) {
+      const int a = 4 * s + hi;
+      float av[C::RT1];
+#pragma unroll
+      for (int t = 0; t < C::RT1; ++t) av[t] = (a < Q0 && 16 * t + lo < R1) ? g0[a * R1 + 16 * t + lo] : 0.f;
+#pragma unroll
+      for (int nt = 0; nt < C::NT1; ++nt) {
+        const int n = 16 * nt + lo;
+        const float bv = a < Q0 ? dpbuf[(a * Q1 + n / R2) * C::LDA + n % R2] : 0.f;
+#pragma unroll
+        for (int t = 0; t < C::RT1; ++t)
+          g1acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv, g1acc[t][nt], 0, 0, 0);
+      }
+    }
+    // dG0[i0] += dP (q0 x q1 r2) . G1[i1]^T (q1 r2 x r1)
+    f32x4 g0acc[C::RT1];
+#pragma unroll
+    for (int t = 0; t < C::RT1; ++t) g0acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < C::N1 / 4; ++s) {
+      const int n = 4 * s + hi;
+      const float av = lo < Q0 ? dpbuf[(lo * Q1 + n / R2) * C::LDA + n % R2] : 0.f;
+#pragma unroll
+      for (int t = 0; t < C::RT1; ++t) {
+        const float bv = 16 * t + lo < R1 ? g1buf[(16 * t + lo) * C::LDG + n] : 0.f;
+        g0acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, g0acc[t], 0, 0, 0);
+      }
+    }
+    float* dst0 = dG0 + (size_t)cur_i0 * C::ROW0;
+#pragma unroll
+    for (int t = 0; t < C::RT1; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int a = 4 * hi + r;
+        if (a < Q0 && 16 * t + lo < R1) atomicAdd(dst0 + a * R1 + 16 * t + lo, g0acc[t][r]);
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  int64_t pos = begin;
+  while (pos < end) {
+    // ---- chunk discovery (as in the forward) ----
+    uint32_t key = sentinel, val = 0;
+    if (lo + pos < end && hi == 0) {
+      key = keys[pos + lo];
+      val = vals[pos + lo];
+    }
+    const uint32_t key0 = __shfl(key, 0, kWave);
+    if (key0 >= sentinel) break;
+    const uint32_t group0 = key0 / p2;
+    const uint32_t my_group = key / p2;
+    const unsigned long long same = __ballot(hi == 0 && key < sentinel && my_group == group0);
+    const int len = __builtin_ctzll(~same);
+    const uint32_t i2 = (lo < len && hi == 0) ? key - my_group * p2 : 0u;
+
+    if (group0 != cur_group) {
+      if (cur_group != 0xffffffffu) flush_group();
+      const uint32_t i1 = group0 / p0;
+      if (i1 != cur_i1) {
+        if (cur_i1 != 0xffffffffu) flush_g1();
+        cur_i1 = i1;
+      }
+      cur_group = group0;
+      cur_i0 = group0 - i1 * p0;
+      // ---- stage 1: P = G0[i0] . G1[i1] -> LDS ----
+      const float* g0 = G0 + (size_t)cur_i0 * C::ROW0;
+      const float* g1 = G1 + (size_t)cur_i1 * C::ROW1;
+      f32x4 acc[C::NT1];
+#pragma unroll
+      for (int nt = 0; nt < C::NT1; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < C::KS1; ++s) {
+        const int k = 4 * s + hi;
+        const float a = lo < Q0 ? g0[lo * R1 + k] : 0.f;
+#pragma unroll
+        for (int nt = 0; nt < C::NT1; ++nt) {
+          const float b = g1[k * C::N1 + 16 * nt + lo];
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[nt], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int nt = 0; nt < C::NT1; ++nt) {
+        const int n = 16 * nt + lo;
+        const int j = n / R2, c2 = n % R2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int a = 4 * hi + r;
+          if (a < Q0) pbuf[(a * Q1 + j) * C::LDA + c2] = acc[nt][r];
+        }
+      }
+    }
+
+    // ---- stage the chunk's G2 rows and d_output rows (zero rows for unused slots) ----
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      constexpr int F4 = C::ROW2 / 4;
+#pragma unroll
+      for (int it = 0; it < (kChunk * F4 + kWave - 1) / kWave; ++it) {
+        const int f = it * kWave + lane;
+        const int b = f / F4, c4 = f - b * F4;
+        const uint32_t row2 = __shfl(i2, b < kChunk ? b : 0, kWave);
+        if (f < kChunk * F4) {
+          const float4 v = *reinterpret_cast<const float4*>(G2 + (size_t)row2 * C::ROW2 + 4 * c4);
+          *reinterpret_cast<float4*>(bbuf + b * C::LDB + 4 * c4) = v;
+        }
+      }
+      constexpr int D4 = C::D / 4;
+#pragma unroll
+      for (int it = 0; it < (kChunk * D4 + kWave - 1) / kWave; ++it) {
+        const int f = it * kWave + lane;
+        const int b = f / D4, c4 = f - b * D4;
+        const uint32_t v = __shfl(val, b < kChunk ? b : 0, kWave);
+        if (f < kChunk * D4) {
+          float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (b < len) x = *reinterpret_cast<const float4*>(d_out + (size_t)(v & ~kMultiBit) * C::D + 4 * c4);
+          *reinterpret_cast<float4*>(dbuf + b * C::LDO + 4 * c4) = x;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- dP += dO (q0q1 x 16 q2) . G2s^T (16 q2 x r2) ----
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 4 * Q2; ++s) {
+      const int col = 4 * s + hi;
+      const int b = col / Q2, kk = col % Q2;
+      float av[C::MT2], bv[C::RT2];
+#pragma unroll
+      for (int mt = 0; mt < C::MT2; ++mt) {
+        const int m = 16 * mt + lo < C::M2 ? 16 * mt + lo : C::M2 - 1;  // rows past M2 are discarded
+        av[mt] = dbuf[b * C::LDO + m * Q2 + kk];
+      }
+#pragma unroll
+      for (int t = 0; t < C::RT2; ++t) bv[t] = 16 * t + lo < R2 ? bbuf[b * C::LDB + (16 * t + lo) * Q2 + kk] : 0.f;
+#pragma unroll
+      for (int mt = 0; mt < C::MT2; ++mt)
+#pragma unroll
+        for (int t = 0; t < C::RT2; ++t)
+          dp[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv[t], dp[mt][t], 0, 0, 0);
+    }
+
+    // ---- dG2s = P^T (r2 x q0q1) . dO (q0q1 x 16 q2), scattered per id ----
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      f32x4 e[C::RT2][C::NT2];
+#pragma unroll
+      for (int t = 0; t < C::RT2; ++t)
+#pragma unroll
+        for (int nt = 0; nt < C::NT2; ++nt) e[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < C::M2 / 4; ++s) {
+        const int m = 4 * s + hi;
+        float av[C::RT2];
+#pragma unroll
+        for (int t = 0; t < C::RT2; ++t) av[t] = 16 * t + lo < R2 ? pbuf[m * C::LDA + 16 * t + lo] : 0.f;
+#pragma unroll
+        for (int nt = 0; nt < C::NT2; ++nt) {
+          const int col = 16 * nt + lo;
+          const float bv = dbuf[(col / Q2) * C::LDO + m * Q2 + col % Q2];
+#pragma unroll
+          for (int t = 0; t < C::RT2; ++t)
+            e[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv, e[t][nt], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int nt = 0; nt < C::NT2; ++nt) {
+        const int col = 16 * nt + lo;
+        const int b = col / Q2, kk = col % Q2;
+        const uint32_t row2 = __shfl(i2, b, kWave);
+        float* dst = (G2LDS ? g2acc : dG2) + (size_t)row2 * C::ROW2 + kk;
+#pragma unroll
+        for (int t = 0; t < C::RT2; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int c2 = 16 * t + 4 * hi + r;
+            if (c2 < R2 && b < len) atomicAdd(dst + c2 * Q2, e[t][nt][r]);
+          }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    pos += len;
+  }
+  if (cur_group != 0xffffffffu) {
+    flush_group();
+    flush_g1();
+  }
+  if (G2LDS) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < g2_floats; e += NW * 64) {
+      const float v = g2acc[e];
+      if (v != 0.f) atomicAdd(dG2 + e, v);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------
@@ -306,7 +627,8 @@ static int sort_ids(const DevShape& s, const int64_t* indices, const int64_t* ro
   const uint32_t sentinel = (uint32_t)((unsigned long long)s.L[0] * s.p[0]);
   const int threads = 256;
   hipLaunchKernelGGL(fast3_keys_kernel, dim3((unsigned)((nnz + threads - 1) / threads)), dim3(threads), 0, st,
-                     indices, rowidx, nnz, nnz_dev, sentinel, k_in, v_in);
+                     indices, rowidx, nnz, nnz_dev, sentinel, (uint32_t)s.p[0], (uint32_t)s.p[1], (uint32_t)s.p[2],
+                     k_in, v_in);
   int rc = check_hip(hipGetLastError(), "fast3_keys_kernel");
   if (rc) return rc;
   e = rocprim::radix_sort_pairs(tmp, tmp_bytes, k_in, k_out, v_in, v_out, (size_t)nnz, 0, bits, st, false);
@@ -334,7 +656,7 @@ static int run_forward(const DevShape& s, const CorePtrs& cores, const SortedIds
   }
   profile_begin(0, st);
   hipLaunchKernelGGL((fast3_forward_kernel<Q0, Q1, Q2, R1, R2>), dim3(blocks), dim3(256), lds, st, cores.c[0],
-                     cores.c[1], cores.c[2], ids.keys, ids.vals, nnz, ids.sentinel, (uint32_t)s.p[1],
+                     cores.c[1], cores.c[2], ids.keys, ids.vals, nnz, ids.sentinel, (uint32_t)s.p[0],
                      (uint32_t)s.p[2], output);
   profile_end(0, st);
   return check_hip(hipGetLastError(), "fast3_forward_kernel");
@@ -355,18 +677,64 @@ int launch_forward_fast3(const DevShape& s, const CorePtrs& cores, const int64_t
   }
 }
 
+template <int Q0, int Q1, int Q2, int R1, int R2, int NW, bool G2LDS>
+static int run_backward_inst(const DevShape& s, const CorePtrs& cores, const SortedIds& ids, int64_t nnz,
+                             const float* d_output, const CorePtrsMut& d_cores, hipStream_t st) {
+  using C = Cfg<Q0, Q1, Q2, R1, R2>;
+  const int g2_floats = s.p[2] * C::ROW2;
+  const size_t lds = ((G2LDS ? ((g2_floats + 3) & ~3) : 0) + (size_t)NW * C::BWD_WAVE_FLOATS) * sizeof(float);
+  // one workgroup per CU at most; every wave walks one contiguous slice of the sorted ids
+  const int64_t max_waves = 256 * NW;
+  int64_t waves = (nnz + kRange - 1) / kRange;
+  if (waves > max_waves) waves = max_waves;
+  const int64_t ids_per_wave = (nnz + waves - 1) / waves;
+  const unsigned blocks = (unsigned)((waves + NW - 1) / NW);
+  static bool attr_set = false;
+  if (!attr_set) {
+    int rc = check_hip(
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&fast3_backward_kernel<Q0, Q1, Q2, R1, R2, NW, G2LDS>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+        "hipFuncSetAttribute");
+    if (rc) return rc;
+    attr_set = true;
+  }
+  profile_begin(1, st);
+  hipLaunchKernelGGL((fast3_backward_kernel<Q0, Q1, Q2, R1, R2, NW, G2LDS>), dim3(blocks), dim3(NW * 64), lds, st,
+                     cores.c[0], cores.c[1], cores.c[2], ids.keys, ids.vals, nnz, ids.sentinel, (uint32_t)s.p[0],
+                     (uint32_t)s.p[2], ids_per_wave, d_output, d_cores.c[0], d_cores.c[1], d_cores.c[2], g2_floats);
+  profile_end(1, st);
+  return check_hip(hipGetLastError(), "fast3_backward_kernel");
+}
+
+template <int Q0, int Q1, int Q2, int R1, int R2, int NW>
+static int run_backward(const DevShape& s, const CorePtrs& cores, const SortedIds& ids, int64_t nnz,
+                        const float* d_output, const CorePtrsMut& d_cores, hipStream_t st) {
+  using C = Cfg<Q0, Q1, Q2, R1, R2>;
+  // a per-workgroup LDS copy of dG2 when the whole core fits beside the per-wave buffers
+  const size_t with_g2 = ((size_t)s.p[2] * C::ROW2 + 4 + (size_t)NW * C::BWD_WAVE_FLOATS) * sizeof(float);
+  if (with_g2 <= 160 * 1024)
+    return run_backward_inst<Q0, Q1, Q2, R1, R2, NW, true>(s, cores, ids, nnz, d_output, d_cores, st);
+  return run_backward_inst<Q0, Q1, Q2, R1, R2, NW, false>(s, cores, ids, nnz, d_output, d_cores, st);
+}
+
 int launch_backward_fast3(const DevShape& s, const CorePtrs& cores, const int64_t* indices,
                           const int64_t* rowidx, int64_t nnz, const int32_t* nnz_dev,
                           const float* d_output, const CorePtrsMut& d_cores, void* ws, int64_t ws_bytes,
                           hipStream_t st) {
-  // backward still runs the generic kernels until its grouped version lands
-  (void)ws;
-  (void)ws_bytes;
   for (int t = 0; t < s.T; ++t) {
     int rc = check_hip(hipMemsetAsync(d_cores.c[t], 0, (size_t)s.p[t] * s.row_len[t] * 4, st), "memset d_core");
     if (rc) return rc;
   }
-  return launch_backward_generic(s, cores, indices, rowidx, nnz, nnz_dev, d_output, d_cores, st);
+  if (nnz <= 0) return TTEMB_OK;
+  SortedIds ids;
+  int rc = sort_ids(s, indices, rowidx, nnz, nnz_dev, ws, ws_bytes, &ids, st);
+  if (rc) return rc;
+  switch (classify(s)) {
+    case kProducts: return run_backward<4, 5, 5, 16, 16, 8>(s, cores, ids, nnz, d_output, d_cores, st);
+    case kArxiv: return run_backward<4, 4, 8, 8, 8, 8>(s, cores, ids, nnz, d_output, d_cores, st);
+    case kPapers: return run_backward<8, 4, 4, 32, 32, 4>(s, cores, ids, nnz, d_output, d_cores, st);
+    default: return fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
+  }
 }
 
 }  // namespace ttemb
