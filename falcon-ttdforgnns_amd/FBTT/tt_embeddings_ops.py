@@ -434,4 +434,10 @@ class TTEmbeddingBag(TableBatchedTTEmbeddingBag):
                          enforce_embedding_dim, batch_count)
 
     def forward(self, indices: torch.Tensor, offsets: torch.Tensor, warmup: bool = True) -> torch.Tensor:
-        return super().forward(indices, offsets, warmup)[0]
+        # same result as the reference's ``super().forward(...)[0]`` (:960-965) without the
+        # [1, B, D] view: selecting table 0 would cost a zero-fill + copy of B*D floats in backward
+        if not indices.is_cuda:
+            raise RuntimeError("TTEmbeddingBag.forward needs tensors on a ROCm device; there is no CPU fallback")
+        indices, offsets = indices.long().contiguous(), offsets.long().contiguous()
+        self.update_cache(indices)
+        return self._lookup_one_table(0, offsets.numel() - 1, indices, offsets)

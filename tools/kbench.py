@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmark: times the forward / backward chain kernels alone (HIP events
+inside the library) on the ogbn-products shape for a few frontier sizes."""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "falcon-ttdforgnns_amd")):
+    sys.path.insert(0, p)
+import numpy as np
+import torch
+import ttemb_native as nat
+
+CFG = {"products": ([125, 140, 140], [4, 5, 5], [1, 16, 16, 1], 2449029),
+       "arxiv": ([56, 60, 51], [4, 4, 8], [1, 8, 8, 1], 169343),
+       "papers": ([500, 560, 400], [8, 4, 4], [1, 32, 32, 1], 111059956)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cfg", default="products")
+    ap.add_argument("--n", type=int, nargs="+", default=[409600])
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--dist", default="uniform", choices=["uniform", "windows", "arange"])
+    ap.add_argument("--path", default="auto")
+    ap.add_argument("--what", default="both", choices=["both", "fwd", "bwd"])
+    a = ap.parse_args()
+    p, q, R, n_emb = CFG[a.cfg]
+    D = int(np.prod(q))
+    nat.set_path({"auto": 0, "generic": 1, "fast3": 2}[a.path])
+    shape = nat.make_shape(p, q, R)
+    rng = np.random.default_rng(0)
+    cores = [torch.tensor((rng.standard_normal((p[t], R[t] * q[t] * R[t + 1])) * 0.3).astype(np.float32)).cuda()
+             for t in range(3)]
+    ws = nat.Workspace()
+    nat.profile_enable(True)
+    for N in a.n:
+        if a.dist == "uniform":
+            ids = rng.choice(n_emb, size=N, replace=False)
+        elif a.dist == "arange":
+            ids = np.arange(N) % n_emb
+        else:  # METIS-like: windows of 200 consecutive ids
+            starts = rng.choice(n_emb // 200 - 1, size=(N + 199) // 200, replace=False) * 200
+            ids = (starts[:, None] + np.arange(200)[None, :]).reshape(-1)[:N]
+        idx = torch.tensor(ids.astype(np.int64)).cuda()
+        offs = torch.arange(N + 1, device="cuda")
+        rowidx = torch.empty(N, dtype=torch.int64, device="cuda")
+        nat.preprocess(idx, offs, N, True, None, None, None, rowidx, None, None, ws)
+        out = torch.empty(N, D, device="cuda")
+        d_out = (torch.rand(N, D, device="cuda") - 0.5) * 0.1
+        grads = [torch.empty_like(c) for c in cores]
+        f, b = [], []
+        for i in range(a.iters + 3):
+            if a.what in ("both", "fwd"):
+                nat.forward(shape, cores, idx, rowidx, offs, N, None, N, out, ws)
+                if i >= 3:
+                    f.append(nat.profile_read(0))
+            if a.what in ("both", "bwd"):
+                nat.backward_dense(shape, cores, idx, rowidx, N, None, N, d_out, grads, ws)
+                if i >= 3:
+                    b.append(nat.profile_read(1))
+        torch.cuda.synchronize()
+        msg = f"{a.cfg} {a.dist} N={N}:"
+        if f:
+            msg += f" fwd {np.mean(f)*1e3:8.1f} us ({N/np.mean(f)/1e6:8.2f} G lookups/s)"
+        if b:
+            msg += f" bwd {np.mean(b)*1e3:8.1f} us ({N/np.mean(b)/1e6:8.2f} G lookups/s)"
+        print(msg, flush=True)
+
+
+if __name__ == "__main__":
+    main()
