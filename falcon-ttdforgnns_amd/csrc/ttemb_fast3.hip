@@ -21,6 +21,8 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <rocprim/device/device_scan.hpp>
+
 
 namespace ttemb {
 
@@ -68,22 +70,34 @@ struct Cfg {
 };
 
 // ---------------------------------------------------------------------------------
-// Grouping pass: a counting sort of the live ids by group' = i1 * p0 + i0 (three tiny
+// Grouping pass: a counting sort of the live ids by group' = i1 * p0 + i0 (three small
 // kernels; rocprim's radix/merge sort needs ~20 launches and > 100 us at these sizes).
 //   key   = (i1 * p0 + i0) * p2 + i2   -- the id with its digits reordered: ids of one
-//           (i0, i1) group end up adjacent, and consecutive groups share i1, which is what
-//           lets the backward kernel keep dG1[i1] in registers;
+//           (i0, i1) group end up adjacent, and consecutive groups share i1;
 //   value = output row | kMultiBit when the bag holds several ids.
-// The order of ids inside a group is whatever the atomics produce; every consumer is
-// insensitive to it except for the summation order of the backward (fp32 rounding only).
+// One returning atomic per id (its arrival rank inside the group) in the first kernel, a
+// rocPRIM exclusive scan of the group sizes, and an atomic-free scatter.  The order of ids inside a group is arrival order: every
+// consumer is insensitive to it except for fp32 summation order in the backward.
 // ---------------------------------------------------------------------------------
-__global__ void fast3_keys_hist_kernel(const int64_t* __restrict__ indices,
-                                       const int64_t* __restrict__ rowidx, int64_t nnz,
-                                       const int32_t* __restrict__ nnz_dev, uint32_t sentinel,
-                                       uint32_t p0, uint32_t p1, uint32_t p2,
-                                       uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                       uint32_t* __restrict__ counts) {
-  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+constexpr int kTile = 256;   // threads per workgroup in the grouping kernels
+
+struct GroupPlan {           // device pointers into the caller's workspace
+  uint32_t* keys_in;         // [nnz] ungrouped keys
+  uint32_t* vals_in;
+  uint32_t* rank_in;         // arrival rank of the id inside its group
+  uint32_t* keys;            // [nnz] grouped
+  uint32_t* vals;
+  uint32_t* counts;          // [G+1] ids per group (entry G stays 0)
+  uint32_t* gstart;          // [G+1] first grouped position of each group; [G] = live ids
+  float* etab;               // [nnz][ROW2] dG2 contribution rows, in grouped order
+  float* dptab;              // [G][M2*R2] dP of every non-empty group
+};
+
+__global__ __launch_bounds__(kTile) void fast3_prep_kernel(
+    const int64_t* __restrict__ indices, const int64_t* __restrict__ rowidx, int64_t nnz,
+    const int32_t* __restrict__ nnz_dev, uint32_t sentinel, uint32_t p0, uint32_t p1, uint32_t p2,
+    GroupPlan plan) {
+  const int64_t n = (int64_t)blockIdx.x * kTile + threadIdx.x;
   const int64_t cnt = live_count(nnz, nnz_dev);
   if (n >= cnt) return;
   int64_t id = indices[n];
@@ -96,46 +110,19 @@ __global__ void fast3_keys_hist_kernel(const int64_t* __restrict__ indices,
   const uint32_t i1 = rem / p2;
   const uint32_t i2 = rem - i1 * p2;
   const uint32_t group = i1 * p0 + i0;
-  keys[n] = group * p2 + i2;
-  vals[n] = (uint32_t)row | (multi ? kMultiBit : 0u);
-  atomicAdd(&counts[group], 1u);
+  plan.keys_in[n] = group * p2 + i2;
+  plan.vals_in[n] = (uint32_t)row | (multi ? kMultiBit : 0u);
+  plan.rank_in[n] = atomicAdd(&plan.counts[group], 1u);
 }
 
-// in-place exclusive scan of counts[0..G) by one 1024-thread workgroup: counts -> cursors
-__global__ __launch_bounds__(1024) void fast3_scan_kernel(uint32_t* __restrict__ counts, int G) {
-  __shared__ uint32_t part[1024];
-  const int tid = threadIdx.x;
-  const int per = (G + 1023) / 1024;
-  const int lo = tid * per;
-  const int hi = lo + per < G ? lo + per : G;
-  uint32_t sum = 0;
-  for (int i = lo; i < hi; ++i) sum += counts[i];
-  part[tid] = sum;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {
-    uint32_t v = tid >= off ? part[tid - off] : 0u;
-    __syncthreads();
-    part[tid] += v;
-    __syncthreads();
-  }
-  uint32_t run = part[tid] - sum;
-  for (int i = lo; i < hi; ++i) {
-    const uint32_t c = counts[i];
-    counts[i] = run;
-    run += c;
-  }
-}
-
-__global__ void fast3_scatter_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                     int64_t nnz, const int32_t* __restrict__ nnz_dev, uint32_t p2,
-                                     uint32_t* __restrict__ cursor, uint32_t* __restrict__ keys_out,
-                                     uint32_t* __restrict__ vals_out) {
-  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(kTile) void fast3_scatter_kernel(int64_t nnz, const int32_t* __restrict__ nnz_dev,
+                                                              uint32_t p2, GroupPlan plan) {
+  const int64_t n = (int64_t)blockIdx.x * kTile + threadIdx.x;
   if (n >= live_count(nnz, nnz_dev)) return;
-  const uint32_t key = keys[n];
-  const uint32_t dst = atomicAdd(&cursor[key / p2], 1u);
-  keys_out[dst] = key;
-  vals_out[dst] = vals[n];
+  const uint32_t key = plan.keys_in[n];
+  const uint32_t dst = plan.gstart[key / p2] + plan.rank_in[n];
+  plan.keys[dst] = key;
+  plan.vals[dst] = plan.vals_in[n];
 }
 
 // ---------------------------------------------------------------------------------
@@ -297,62 +284,394 @@ __global__ __launch_bounds__(256) void fast3_forward_kernel(
 }
 
 // ---------------------------------------------------------------------------------
-// backward (dense core gradients; the fused optimiser epilogue runs afterwards)
+// backward, atomics-free formulation (three kernels)
 //
-// Same walk as the forward.  Per chunk of <= 16 ids of one (i0, i1) group, with dO the
-// chunk's gradient rows viewed as a (q0 q1) x (16 q2) matrix and G2s the stacked G2 rows:
-//     dP   += dO . G2s^T                 (q0 q1 x r2, accumulated over the group's chunks)
-//     dG2s  = P^T . dO                   (r2 x 16 q2, scattered to dG2[i2] of each id)
-// per group, once its chunks are done:
-//     dG1[i1] += G0[i0]^T . dP           (r1 x q1 r2; stays in registers while i1 repeats)
-//     dG0[i0] += dP . G1[i1]^T           (q0 x r1)
-// All four are fp32 MFMA.  dG2 is accumulated in an LDS copy per workgroup (when the core
-// fits) and flushed once with 256-byte atomic rows; dG1 is flushed when the wave's i1
-// changes; dG0 is flushed per group (64 floats).  The reference issues 1424 global float
-// atomics PER ID (FBTT/tt_embeddings_cuda.cu:364-379); here it is a few per id.
+//  A. chunk kernel (stateless, one wavefront per 64 sorted ids): per chunk
+//        dP  += dO . G2s^T                        (q0q1 x r2, per group-run)
+//        E    = P^T . dO   -> one (r2 q2)-float row per id, stored at the id's grouped position
+//     and per group-run the dP partial sum is stored in its own slot.  Plain stores only.
+//  B. dG2[i2] = sum of the E rows whose id has that i2: each wave of a workgroup owns a slice of
+//     the i2 range and accumulates its rows into an LDS copy with plain read-modify-writes.
+//  C. group epilogue: per non-empty group (ranks are (i1, i0)-ordered) dP = sum of its parts,
+//        dG1[i1] += G0[i0]^T . dP  (registers while i1 repeats),  dG0[i0] += dP . G1[i1]^T.
+// LDS float atomics cost ~160 LDS cycles per wave-instruction on gfx950 (measured), global
+// ones ~1.3 TB/s chip-wide; a store pass + per-destination sum pass is several times cheaper.
 // ---------------------------------------------------------------------------------
-template <int Q0, int Q1, int Q2, int R1, int R2, int NW, bool G2LDS>
-__global__ __launch_bounds__(NW * 64) void fast3_backward_kernel(
+template <int Q0, int Q1, int Q2, int R1, int R2>
+__global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(
     const float* __restrict__ G0, const float* __restrict__ G1, const float* __restrict__ G2,
-    const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, int64_t nnz,
-    const int32_t* __restrict__ nnz_dev, uint32_t p0, uint32_t p2, int64_t ids_per_wave,
-    const float* __restrict__ d_out, float* __restrict__ dG0, float* __restrict__ dG1,
-    float* __restrict__ dG2, int g2_floats, int dbg) {
+    int64_t nnz, const int32_t* __restrict__ nnz_dev, uint32_t p0, uint32_t p2,
+    const float* __restrict__ d_out, GroupPlan plan) {
   using C = Cfg<Q0, Q1, Q2, R1, R2>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int wave = threadIdx.x >> 6;
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x;
   const int hi = lane >> 4, lo = lane & 15;
-  float* g2acc = smem;
-  const int g2_rows = g2_floats / C::ROW2;
-  const int g2_region = G2LDS ? ((g2_rows * C::LD2 + 3) & ~3) : 0;
-  float* pbuf = smem + g2_region + wave * C::BWD_WAVE_FLOATS;
-  float* bbuf = pbuf + C::P_FLOATS;   // staged G2 rows; reused for dP at group end
-  float* dbuf = bbuf + C::BB_FLOATS;  // staged d_output rows; reused for G1[i1] at group end
+  float* pbuf = smem;
+  float* bbuf = pbuf + C::P_FLOATS;   // staged G2 rows
+  float* dbuf = bbuf + C::B_FLOATS;   // staged d_output rows, later the chunk's E rows
 
-  if (G2LDS) {
-    for (int e = threadIdx.x; e < g2_rows * C::LD2; e += NW * 64) g2acc[e] = 0.f;
-    __syncthreads();
+  // A wavefront owns the groups that START inside its 64-id window [begin, end): it skips a
+  // leading group that began earlier and follows its last group past `end`, so every group is
+  // handled by exactly one wavefront and its dP needs no partial sums.
+  const int64_t cnt = live_count(nnz, nnz_dev);
+  const int64_t begin = (int64_t)blockIdx.x * kRange;
+  if (begin >= cnt) return;
+  const int64_t end = begin + kRange < cnt ? begin + kRange : cnt;
+  int64_t pos = begin;
+  if (begin > 0) {
+    const uint32_t prev = plan.keys[begin - 1] / p2;
+    while (pos < end) {  // wave-uniform scan, 64 keys at a time
+      const uint32_t k = pos + lane < cnt ? plan.keys[pos + lane] : 0xffffffffu;
+      const unsigned long long cont = __ballot(pos + lane < cnt && k / p2 == prev);
+      const int run = __builtin_ctzll(~cont);
+      pos += run;
+      if (run < kWave) break;
+    }
+    if (pos >= end) return;  // the window holds nothing but the tail of an earlier group
   }
 
-  const int64_t cnt = live_count(nnz, nnz_dev);
-  const int64_t begin = ((int64_t)blockIdx.x * NW + wave) * ids_per_wave;
-  const int64_t end = begin + ids_per_wave < cnt ? begin + ids_per_wave : cnt;
+  // ---- lane-constant LDS offsets of the MFMA operands ----
+  // dP step (b4, kk): lane group `hi` contributes id b = 4 b4 + hi, column kk of that id
+  int offA[C::MT2], offB[C::RT2], offE[C::NT2];
+#pragma unroll
+  for (int mt = 0; mt < C::MT2; ++mt) {
+    const int m = 16 * mt + lo < C::M2 ? 16 * mt + lo : C::M2 - 1;  // rows past M2 are discarded
+    offA[mt] = hi * C::LDO + m * Q2;
+  }
+#pragma unroll
+  for (int t = 0; t < C::RT2; ++t) offB[t] = hi * C::LDB + ((16 * t + lo) % R2) * Q2;
+#pragma unroll
+  for (int nt = 0; nt < C::NT2; ++nt) {
+    const int col = 16 * nt + lo;
+    offE[nt] = (col / Q2) * C::LDO + col % Q2 + hi * Q2;
+  }
+  constexpr int F4G = C::ROW2 / 4, NLG = (kChunk * F4G + kWave - 1) / kWave;  // G2-row float4 loads per lane
+  constexpr int F4D = C::D / 4, NLD = (kChunk * F4D + kWave - 1) / kWave;     // d_output-row float4 loads per lane
 
-  f32x4 dp[C::MT2][C::RT2];     // dP of the current group
-  f32x4 g1acc[C::RT1][C::NT1];  // dG1[i1] of the current i1
+  f32x4 dp[C::MT2][C::RT2];
+  uint32_t cur_group = 0xffffffffu;
+  auto store_dp = [&]() {
+    float* dst = plan.dptab + (size_t)cur_group * (C::M2 * R2);
+#pragma unroll
+    for (int mt = 0; mt < C::MT2; ++mt)
+#pragma unroll
+      for (int t = 0; t < C::RT2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = 16 * mt + 4 * hi + r;
+          const int c2 = 16 * t + lo;
+          if (m < C::M2 && c2 < R2) dst[m * R2 + c2] = dp[mt][t][r];
+        }
+  };
+
+  // ---- chunk discovery over a sliding 64-id register window ----
+  int64_t win = -kWave;
+  uint32_t key_r = 0xffffffffu, val_r = 0;
+  struct Chunk {
+    int len;            // ids in the chunk, 0 = nothing left for this wavefront
+    uint32_t group, i2, val;
+  };
+  auto discover = [&](int64_t at, uint32_t open_group) {
+    Chunk c;
+    c.len = 0;
+    c.group = 0xffffffffu;
+    c.i2 = 0;
+    c.val = 0;
+    if (at >= cnt) return c;
+    if (at + kChunk > win + kWave) {  // slide the window
+      win = at;
+      key_r = 0xffffffffu;
+      if (win + lane < cnt) {
+        key_r = plan.keys[win + lane];
+        val_r = plan.vals[win + lane];
+      }
+    }
+    const int off = (int)(at - win);
+    const uint32_t key = __shfl(key_r, (off + lo) & 63, kWave);
+    c.val = __shfl(val_r, (off + lo) & 63, kWave);
+    c.group = __shfl(key_r, off, kWave) / p2;
+    if (at >= end && c.group != open_group) return c;  // past the window: only the open group continues
+    const uint32_t my_group = key / p2;
+    const unsigned long long same = __ballot(hi == 0 && at + lo < cnt && my_group == c.group);
+    c.len = __builtin_ctzll(~same);
+    c.i2 = lo < c.len ? key - my_group * p2 : 0u;
+    return c;
+  };
+  // the chunk's G2 rows and d_output rows travel through registers: they are requested one
+  // chunk ahead so that their HBM / L2 latency hides behind the previous chunk's MFMAs
+  float4 pre_g[NLG], pre_d[NLD];
+  auto request_rows = [&](const Chunk& c) {
+#pragma unroll
+    for (int it = 0; it < NLG; ++it) {
+      const int f = it * kWave + lane;
+      const int b = f / F4G, c4 = f - b * F4G;
+      const uint32_t row2 = __shfl(c.i2, b < kChunk ? b : 0, kWave);
+      pre_g[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (f < kChunk * F4G) pre_g[it] = *reinterpret_cast<const float4*>(G2 + (size_t)row2 * C::ROW2 + 4 * c4);
+    }
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {
+      const int f = it * kWave + lane;
+      const int b = f / F4D, c4 = f - b * F4D;
+      const uint32_t v = __shfl(c.val, b < kChunk ? b : 0, kWave);
+      pre_d[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (f < kChunk * F4D && b < c.len)
+        pre_d[it] = *reinterpret_cast<const float4*>(d_out + (size_t)(v & ~kMultiBit) * C::D + 4 * c4);
+    }
+  };
+
+  Chunk cur = discover(pos, cur_group);
+  if (cur.len) request_rows(cur);
+  while (cur.len) {
+    // ---- group change: close the previous group, form P = G0[i0] . G1[i1] ----
+    if (cur.group != cur_group) {
+      if (cur_group != 0xffffffffu) store_dp();
+      cur_group = cur.group;
+#pragma unroll
+      for (int mt = 0; mt < C::MT2; ++mt)
+#pragma unroll
+        for (int t = 0; t < C::RT2; ++t) dp[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const uint32_t i1 = cur_group / p0;
+      const uint32_t i0 = cur_group - i1 * p0;
+      const float* g0 = G0 + (size_t)i0 * C::ROW0;
+      const float* g1 = G1 + (size_t)i1 * C::ROW1;
+      f32x4 acc[C::NT1];
+#pragma unroll
+      for (int nt = 0; nt < C::NT1; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < C::KS1; ++s) {
+        const int k = 4 * s + hi;
+        const float a = lo < Q0 ? g0[lo * R1 + k] : 0.f;
+#pragma unroll
+        for (int nt = 0; nt < C::NT1; ++nt) {
+          const float b = g1[k * C::N1 + 16 * nt + lo];
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[nt], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int nt = 0; nt < C::NT1; ++nt) {
+        const int n = 16 * nt + lo;
+        const int j = n / R2, c2 = n % R2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int a = 4 * hi + r;
+          if (a < Q0) pbuf[(a * Q1 + j) * C::LDA + c2] = acc[nt][r];
+        }
+      }
+    }
+    // ---- the chunk's rows: registers -> LDS ----
+#pragma unroll
+    for (int it = 0; it < NLG; ++it) {
+      const int f = it * kWave + lane;
+      const int b = f / F4G, c4 = f - b * F4G;
+      if (f < kChunk * F4G) *reinterpret_cast<float4*>(bbuf + b * C::LDB + 4 * c4) = pre_g[it];
+    }
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {
+      const int f = it * kWave + lane;
+      const int b = f / F4D, c4 = f - b * F4D;
+      if (f < kChunk * F4D) *reinterpret_cast<float4*>(dbuf + b * C::LDO + 4 * c4) = pre_d[it];
+    }
+    // ---- request the next chunk's rows now; they land while this chunk computes ----
+    const int64_t here = pos;
+    const int len = cur.len;
+    pos += len;
+    cur = discover(pos, cur_group);
+    if (cur.len) request_rows(cur);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- dP += dO (q0q1 x 16 q2) . G2s^T (16 q2 x r2) ----
+#pragma unroll
+    for (int b4 = 0; b4 < kChunk / 4; ++b4)
+#pragma unroll
+      for (int kk = 0; kk < Q2; ++kk) {
+        float av[C::MT2], bv[C::RT2];
+#pragma unroll
+        for (int mt = 0; mt < C::MT2; ++mt) av[mt] = dbuf[offA[mt] + b4 * 4 * C::LDO + kk];
+#pragma unroll
+        for (int t = 0; t < C::RT2; ++t) {
+          bv[t] = bbuf[offB[t] + b4 * 4 * C::LDB + kk];
+          if (16 * t + lo >= R2) bv[t] = 0.f;
+        }
+#pragma unroll
+        for (int mt = 0; mt < C::MT2; ++mt)
+#pragma unroll
+          for (int t = 0; t < C::RT2; ++t)
+            dp[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv[t], dp[mt][t], 0, 0, 0);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- E = P^T (r2 x q0q1) . dO (q0q1 x 16 q2) ----
+    f32x4 e[C::RT2][C::NT2];
+#pragma unroll
+    for (int t = 0; t < C::RT2; ++t)
+#pragma unroll
+      for (int nt = 0; nt < C::NT2; ++nt) e[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < C::M2 / 4; ++s) {
+      float av[C::RT2];
+#pragma unroll
+      for (int t = 0; t < C::RT2; ++t) {
+        av[t] = pbuf[(4 * s + hi) * C::LDA + (16 * t + lo) % R2];
+        if (16 * t + lo >= R2) av[t] = 0.f;
+      }
+#pragma unroll
+      for (int nt = 0; nt < C::NT2; ++nt) {
+        const float bv = dbuf[offE[nt] + 4 * s * Q2];
+#pragma unroll
+        for (int t = 0; t < C::RT2; ++t)
+          e[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv, e[t][nt], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // every dO read is done: the region now takes the E rows
+    // E accumulators (row c2 = 16 t + 4 hi + r, col 16 nt + lo) -> LDS [id][c2 * q2 + kk]
+#pragma unroll
+    for (int nt = 0; nt < C::NT2; ++nt) {
+      const int col = 16 * nt + lo;
+      const int b = col / Q2, kk = col % Q2;
+#pragma unroll
+      for (int t = 0; t < C::RT2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c2 = 16 * t + 4 * hi + r;
+          if (c2 < R2) dbuf[b * C::LDB + c2 * Q2 + kk] = e[t][nt][r];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int it = 0; it < NLG; ++it) {
+      const int f = it * kWave + lane;
+      const int b = f / F4G, c4 = f - b * F4G;
+      if (f < kChunk * F4G && b < len)  // the chunk's rows are consecutive in the table
+        *reinterpret_cast<float4*>(plan.etab + (size_t)(here + b) * C::ROW2 + 4 * c4) =
+            *reinterpret_cast<const float4*>(dbuf + b * C::LDB + 4 * c4);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (cur_group != 0xffffffffu) store_dp();
+}
+
+// B. dG2 reduce.  A workgroup takes kRowsB consecutive E rows, buckets them by i2 inside LDS
+// (a tile-local counting sort of row numbers), then each wave sums the rows of "its" i2 values
+// in registers and adds one (r2 q2)-float row per touched i2 to dG2.  E rows are read exactly
+// once, 16 bytes per lane; the only float atomics are the per-tile row flushes.
+constexpr int kRowsB = 2048;
+constexpr int NWB = 8;
+template <int ROW2>
+__global__ __launch_bounds__(NWB * 64) void fast3_dg2_reduce_kernel(GroupPlan plan, int G, uint32_t p2,
+                                                                     float* __restrict__ dG2) {
+  extern __shared__ uint32_t lds_u[];   // [p2 + 1] bucket starts | [p2] cursors | [kRowsB] row list (uint16)
+  uint32_t* bstart = lds_u;
+  uint32_t* cursor = lds_u + p2 + 1;
+  unsigned short* rows = reinterpret_cast<unsigned short*>(cursor + p2);
+  constexpr int F4 = ROW2 / 4;      // float4 per row
+  constexpr int SUB = kWave / F4;   // rows handled per load instruction
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const uint32_t total = plan.gstart[G];
+  const uint32_t s0 = blockIdx.x * kRowsB;
+  if (s0 >= total) return;
+  const uint32_t n_rows = s0 + kRowsB < total ? kRowsB : total - s0;
+  for (uint32_t e = tid; e <= p2; e += NWB * 64) bstart[e] = 0;
+  __syncthreads();
+  // histogram of i2 over the tile (integer LDS atomics; 8 ids per thread)
+  uint32_t my_i2[kRowsB / (NWB * 64)], my_rank[kRowsB / (NWB * 64)];
+#pragma unroll
+  for (int k = 0; k < kRowsB / (NWB * 64); ++k) {
+    const uint32_t r = k * NWB * 64 + tid;
+    my_i2[k] = 0xffffffffu;
+    if (r < n_rows) {
+      const uint32_t key = plan.keys[s0 + r];
+      my_i2[k] = key - (key / p2) * p2;
+      my_rank[k] = atomicAdd(&bstart[my_i2[k] + 1], 1u);
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {  // exclusive scan of <= 1024 buckets by one wave
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < p2; base += kWave) {
+      const uint32_t i = base + lane;
+      uint32_t v = i < p2 ? bstart[i + 1] : 0u;
+      uint32_t incl = v;
+#pragma unroll
+      for (int d = 1; d < kWave; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d, kWave);
+        if (lane >= d) incl += up;
+      }
+      if (i < p2) bstart[i + 1] = carry + incl;
+      carry += __shfl(incl, kWave - 1, kWave);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kRowsB / (NWB * 64); ++k)
+    if (my_i2[k] != 0xffffffffu) rows[bstart[my_i2[k]] + my_rank[k]] = (unsigned short)(k * NWB * 64 + tid);
+  __syncthreads();
+  // wave w sums the buckets i2 = w, w + NWB, ...
+  const int sub = lane / F4, c4 = lane - sub * F4;
+  for (uint32_t i2 = wave; i2 < p2; i2 += NWB) {
+    const uint32_t b0 = bstart[i2], b1 = bstart[i2 + 1];
+    if (b0 == b1) continue;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (sub < SUB) {
+      // four independent row loads in flight per lane group (the loop is latency-bound otherwise)
+      for (uint32_t j = b0 + sub; j < b1; j += 4 * SUB) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          const uint32_t jj = j + u * SUB;
+          if (jj < b1) v[u] = *reinterpret_cast<const float4*>(plan.etab + (size_t)(s0 + rows[jj]) * ROW2 + 4 * c4);
+        }
+        acc.x += (v[0].x + v[1].x) + (v[2].x + v[3].x);
+        acc.y += (v[0].y + v[1].y) + (v[2].y + v[3].y);
+        acc.z += (v[0].z + v[1].z) + (v[2].z + v[3].z);
+        acc.w += (v[0].w + v[1].w) + (v[2].w + v[3].w);
+      }
+    }
+#pragma unroll
+    for (int k = 1; k < SUB; ++k) {
+      const int src = (lane + k * F4) & 63;
+      const float x = __shfl(acc.x, src, kWave), y = __shfl(acc.y, src, kWave);
+      const float z = __shfl(acc.z, src, kWave), w = __shfl(acc.w, src, kWave);
+      if (lane < F4) { acc.x += x; acc.y += y; acc.z += z; acc.w += w; }
+    }
+    if (lane < F4) {
+      float* dst = dG2 + (size_t)i2 * ROW2 + 4 * lane;
+      atomicAdd(dst + 0, acc.x);
+      atomicAdd(dst + 1, acc.y);
+      atomicAdd(dst + 2, acc.z);
+      atomicAdd(dst + 3, acc.w);
+    }
+  }
+}
+
+// C. group epilogue: one wavefront per kGroupsC consecutive groups (empty ones are skipped)
+constexpr int kGroupsC = 8;
+template <int Q0, int Q1, int Q2, int R1, int R2>
+__global__ __launch_bounds__(64) void fast3_group_epilogue_kernel(
+    const float* __restrict__ G0, const float* __restrict__ G1, uint32_t p0, uint32_t G, GroupPlan plan,
+    float* __restrict__ dG0, float* __restrict__ dG1) {
+  using C = Cfg<Q0, Q1, Q2, R1, R2>;
+  __shared__ __attribute__((aligned(16))) float dpbuf[C::P_FLOATS];
+  __shared__ __attribute__((aligned(16))) float g1buf[R1 * C::LDG];
+  const int lane = threadIdx.x;
+  const int hi = lane >> 4, lo = lane & 15;
+  const uint32_t g_begin = blockIdx.x * kGroupsC;
+  const uint32_t g_end = g_begin + kGroupsC < G ? g_begin + kGroupsC : G;
+
+  f32x4 g1acc[C::RT1][C::NT1];
 #pragma unroll
   for (int t = 0; t < C::RT1; ++t)
 #pragma unroll
     for (int nt = 0; nt < C::NT1; ++nt) g1acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int mt = 0; mt < C::MT2; ++mt)
-#pragma unroll
-    for (int t = 0; t < C::RT2; ++t) dp[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  uint32_t cur_group = 0xffffffffu, cur_i1 = 0xffffffffu, cur_i0 = 0;
-
-  // dG1[i1] += accumulators ; accumulators = 0
+  uint32_t cur_i1 = 0xffffffffu;
   auto flush_g1 = [&]() {
     float* dst = dG1 + (size_t)cur_i1 * C::ROW1;
 #pragma unroll
@@ -368,38 +687,31 @@ __global__ __launch_bounds__(NW * 64) void fast3_backward_kernel(
       }
   };
 
-  // group epilogue: fold the group's dP into dG1 (registers) and dG0 (atomics)
-  auto flush_group = [&]() {
-    float* dpbuf = bbuf;
-    float* g1buf = dbuf;
-    // dP accumulators (row 16 mt + 4 hi + r, col 16 t + lo) -> LDS matrix [m2][c2]
+  for (uint32_t g = g_begin; g < g_end; ++g) {
+    if (plan.counts[g] == 0) continue;  // wave-uniform
+    const uint32_t i1 = g / p0, i0 = g - i1 * p0;
+    // dP of the group -> LDS matrix [m2][c2]
+    {
+      const float* src = plan.dptab + (size_t)g * (C::M2 * R2);
 #pragma unroll
-    for (int mt = 0; mt < C::MT2; ++mt)
-#pragma unroll
-      for (int t = 0; t < C::RT2; ++t) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = 16 * mt + 4 * hi + r;
-          const int c2 = 16 * t + lo;
-          if (m < C::M2 && c2 < R2) dpbuf[m * C::LDA + c2] = dp[mt][t][r];
-        }
-        dp[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      }
-    // G1[i1] (r1 x q1 r2) -> LDS with a padded row stride, coalesced reads
-    const float* g1 = G1 + (size_t)cur_i1 * C::ROW1;
-#pragma unroll
-    for (int it = 0; it < (C::ROW1 + kWave - 1) / kWave; ++it) {
-      const int e = it * kWave + lane;
-      if (e < C::ROW1) {
-        const int c = e / C::N1, n = e - c * C::N1;
-        g1buf[c * C::LDG + n] = g1[e];
+      for (int i = 0; i < (C::M2 * R2 + kWave - 1) / kWave; ++i) {
+        const int e = i * kWave + lane;
+        if (e < C::M2 * R2) dpbuf[(e / R2) * C::LDA + e % R2] = src[e];
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (i1 != cur_i1) {
+      if (cur_i1 != 0xffffffffu) flush_g1();
+      cur_i1 = i1;
+      const float* g1 = G1 + (size_t)i1 * C::ROW1;
+#pragma unroll
+      for (int it = 0; it < (C::ROW1 + kWave - 1) / kWave; ++it) {
+        const int e = it * kWave + lane;
+        if (e < C::ROW1) g1buf[(e / C::N1) * C::LDG + e % C::N1] = g1[e];
+      }
+    }
+    __syncthreads();
     // dG1[i1] += G0[i0]^T (r1 x q0) . dP (q0 x q1 r2)
-    const float* g0 = G0 + (size_t)cur_i0 * C::ROW0;
+    const float* g0 = G0 + (size_t)i0 * C::ROW0;
 #pragma unroll
     for (int s = 0; s < (Q0 + 3) / 4; ++s) {
       const int a = 4 * s + hi;
@@ -431,180 +743,19 @@ __global__ __launch_bounds__(NW * 64) void fast3_backward_kernel(
         g0part[s & 3][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, g0part[s & 3][t], 0, 0, 0);
       }
     }
-    f32x4 g0acc[C::RT1];
+    float* dst0 = dG0 + (size_t)i0 * C::ROW0;
 #pragma unroll
-    for (int t = 0; t < C::RT1; ++t) g0acc[t] = (g0part[0][t] + g0part[1][t]) + (g0part[2][t] + g0part[3][t]);
-    float* dst0 = dG0 + (size_t)cur_i0 * C::ROW0;
-#pragma unroll
-    for (int t = 0; t < C::RT1; ++t)
+    for (int t = 0; t < C::RT1; ++t) {
+      const f32x4 sum = (g0part[0][t] + g0part[1][t]) + (g0part[2][t] + g0part[3][t]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int a = 4 * hi + r;
-        if (a < Q0 && 16 * t + lo < R1) atomicAdd(dst0 + a * R1 + 16 * t + lo, g0acc[t][r]);
-      }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  };
-
-  int64_t pos = begin;
-  while (pos < end) {
-    // ---- chunk discovery (as in the forward) ----
-    uint32_t key = 0xffffffffu, val = 0;
-    if (lo + pos < end && hi == 0) {
-      key = keys[pos + lo];
-      val = vals[pos + lo];
-    }
-    const uint32_t key0 = __shfl(key, 0, kWave);
-    const uint32_t group0 = key0 / p2;
-    const uint32_t my_group = key / p2;
-    const unsigned long long same = __ballot(hi == 0 && lo + pos < end && my_group == group0);
-    const int len = __builtin_ctzll(~same);
-    const uint32_t i2 = (lo < len && hi == 0) ? key - my_group * p2 : 0u;
-
-    if (group0 != cur_group) {
-      if (cur_group != 0xffffffffu && !(dbg & 2)) flush_group();
-      const uint32_t i1 = group0 / p0;
-      if (i1 != cur_i1) {
-        if (cur_i1 != 0xffffffffu) flush_g1();
-        cur_i1 = i1;
-      }
-      cur_group = group0;
-      cur_i0 = group0 - i1 * p0;
-      // ---- stage 1: P = G0[i0] . G1[i1] -> LDS ----
-      const float* g0 = G0 + (size_t)cur_i0 * C::ROW0;
-      const float* g1 = G1 + (size_t)cur_i1 * C::ROW1;
-      f32x4 acc[C::NT1];
-#pragma unroll
-      for (int nt = 0; nt < C::NT1; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < C::KS1; ++s) {
-        const int k = 4 * s + hi;
-        const float a = lo < Q0 ? g0[lo * R1 + k] : 0.f;
-#pragma unroll
-        for (int nt = 0; nt < C::NT1; ++nt) {
-          const float b = g1[k * C::N1 + 16 * nt + lo];
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[nt], 0, 0, 0);
-        }
-      }
-#pragma unroll
-      for (int nt = 0; nt < C::NT1; ++nt) {
-        const int n = 16 * nt + lo;
-        const int j = n / R2, c2 = n % R2;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int a = 4 * hi + r;
-          if (a < Q0) pbuf[(a * Q1 + j) * C::LDA + c2] = acc[nt][r];
-        }
+        if (a < Q0 && 16 * t + lo < R1) atomicAdd(dst0 + a * R1 + 16 * t + lo, sum[r]);
       }
     }
-
-    // ---- stage the chunk's G2 rows and d_output rows (zero rows for unused slots) ----
-    __builtin_amdgcn_sched_barrier(0);
-    {
-      constexpr int F4 = C::ROW2 / 4;
-#pragma unroll
-      for (int it = 0; it < (kChunk * F4 + kWave - 1) / kWave; ++it) {
-        const int f = it * kWave + lane;
-        const int b = f / F4, c4 = f - b * F4;
-        const uint32_t row2 = __shfl(i2, b < kChunk ? b : 0, kWave);
-        if (f < kChunk * F4) {
-          const float4 v = *reinterpret_cast<const float4*>(G2 + (size_t)row2 * C::ROW2 + 4 * c4);
-          *reinterpret_cast<float4*>(bbuf + b * C::LDB + 4 * c4) = v;
-        }
-      }
-      constexpr int D4 = C::D / 4;
-#pragma unroll
-      for (int it = 0; it < (kChunk * D4 + kWave - 1) / kWave; ++it) {
-        const int f = it * kWave + lane;
-        const int b = f / D4, c4 = f - b * D4;
-        const uint32_t v = __shfl(val, b < kChunk ? b : 0, kWave);
-        if (f < kChunk * D4) {
-          float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (b < len && !(dbg & 8)) x = *reinterpret_cast<const float4*>(d_out + (size_t)(v & ~kMultiBit) * C::D + 4 * c4);
-          *reinterpret_cast<float4*>(dbuf + b * C::LDO + 4 * c4) = x;
-        }
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-    // ---- dP += dO (q0q1 x 16 q2) . G2s^T (16 q2 x r2) ----
-    __builtin_amdgcn_sched_barrier(0);
-    if (!(dbg & 4))
-#pragma unroll
-    for (int s = 0; s < 4 * Q2; ++s) {
-      const int col = 4 * s + hi;
-      const int b = col / Q2, kk = col % Q2;
-      float av[C::MT2], bv[C::RT2];
-#pragma unroll
-      for (int mt = 0; mt < C::MT2; ++mt) {
-        const int m = 16 * mt + lo < C::M2 ? 16 * mt + lo : C::M2 - 1;  // rows past M2 are discarded
-        av[mt] = dbuf[b * C::LDO + m * Q2 + kk];
-      }
-#pragma unroll
-      for (int t = 0; t < C::RT2; ++t) bv[t] = 16 * t + lo < R2 ? bbuf[b * C::LDB + (16 * t + lo) * Q2 + kk] : 0.f;
-#pragma unroll
-      for (int mt = 0; mt < C::MT2; ++mt)
-#pragma unroll
-        for (int t = 0; t < C::RT2; ++t)
-          dp[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv[t], dp[mt][t], 0, 0, 0);
-    }
-
-    // ---- dG2s = P^T (r2 x q0q1) . dO (q0q1 x 16 q2), scattered per id ----
-    __builtin_amdgcn_sched_barrier(0);
-    {
-      f32x4 e[C::RT2][C::NT2];
-#pragma unroll
-      for (int t = 0; t < C::RT2; ++t)
-#pragma unroll
-        for (int nt = 0; nt < C::NT2; ++nt) e[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < C::M2 / 4; ++s) {
-        const int m = 4 * s + hi;
-        float av[C::RT2];
-#pragma unroll
-        for (int t = 0; t < C::RT2; ++t) av[t] = 16 * t + lo < R2 ? pbuf[m * C::LDA + 16 * t + lo] : 0.f;
-#pragma unroll
-        for (int nt = 0; nt < C::NT2; ++nt) {
-          const int col = 16 * nt + lo;
-          const float bv = dbuf[(col / Q2) * C::LDO + m * Q2 + col % Q2];
-#pragma unroll
-          for (int t = 0; t < C::RT2; ++t)
-            e[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv, e[t][nt], 0, 0, 0);
-        }
-      }
-#pragma unroll
-      for (int nt = 0; nt < C::NT2; ++nt) {
-        const int col = 16 * nt + lo;
-        const int b = col / Q2, kk = col % Q2;
-        const uint32_t row2 = __shfl(i2, b, kWave);
-        float* dst = G2LDS ? g2acc + row2 * C::LD2 + kk : dG2 + (size_t)row2 * C::ROW2 + kk;
-#pragma unroll
-        for (int t = 0; t < C::RT2; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int c2 = 16 * t + 4 * hi + r;
-            if (c2 < R2 && b < len && !(dbg & 1)) atomicAdd(dst + c2 * Q2, e[t][nt][r]);
-          }
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    pos += len;
-  }
-  if (cur_group != 0xffffffffu) {
-    flush_group();
-    flush_g1();
-  }
-  if (G2LDS) {
     __syncthreads();
-    for (int e = threadIdx.x; e < g2_floats; e += NW * 64) {
-      const int row = e / C::ROW2;
-      const float v = g2acc[row * C::LD2 + (e - row * C::ROW2)];
-      if (v != 0.f) atomicAdd(dG2 + e, v);
-    }
   }
+  if (cur_i1 != 0xffffffffu) flush_g1();
 }
 
 // ---------------------------------------------------------------------------------
@@ -628,56 +779,76 @@ bool fast3_supported(const DevShape& s) { return classify(s) != kNone; }
 
 static int64_t num_groups(const DevShape& s) { return (int64_t)s.p[0] * s.p[1]; }
 
-int64_t fast3_workspace_bytes(const DevShape& s, int32_t op, int64_t nnz, int64_t B) {
-  (void)op;
-  (void)B;
-  return 4 * align256(nnz * 4) + align256((num_groups(s) + 1) * 4) + 256;
+// rocPRIM's look-back scan needs a few bytes per block of ~1K items; reserve a generous bound so
+// that sizing the workspace needs no HIP call (the launch checks the real requirement)
+static int64_t scan_temp_bytes(int64_t G) { return 64 * 1024 + (G + 1) / 8; }
+
+// carve the workspace; `bwd` adds the E rows and the per-group dP table
+static int64_t carve_plan(const DevShape& s, int64_t nnz, bool bwd, char* base, GroupPlan* plan, char** scan_tmp,
+                          int64_t scan_bytes) {
+  const int64_t G = num_groups(s);
+  int64_t off = 0;
+  auto take = [&](int64_t bytes) {
+    char* p = base ? base + off : nullptr;
+    off += align256(bytes);
+    return p;
+  };
+  GroupPlan pl;
+  memset(&pl, 0, sizeof(pl));
+  pl.keys_in = (uint32_t*)take(nnz * 4);
+  pl.vals_in = (uint32_t*)take(nnz * 4);
+  pl.rank_in = (uint32_t*)take(nnz * 4);
+  pl.keys = (uint32_t*)take(nnz * 4);
+  pl.vals = (uint32_t*)take(nnz * 4);
+  pl.counts = (uint32_t*)take((G + 1) * 4);
+  pl.gstart = (uint32_t*)take((G + 1) * 4);
+  char* tmp = take(scan_bytes);
+  if (scan_tmp) *scan_tmp = tmp;
+  if (bwd) {
+    pl.etab = (float*)take(nnz * (int64_t)s.row_len[2] * 4);
+    pl.dptab = (float*)take(G * (int64_t)s.q[0] * s.q[1] * s.R[2] * 4);
+  }
+  if (plan) *plan = pl;
+  return off;
 }
 
-struct SortedIds {
-  uint32_t* keys;
-  uint32_t* vals;
-  uint32_t sentinel;
-};
+int64_t fast3_workspace_bytes(const DevShape& s, int32_t op, int64_t nnz, int64_t B) {
+  (void)B;
+  const int64_t tmp = scan_temp_bytes(num_groups(s));
+  return carve_plan(s, nnz, op == TTEMB_OP_BACKWARD, nullptr, nullptr, nullptr, tmp) + 256;
+}
 
-static int sort_ids(const DevShape& s, const int64_t* indices, const int64_t* rowidx, int64_t nnz,
-                    const int32_t* nnz_dev, void* ws, int64_t ws_bytes, SortedIds* out, hipStream_t st) {
+static int group_ids(const DevShape& s, bool bwd, const int64_t* indices, const int64_t* rowidx, int64_t nnz,
+                     const int32_t* nnz_dev, void* ws, int64_t ws_bytes, GroupPlan* plan, hipStream_t st) {
   if (ws == nullptr) return fail(TTEMB_E_WORKSPACE, "fast path needs a workspace");
-  char* base = reinterpret_cast<char*>(ws);
-  const int64_t seg = align256(nnz * 4);
   const int64_t G = num_groups(s);
-  uint32_t* k_in = reinterpret_cast<uint32_t*>(base);
-  uint32_t* v_in = reinterpret_cast<uint32_t*>(base + seg);
-  uint32_t* k_out = reinterpret_cast<uint32_t*>(base + 2 * seg);
-  uint32_t* v_out = reinterpret_cast<uint32_t*>(base + 3 * seg);
-  uint32_t* counts = reinterpret_cast<uint32_t*>(base + 4 * seg);
-  if (4 * seg + (G + 1) * 4 > ws_bytes)
-    return fail(TTEMB_E_WORKSPACE, "fast path needs %lld workspace bytes, got %lld",
-                (long long)(4 * seg + (G + 1) * 4), (long long)ws_bytes);
+  size_t tmp_bytes = 0;
+  uint32_t* nul = nullptr;
+  hipError_t e = rocprim::exclusive_scan(nullptr, tmp_bytes, nul, nul, 0u, (size_t)(G + 1), rocprim::plus<uint32_t>(), st, false);
+  if (e != hipSuccess) return check_hip(e, "exclusive_scan(size)");
+  if ((int64_t)tmp_bytes > scan_temp_bytes(G)) return fail(TTEMB_E_WORKSPACE, "scan scratch bound too small");
+  char* scan_tmp = nullptr;
+  const int64_t need = carve_plan(s, nnz, bwd, reinterpret_cast<char*>(ws), plan, &scan_tmp, scan_temp_bytes(G));
+  if (need > ws_bytes)
+    return fail(TTEMB_E_WORKSPACE, "fast path needs %lld workspace bytes, got %lld", (long long)need, (long long)ws_bytes);
   const uint32_t sentinel = (uint32_t)((unsigned long long)s.L[0] * s.p[0]);
-  int rc = check_hip(hipMemsetAsync(counts, 0, (size_t)(G + 1) * 4, st), "memset counts");
+  int rc = check_hip(hipMemsetAsync(plan->counts, 0, (size_t)(G + 1) * 4, st), "memset counts");
   if (rc) return rc;
-  const int threads = 256;
-  const unsigned blocks = (unsigned)((nnz + threads - 1) / threads);
-  hipLaunchKernelGGL(fast3_keys_hist_kernel, dim3(blocks), dim3(threads), 0, st, indices, rowidx, nnz, nnz_dev,
-                     sentinel, (uint32_t)s.p[0], (uint32_t)s.p[1], (uint32_t)s.p[2], k_in, v_in, counts);
-  rc = check_hip(hipGetLastError(), "fast3_keys_hist_kernel");
+  const unsigned tiles = (unsigned)((nnz + kTile - 1) / kTile);
+  hipLaunchKernelGGL(fast3_prep_kernel, dim3(tiles), dim3(kTile), 0, st, indices, rowidx, nnz, nnz_dev, sentinel,
+                     (uint32_t)s.p[0], (uint32_t)s.p[1], (uint32_t)s.p[2], *plan);
+  rc = check_hip(hipGetLastError(), "fast3_prep_kernel");
   if (rc) return rc;
-  hipLaunchKernelGGL(fast3_scan_kernel, dim3(1), dim3(1024), 0, st, counts, (int)G);
-  rc = check_hip(hipGetLastError(), "fast3_scan_kernel");
-  if (rc) return rc;
-  hipLaunchKernelGGL(fast3_scatter_kernel, dim3(blocks), dim3(threads), 0, st, k_in, v_in, nnz, nnz_dev,
-                     (uint32_t)s.p[2], counts, k_out, v_out);
-  rc = check_hip(hipGetLastError(), "fast3_scatter_kernel");
-  if (rc) return rc;
-  out->keys = k_out;
-  out->vals = v_out;
-  out->sentinel = sentinel;
-  return TTEMB_OK;
+  // gstart[g] = first grouped position of group g; gstart[G] = number of live ids
+  e = rocprim::exclusive_scan(scan_tmp, tmp_bytes, plan->counts, plan->gstart, 0u, (size_t)(G + 1),
+                              rocprim::plus<uint32_t>(), st, false);
+  if (e != hipSuccess) return check_hip(e, "exclusive_scan");
+  hipLaunchKernelGGL(fast3_scatter_kernel, dim3(tiles), dim3(kTile), 0, st, nnz, nnz_dev, (uint32_t)s.p[2], *plan);
+  return check_hip(hipGetLastError(), "fast3_scatter_kernel");
 }
 
 template <int Q0, int Q1, int Q2, int R1, int R2>
-static int run_forward(const DevShape& s, const CorePtrs& cores, const SortedIds& ids, int64_t nnz,
+static int run_forward(const DevShape& s, const CorePtrs& cores, const GroupPlan& ids, int64_t nnz,
                        const int32_t* nnz_dev, float* output, hipStream_t st) {
   using C = Cfg<Q0, Q1, Q2, R1, R2>;
   const size_t lds = 4 * C::WAVE_FLOATS * sizeof(float);
@@ -703,8 +874,8 @@ int launch_forward_fast3(const DevShape& s, const CorePtrs& cores, const int64_t
                          const int64_t* rowidx, int64_t nnz, const int32_t* nnz_dev, float* output,
                          void* ws, int64_t ws_bytes, hipStream_t st) {
   if (nnz <= 0) return TTEMB_OK;
-  SortedIds ids;
-  int rc = sort_ids(s, indices, rowidx, nnz, nnz_dev, ws, ws_bytes, &ids, st);
+  GroupPlan ids;
+  int rc = group_ids(s, false, indices, rowidx, nnz, nnz_dev, ws, ws_bytes, &ids, st);
   if (rc) return rc;
   switch (classify(s)) {
     case kProducts: return run_forward<4, 5, 5, 16, 16>(s, cores, ids, nnz, nnz_dev, output, st);
@@ -714,45 +885,29 @@ int launch_forward_fast3(const DevShape& s, const CorePtrs& cores, const int64_t
   }
 }
 
-template <int Q0, int Q1, int Q2, int R1, int R2, int NW, bool G2LDS>
-static int run_backward_inst(const DevShape& s, const CorePtrs& cores, const SortedIds& ids, int64_t nnz,
-                             const int32_t* nnz_dev, const float* d_output, const CorePtrsMut& d_cores, hipStream_t st) {
+template <int Q0, int Q1, int Q2, int R1, int R2>
+static int run_backward(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int64_t nnz,
+                        const int32_t* nnz_dev, const float* d_output, const CorePtrsMut& d_cores,
+                        hipStream_t st) {
   using C = Cfg<Q0, Q1, Q2, R1, R2>;
-  const int g2_floats = s.p[2] * C::ROW2;
-  const size_t lds = ((G2LDS ? ((s.p[2] * C::LD2 + 3) & ~3) : 0) + (size_t)NW * C::BWD_WAVE_FLOATS) * sizeof(float);
-  // one workgroup per CU at most; every wave walks one contiguous slice of the sorted ids
-  const int64_t max_waves = 256 * NW;
-  int64_t waves = (nnz + kRange - 1) / kRange;
-  if (waves > max_waves) waves = max_waves;
-  const int64_t ids_per_wave = (nnz + waves - 1) / waves;
-  const unsigned blocks = (unsigned)((waves + NW - 1) / NW);
-  static bool attr_set = false;
-  if (!attr_set) {
-    int rc = check_hip(
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&fast3_backward_kernel<Q0, Q1, Q2, R1, R2, NW, G2LDS>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-        "hipFuncSetAttribute");
-    if (rc) return rc;
-    attr_set = true;
-  }
+  const size_t lds = (size_t)(C::P_FLOATS + C::B_FLOATS + C::O_FLOATS) * sizeof(float);
+  const unsigned ranges = (unsigned)((nnz + kRange - 1) / kRange);
   profile_begin(1, st);
-  hipLaunchKernelGGL((fast3_backward_kernel<Q0, Q1, Q2, R1, R2, NW, G2LDS>), dim3(blocks), dim3(NW * 64), lds, st,
-                     cores.c[0], cores.c[1], cores.c[2], ids.keys, ids.vals, nnz, nnz_dev, (uint32_t)s.p[0],
-                     (uint32_t)s.p[2], ids_per_wave, d_output, d_cores.c[0], d_cores.c[1], d_cores.c[2], g2_floats,
-                     getenv("TTEMB_DBG") ? atoi(getenv("TTEMB_DBG")) : 0);
+  hipLaunchKernelGGL((fast3_bwd_chunk_kernel<Q0, Q1, Q2, R1, R2>), dim3(ranges), dim3(64), lds, st, cores.c[0],
+                     cores.c[1], cores.c[2], nnz, nnz_dev, (uint32_t)s.p[0], (uint32_t)s.p[2], d_output, plan);
+  int rc = check_hip(hipGetLastError(), "fast3_bwd_chunk_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL((fast3_dg2_reduce_kernel<C::ROW2>), dim3((unsigned)((nnz + kRowsB - 1) / kRowsB)),
+                     dim3(NWB * 64), (size_t)(2 * s.p[2] + 1) * 4 + kRowsB * 2, st, plan, (int)num_groups(s),
+                     (uint32_t)s.p[2], d_cores.c[2]);
+  rc = check_hip(hipGetLastError(), "fast3_dg2_reduce_kernel");
+  if (rc) return rc;
+  const int64_t G = num_groups(s);
+  hipLaunchKernelGGL((fast3_group_epilogue_kernel<Q0, Q1, Q2, R1, R2>), dim3((unsigned)((G + kGroupsC - 1) / kGroupsC)),
+                     dim3(64), 0, st, cores.c[0], cores.c[1], (uint32_t)s.p[0], (uint32_t)G, plan, d_cores.c[0],
+                     d_cores.c[1]);
   profile_end(1, st);
-  return check_hip(hipGetLastError(), "fast3_backward_kernel");
-}
-
-template <int Q0, int Q1, int Q2, int R1, int R2, int NW>
-static int run_backward(const DevShape& s, const CorePtrs& cores, const SortedIds& ids, int64_t nnz,
-                        const int32_t* nnz_dev, const float* d_output, const CorePtrsMut& d_cores, hipStream_t st) {
-  using C = Cfg<Q0, Q1, Q2, R1, R2>;
-  // a per-workgroup LDS copy of dG2 when the whole core fits beside the per-wave buffers
-  const size_t with_g2 = ((size_t)s.p[2] * C::LD2 + 4 + (size_t)NW * C::BWD_WAVE_FLOATS) * sizeof(float);
-  if (with_g2 <= 160 * 1024)
-    return run_backward_inst<Q0, Q1, Q2, R1, R2, NW, true>(s, cores, ids, nnz, nnz_dev, d_output, d_cores, st);
-  return run_backward_inst<Q0, Q1, Q2, R1, R2, NW, false>(s, cores, ids, nnz, nnz_dev, d_output, d_cores, st);
+  return check_hip(hipGetLastError(), "fast3_group_epilogue_kernel");
 }
 
 int launch_backward_fast3(const DevShape& s, const CorePtrs& cores, const int64_t* indices,
@@ -764,13 +919,13 @@ int launch_backward_fast3(const DevShape& s, const CorePtrs& cores, const int64_
     if (rc) return rc;
   }
   if (nnz <= 0) return TTEMB_OK;
-  SortedIds ids;
-  int rc = sort_ids(s, indices, rowidx, nnz, nnz_dev, ws, ws_bytes, &ids, st);
+  GroupPlan plan;
+  int rc = group_ids(s, true, indices, rowidx, nnz, nnz_dev, ws, ws_bytes, &plan, st);
   if (rc) return rc;
   switch (classify(s)) {
-    case kProducts: return run_backward<4, 5, 5, 16, 16, 8>(s, cores, ids, nnz, nnz_dev, d_output, d_cores, st);
-    case kArxiv: return run_backward<4, 4, 8, 8, 8, 8>(s, cores, ids, nnz, nnz_dev, d_output, d_cores, st);
-    case kPapers: return run_backward<8, 4, 4, 32, 32, 4>(s, cores, ids, nnz, nnz_dev, d_output, d_cores, st);
+    case kProducts: return run_backward<4, 5, 5, 16, 16>(s, cores, plan, nnz, nnz_dev, d_output, d_cores, st);
+    case kArxiv: return run_backward<4, 4, 8, 8, 8>(s, cores, plan, nnz, nnz_dev, d_output, d_cores, st);
+    case kPapers: return run_backward<8, 4, 4, 32, 32>(s, cores, plan, nnz, nnz_dev, d_output, d_cores, st);
     default: return fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
   }
 }
