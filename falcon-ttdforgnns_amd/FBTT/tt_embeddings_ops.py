@@ -211,7 +211,9 @@ class TTLookupFunction(torch.autograd.Function):
         cores = _nat.core_views(tt_cores, table)
         nnz = indices.numel()
         out = torch.empty((B, module.embedding_dim), dtype=torch.float32, device=indices.device)
-        _nat.forward(module._shape, cores, indices, rowidx, offsets, nnz, nnz_dev, B, out, module._ws)
+        # the forward's grouping of the ids is kept for the backward of this very call
+        ctx.plan = _nat.new_plan(module._shape, nnz, indices.device)
+        _nat.forward(module._shape, cores, indices, rowidx, offsets, nnz, nnz_dev, B, out, module._ws, ctx.plan)
         if ctx.live_cache and nnz > 0:
             _nat.cache_forward(cache_loc, rowidx, 0, nnz_dev, nnz, cache_weight.data, out)
         return out
@@ -227,21 +229,21 @@ class TTLookupFunction(torch.autograd.Function):
         if m.sparse:
             if m.optimizer in _SGD_LIKE:
                 _nat.backward_sgd(m._shape, cores, indices, rowidx, nnz, nnz_dev, B, d_output,
-                                  float(m.learning_rate), m._ws)
+                                  float(m.learning_rate), m._ws, ctx.plan)
                 if ctx.live_cache and nnz > 0:
                     _nat.cache_backward_sgd(cache_loc, rowidx, 0, nnz_dev, nnz, d_output,
                                             float(m.learning_rate), m.cache_weight.data)
             else:
                 state = _nat.core_views(list(m.optimizer_state), table)
                 _nat.backward_adagrad(m._shape, cores, state, indices, rowidx, nnz, nnz_dev, B, d_output,
-                                      float(m.learning_rate), float(m.eps), m._ws)
+                                      float(m.learning_rate), float(m.eps), m._ws, ctx.plan)
                 if ctx.live_cache and nnz > 0:
                     _nat.cache_backward_rowwise_adagrad(cache_loc, rowidx, 0, nnz_dev, nnz, d_output,
                                                         float(m.learning_rate), float(m.eps),
                                                         m.cache_optimizer_state, m.cache_weight.data)
             return (None,) * (n_fixed + len(cores))
         grads = [torch.empty_like(c) for c in cores]
-        _nat.backward_dense(m._shape, cores, indices, rowidx, nnz, nnz_dev, B, d_output, grads, m._ws)
+        _nat.backward_dense(m._shape, cores, indices, rowidx, nnz, nnz_dev, B, d_output, grads, m._ws, ctx.plan)
         d_cache = None
         if ctx.live_cache:
             d_cache = torch.empty_like(m.cache_weight.data)

@@ -95,10 +95,10 @@ static int64_t grad_scratch_bytes(const DevShape& s) {
   return b;
 }
 
-static bool use_fast3(const DevShape& s) {
+static bool use_fast3(const DevShape& s, int64_t nnz) {
   const int path = current_path();
-  if (path == TTEMB_PATH_GENERIC) return false;
-  return fast3_supported(s);
+  if (path == TTEMB_PATH_GENERIC || !fast3_supported(s)) return false;
+  return path == TTEMB_PATH_FAST3 || fast3_pays(s, nnz);
 }
 
 // rows whose bag length is not 1 must be zero before the lookups accumulate into them
@@ -164,9 +164,10 @@ static int check_lookup_args(const void* cores, const void* indices, int64_t nnz
 static int backward_into(const DevShape& ds, const CorePtrs& cp, const int64_t* indices,
                          const int64_t* rowidx, int64_t nnz, const int32_t* nnz_dev,
                          const float* d_output, const CorePtrsMut& dst, void* ws, int64_t ws_bytes,
-                         hipStream_t st) {
-  if (use_fast3(ds))
-    return launch_backward_fast3(ds, cp, indices, rowidx, nnz, nnz_dev, d_output, dst, ws, ws_bytes, st);
+                         const void* plan, int64_t plan_bytes, hipStream_t st) {
+  if (use_fast3(ds, nnz))
+    return launch_backward_fast3(ds, cp, indices, rowidx, nnz, nnz_dev, d_output, dst, ws, ws_bytes, plan,
+                                 plan_bytes, st);
   if (current_path() == TTEMB_PATH_FAST3) return fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
   for (int t = 0; t < ds.T; ++t) {
     int rc = check_hip(hipMemsetAsync(dst.c[t], 0, (size_t)ds.p[t] * ds.row_len[t] * 4, st), "memset d_core");
@@ -210,7 +211,7 @@ int64_t ttemb_workspace_bytes(const ttemb_shape_t* shape, int32_t op, int64_t nn
   DevShape ds;
   int rc = make_dev_shape(shape, &ds);
   if (rc) return rc;
-  const bool f3 = use_fast3(ds);
+  const bool f3 = use_fast3(ds, op == TTEMB_OP_CACHE_POPULATE ? B : nnz);
   switch (op) {
     case TTEMB_OP_FORWARD:
       return f3 ? fast3_workspace_bytes(ds, op, nnz, B) : 0;
@@ -226,10 +227,18 @@ int64_t ttemb_workspace_bytes(const ttemb_shape_t* shape, int32_t op, int64_t nn
   }
 }
 
+int64_t ttemb_plan_bytes(const ttemb_shape_t* shape, int64_t nnz) {
+  DevShape ds;
+  int rc = make_dev_shape(shape, &ds);
+  if (rc) return rc;
+  if (nnz < 0) return fail(TTEMB_E_BADARG, "negative size");
+  return use_fast3(ds, nnz) ? fast3_plan_bytes(ds, nnz) : 0;
+}
+
 int ttemb_forward(const ttemb_shape_t* shape, const float* const* cores, const int64_t* indices,
                   const int64_t* rowidx, const int64_t* offsets, int64_t nnz,
                   const int32_t* nnz_dev, int64_t B, float* output, void* workspace,
-                  int64_t workspace_bytes, void* stream) {
+                  int64_t workspace_bytes, void* plan, int64_t plan_bytes, void* stream) {
   DevShape ds;
   int rc = make_dev_shape(shape, &ds);
   if (rc) return rc;
@@ -250,8 +259,9 @@ int ttemb_forward(const ttemb_shape_t* shape, const float* const* cores, const i
   if (rc || nnz == 0) return rc;
   CorePtrs cp;
   for (int t = 0; t < TTEMB_MAX_CORES; ++t) cp.c[t] = t < ds.T ? cores[t] : nullptr;
-  if (use_fast3(ds))
-    return launch_forward_fast3(ds, cp, indices, rowidx, nnz, nnz_dev, output, workspace, workspace_bytes, st);
+  if (use_fast3(ds, nnz))
+    return launch_forward_fast3(ds, cp, indices, rowidx, nnz, nnz_dev, output, workspace, workspace_bytes, plan,
+                                plan_bytes, st);
   if (current_path() == TTEMB_PATH_FAST3) return fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
   return launch_forward_generic(ds, cp, indices, rowidx, nnz, nnz_dev, output, st);
 }
@@ -260,7 +270,7 @@ int ttemb_backward_dense(const ttemb_shape_t* shape, const float* const* cores,
                          const int64_t* indices, const int64_t* rowidx, int64_t nnz,
                          const int32_t* nnz_dev, int64_t B, const float* d_output,
                          float* const* d_cores, void* workspace, int64_t workspace_bytes,
-                         void* stream) {
+                         const void* plan, int64_t plan_bytes, void* stream) {
   DevShape ds;
   int rc = make_dev_shape(shape, &ds);
   if (rc) return rc;
@@ -279,13 +289,15 @@ int ttemb_backward_dense(const ttemb_shape_t* shape, const float* const* cores,
   const int64_t skip = grad_scratch_bytes(ds);
   char* ws = reinterpret_cast<char*>(workspace);
   const int64_t rest = workspace_bytes > skip ? workspace_bytes - skip : 0;
-  return backward_into(ds, cp, indices, rowidx, nnz, nnz_dev, d_output, dp, ws ? ws + skip : nullptr, rest, st);
+  return backward_into(ds, cp, indices, rowidx, nnz, nnz_dev, d_output, dp, ws ? ws + skip : nullptr, rest, plan,
+                       plan_bytes, st);
 }
 
 static int fused_backward(const ttemb_shape_t* shape, float* const* cores, float* const* opt_state,
                           const int64_t* indices, const int64_t* rowidx, int64_t nnz,
                           const int32_t* nnz_dev, int64_t B, const float* d_output, float lr, float eps,
-                          void* workspace, int64_t workspace_bytes, void* stream) {
+                          void* workspace, int64_t workspace_bytes, const void* plan, int64_t plan_bytes,
+                          void* stream) {
   DevShape ds;
   int rc = make_dev_shape(shape, &ds);
   if (rc) return rc;
@@ -309,7 +321,8 @@ static int fused_backward(const ttemb_shape_t* shape, float* const* cores, float
       off += align256((int64_t)ds.p[t] * ds.row_len[t] * 4);
     }
   }
-  rc = backward_into(ds, cp, indices, rowidx, nnz, nnz_dev, d_output, gp, ws + off, workspace_bytes - off, st);
+  rc = backward_into(ds, cp, indices, rowidx, nnz, nnz_dev, d_output, gp, ws + off, workspace_bytes - off, plan,
+                     plan_bytes, st);
   if (rc) return rc;
   for (int t = 0; t < ds.T; ++t) {
     const int64_t n = (int64_t)ds.p[t] * ds.row_len[t];
@@ -323,18 +336,19 @@ static int fused_backward(const ttemb_shape_t* shape, float* const* cores, float
 int ttemb_backward_sgd(const ttemb_shape_t* shape, float* const* cores, const int64_t* indices,
                        const int64_t* rowidx, int64_t nnz, const int32_t* nnz_dev, int64_t B,
                        const float* d_output, float lr, void* workspace, int64_t workspace_bytes,
-                       void* stream) {
+                       const void* plan, int64_t plan_bytes, void* stream) {
   return fused_backward(shape, cores, nullptr, indices, rowidx, nnz, nnz_dev, B, d_output, lr, 0.f,
-                        workspace, workspace_bytes, stream);
+                        workspace, workspace_bytes, plan, plan_bytes, stream);
 }
 
 int ttemb_backward_adagrad(const ttemb_shape_t* shape, float* const* cores, float* const* opt_state,
                            const int64_t* indices, const int64_t* rowidx, int64_t nnz,
                            const int32_t* nnz_dev, int64_t B, const float* d_output, float lr,
-                           float eps, void* workspace, int64_t workspace_bytes, void* stream) {
+                           float eps, void* workspace, int64_t workspace_bytes, const void* plan,
+                           int64_t plan_bytes, void* stream) {
   if (opt_state == nullptr) return fail(TTEMB_E_BADARG, "opt_state is null");
   return fused_backward(shape, cores, opt_state, indices, rowidx, nnz, nnz_dev, B, d_output, lr, eps,
-                        workspace, workspace_bytes, stream);
+                        workspace, workspace_bytes, plan, plan_bytes, stream);
 }
 
 int ttemb_sgd_step(float* weights, const float* grads, int64_t n, float lr, void* stream) {

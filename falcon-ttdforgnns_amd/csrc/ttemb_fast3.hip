@@ -563,7 +563,7 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(
 // in registers and adds one (r2 q2)-float row per touched i2 to dG2.  E rows are read exactly
 // once, 16 bytes per lane; the only float atomics are the per-tile row flushes.
 constexpr int kRowsB = 2048;
-constexpr int NWB = 8;
+constexpr int NWB = 16;
 template <int ROW2>
 __global__ __launch_bounds__(NWB * 64) void fast3_dg2_reduce_kernel(GroupPlan plan, int G, uint32_t p2,
                                                                      float* __restrict__ dG2) {
@@ -620,19 +620,20 @@ __global__ __launch_bounds__(NWB * 64) void fast3_dg2_reduce_kernel(GroupPlan pl
     if (b0 == b1) continue;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (sub < SUB) {
-      // four independent row loads in flight per lane group (the loop is latency-bound otherwise)
-      for (uint32_t j = b0 + sub; j < b1; j += 4 * SUB) {
-        float4 v[4];
+      // several independent row loads in flight per lane group (the loop is latency-bound otherwise)
+      constexpr int U = 6;
+      for (uint32_t j = b0 + sub; j < b1; j += U * SUB) {
+        float4 v[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
           v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
           const uint32_t jj = j + u * SUB;
           if (jj < b1) v[u] = *reinterpret_cast<const float4*>(plan.etab + (size_t)(s0 + rows[jj]) * ROW2 + 4 * c4);
         }
-        acc.x += (v[0].x + v[1].x) + (v[2].x + v[3].x);
-        acc.y += (v[0].y + v[1].y) + (v[2].y + v[3].y);
-        acc.z += (v[0].z + v[1].z) + (v[2].z + v[3].z);
-        acc.w += (v[0].w + v[1].w) + (v[2].w + v[3].w);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
+        }
       }
     }
 #pragma unroll
@@ -783,9 +784,25 @@ static int64_t num_groups(const DevShape& s) { return (int64_t)s.p[0] * s.p[1]; 
 // that sizing the workspace needs no HIP call (the launch checks the real requirement)
 static int64_t scan_temp_bytes(int64_t G) { return 64 * 1024 + (G + 1) / 8; }
 
-// carve the workspace; `bwd` adds the E rows and the per-group dP table
-static int64_t carve_plan(const DevShape& s, int64_t nnz, bool bwd, char* base, GroupPlan* plan, char** scan_tmp,
-                          int64_t scan_bytes) {
+bool fast3_pays(const DevShape& s, int64_t nnz) { return nnz >= 2 * num_groups(s); }
+
+// The grouping that forward and backward share ("plan"): grouped keys / values and the group
+// sizes / starts.  It lives in a caller buffer when one is given, else in the workspace.
+int64_t fast3_plan_bytes(const DevShape& s, int64_t nnz) {
+  return 2 * align256(nnz * 4) + 2 * align256((num_groups(s) + 1) * 4);
+}
+
+static void carve_plan_part(const DevShape& s, int64_t nnz, char* base, GroupPlan* pl) {
+  const int64_t G = num_groups(s);
+  pl->keys = (uint32_t*)base;
+  pl->vals = (uint32_t*)(base + align256(nnz * 4));
+  pl->counts = (uint32_t*)(base + 2 * align256(nnz * 4));
+  pl->gstart = (uint32_t*)(base + 2 * align256(nnz * 4) + align256((G + 1) * 4));
+}
+
+// workspace layout: [plan part unless external] [grouping scratch] [backward tables]
+static int64_t carve_workspace(const DevShape& s, int64_t nnz, bool bwd, bool plan_inside, bool need_grouping,
+                               char* base, GroupPlan* pl, char** scan_tmp) {
   const int64_t G = num_groups(s);
   int64_t off = 0;
   auto take = [&](int64_t bytes) {
@@ -793,44 +810,47 @@ static int64_t carve_plan(const DevShape& s, int64_t nnz, bool bwd, char* base, 
     off += align256(bytes);
     return p;
   };
-  GroupPlan pl;
-  memset(&pl, 0, sizeof(pl));
-  pl.keys_in = (uint32_t*)take(nnz * 4);
-  pl.vals_in = (uint32_t*)take(nnz * 4);
-  pl.rank_in = (uint32_t*)take(nnz * 4);
-  pl.keys = (uint32_t*)take(nnz * 4);
-  pl.vals = (uint32_t*)take(nnz * 4);
-  pl.counts = (uint32_t*)take((G + 1) * 4);
-  pl.gstart = (uint32_t*)take((G + 1) * 4);
-  char* tmp = take(scan_bytes);
-  if (scan_tmp) *scan_tmp = tmp;
-  if (bwd) {
-    pl.etab = (float*)take(nnz * (int64_t)s.row_len[2] * 4);
-    pl.dptab = (float*)take(G * (int64_t)s.q[0] * s.q[1] * s.R[2] * 4);
+  if (plan_inside) {
+    char* p = take(fast3_plan_bytes(s, nnz));
+    if (pl && p) carve_plan_part(s, nnz, p, pl);
   }
-  if (plan) *plan = pl;
+  if (need_grouping) {
+    uint32_t* a = (uint32_t*)take(nnz * 4);
+    uint32_t* b = (uint32_t*)take(nnz * 4);
+    uint32_t* c = (uint32_t*)take(nnz * 4);
+    char* t = take(scan_temp_bytes(G));
+    if (pl) {
+      pl->keys_in = a;
+      pl->vals_in = b;
+      pl->rank_in = c;
+    }
+    if (scan_tmp) *scan_tmp = t;
+  }
+  if (bwd) {
+    float* e = (float*)take(nnz * (int64_t)s.row_len[2] * 4);
+    float* d = (float*)take(G * (int64_t)s.q[0] * s.q[1] * s.R[2] * 4);
+    if (pl) {
+      pl->etab = e;
+      pl->dptab = d;
+    }
+  }
   return off;
 }
 
 int64_t fast3_workspace_bytes(const DevShape& s, int32_t op, int64_t nnz, int64_t B) {
   (void)B;
-  const int64_t tmp = scan_temp_bytes(num_groups(s));
-  return carve_plan(s, nnz, op == TTEMB_OP_BACKWARD, nullptr, nullptr, nullptr, tmp) + 256;
+  return carve_workspace(s, nnz, op == TTEMB_OP_BACKWARD, true, true, nullptr, nullptr, nullptr) + 256;
 }
 
-static int group_ids(const DevShape& s, bool bwd, const int64_t* indices, const int64_t* rowidx, int64_t nnz,
-                     const int32_t* nnz_dev, void* ws, int64_t ws_bytes, GroupPlan* plan, hipStream_t st) {
-  if (ws == nullptr) return fail(TTEMB_E_WORKSPACE, "fast path needs a workspace");
+// fill plan->{keys, vals, counts, gstart} from the ids
+static int group_ids(const DevShape& s, const int64_t* indices, const int64_t* rowidx, int64_t nnz,
+                     const int32_t* nnz_dev, GroupPlan* plan, char* scan_tmp, hipStream_t st) {
   const int64_t G = num_groups(s);
   size_t tmp_bytes = 0;
   uint32_t* nul = nullptr;
   hipError_t e = rocprim::exclusive_scan(nullptr, tmp_bytes, nul, nul, 0u, (size_t)(G + 1), rocprim::plus<uint32_t>(), st, false);
   if (e != hipSuccess) return check_hip(e, "exclusive_scan(size)");
   if ((int64_t)tmp_bytes > scan_temp_bytes(G)) return fail(TTEMB_E_WORKSPACE, "scan scratch bound too small");
-  char* scan_tmp = nullptr;
-  const int64_t need = carve_plan(s, nnz, bwd, reinterpret_cast<char*>(ws), plan, &scan_tmp, scan_temp_bytes(G));
-  if (need > ws_bytes)
-    return fail(TTEMB_E_WORKSPACE, "fast path needs %lld workspace bytes, got %lld", (long long)need, (long long)ws_bytes);
   const uint32_t sentinel = (uint32_t)((unsigned long long)s.L[0] * s.p[0]);
   int rc = check_hip(hipMemsetAsync(plan->counts, 0, (size_t)(G + 1) * 4, st), "memset counts");
   if (rc) return rc;
@@ -845,6 +865,23 @@ static int group_ids(const DevShape& s, bool bwd, const int64_t* indices, const 
   if (e != hipSuccess) return check_hip(e, "exclusive_scan");
   hipLaunchKernelGGL(fast3_scatter_kernel, dim3(tiles), dim3(kTile), 0, st, nnz, nnz_dev, (uint32_t)s.p[2], *plan);
   return check_hip(hipGetLastError(), "fast3_scatter_kernel");
+}
+
+// resolve where the plan lives, carve the workspace, group the ids unless a ready plan was passed
+static int prepare(const DevShape& s, bool bwd, const int64_t* indices, const int64_t* rowidx, int64_t nnz,
+                   const int32_t* nnz_dev, void* ws, int64_t ws_bytes, void* plan_buf, int64_t plan_bytes,
+                   bool plan_ready, GroupPlan* plan, hipStream_t st) {
+  memset(plan, 0, sizeof(*plan));
+  const bool external = plan_buf != nullptr && plan_bytes >= fast3_plan_bytes(s, nnz);
+  const bool reuse = external && plan_ready;
+  char* scan_tmp = nullptr;
+  const int64_t need = carve_workspace(s, nnz, bwd, !external, !reuse, reinterpret_cast<char*>(ws), plan, &scan_tmp);
+  if (need > 0 && ws == nullptr) return fail(TTEMB_E_WORKSPACE, "fast path needs a workspace");
+  if (need > ws_bytes)
+    return fail(TTEMB_E_WORKSPACE, "fast path needs %lld workspace bytes, got %lld", (long long)need, (long long)ws_bytes);
+  if (external) carve_plan_part(s, nnz, reinterpret_cast<char*>(plan_buf), plan);
+  if (reuse) return TTEMB_OK;
+  return group_ids(s, indices, rowidx, nnz, nnz_dev, plan, scan_tmp, st);
 }
 
 template <int Q0, int Q1, int Q2, int R1, int R2>
@@ -872,10 +909,10 @@ static int run_forward(const DevShape& s, const CorePtrs& cores, const GroupPlan
 
 int launch_forward_fast3(const DevShape& s, const CorePtrs& cores, const int64_t* indices,
                          const int64_t* rowidx, int64_t nnz, const int32_t* nnz_dev, float* output,
-                         void* ws, int64_t ws_bytes, hipStream_t st) {
+                         void* ws, int64_t ws_bytes, void* plan_buf, int64_t plan_bytes, hipStream_t st) {
   if (nnz <= 0) return TTEMB_OK;
   GroupPlan ids;
-  int rc = group_ids(s, false, indices, rowidx, nnz, nnz_dev, ws, ws_bytes, &ids, st);
+  int rc = prepare(s, false, indices, rowidx, nnz, nnz_dev, ws, ws_bytes, plan_buf, plan_bytes, false, &ids, st);
   if (rc) return rc;
   switch (classify(s)) {
     case kProducts: return run_forward<4, 5, 5, 16, 16>(s, cores, ids, nnz, nnz_dev, output, st);
@@ -913,14 +950,15 @@ static int run_backward(const DevShape& s, const CorePtrs& cores, const GroupPla
 int launch_backward_fast3(const DevShape& s, const CorePtrs& cores, const int64_t* indices,
                           const int64_t* rowidx, int64_t nnz, const int32_t* nnz_dev,
                           const float* d_output, const CorePtrsMut& d_cores, void* ws, int64_t ws_bytes,
-                          hipStream_t st) {
+                          const void* plan_buf, int64_t plan_bytes, hipStream_t st) {
   for (int t = 0; t < s.T; ++t) {
     int rc = check_hip(hipMemsetAsync(d_cores.c[t], 0, (size_t)s.p[t] * s.row_len[t] * 4, st), "memset d_core");
     if (rc) return rc;
   }
   if (nnz <= 0) return TTEMB_OK;
   GroupPlan plan;
-  int rc = group_ids(s, true, indices, rowidx, nnz, nnz_dev, ws, ws_bytes, &plan, st);
+  int rc = prepare(s, true, indices, rowidx, nnz, nnz_dev, ws, ws_bytes, const_cast<void*>(plan_buf), plan_bytes,
+                   plan_buf != nullptr, &plan, st);
   if (rc) return rc;
   switch (classify(s)) {
     case kProducts: return run_backward<4, 5, 5, 16, 16>(s, cores, plan, nnz, nnz_dev, d_output, d_cores, st);

@@ -26,7 +26,7 @@ PATH_AUTO, PATH_GENERIC, PATH_FAST3 = 0, 1, 2
 
 # every symbol include/ttemb.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = (
-    "ttemb_abi_version", "ttemb_last_error", "ttemb_workspace_bytes", "ttemb_set_path",
+    "ttemb_abi_version", "ttemb_last_error", "ttemb_workspace_bytes", "ttemb_plan_bytes", "ttemb_set_path",
     "ttemb_profile_enable", "ttemb_profile_read",
     "ttemb_forward", "ttemb_backward_dense", "ttemb_backward_sgd", "ttemb_backward_adagrad",
     "ttemb_sgd_step", "ttemb_adagrad_step", "ttemb_cache_update", "ttemb_cache_populate",
@@ -73,10 +73,12 @@ def _load() -> ctypes.CDLL:
     lib.ttemb_set_path.argtypes = [i32]
     lib.ttemb_profile_enable.argtypes = [i32]
     lib.ttemb_profile_read.argtypes = [i32, ctypes.POINTER(ctypes.c_float)]
-    lib.ttemb_forward.argtypes = [shp, vp, vp, vp, vp, i64, vp, i64, vp, vp, i64, vp]
-    lib.ttemb_backward_dense.argtypes = [shp, vp, vp, vp, i64, vp, i64, vp, vp, vp, i64, vp]
-    lib.ttemb_backward_sgd.argtypes = [shp, vp, vp, vp, i64, vp, i64, vp, f32, vp, i64, vp]
-    lib.ttemb_backward_adagrad.argtypes = [shp, vp, vp, vp, vp, i64, vp, i64, vp, f32, f32, vp, i64, vp]
+    lib.ttemb_plan_bytes.restype = i64
+    lib.ttemb_plan_bytes.argtypes = [shp, i64]
+    lib.ttemb_forward.argtypes = [shp, vp, vp, vp, vp, i64, vp, i64, vp, vp, i64, vp, i64, vp]
+    lib.ttemb_backward_dense.argtypes = [shp, vp, vp, vp, i64, vp, i64, vp, vp, vp, i64, vp, i64, vp]
+    lib.ttemb_backward_sgd.argtypes = [shp, vp, vp, vp, i64, vp, i64, vp, f32, vp, i64, vp, i64, vp]
+    lib.ttemb_backward_adagrad.argtypes = [shp, vp, vp, vp, vp, i64, vp, i64, vp, f32, f32, vp, i64, vp, i64, vp]
     lib.ttemb_sgd_step.argtypes = [vp, vp, i64, f32, vp]
     lib.ttemb_adagrad_step.argtypes = [vp, vp, vp, i64, f32, f32, vp]
     lib.ttemb_cache_update.argtypes = [vp, i64, vp, vp, i64, vp]
@@ -88,7 +90,7 @@ def _load() -> ctypes.CDLL:
     lib.ttemb_cache_backward_rowwise_adagrad.argtypes = [vp, vp, i64, vp, i64, vp, i64, f32, f32, vp, vp, vp]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
-        if name not in ("ttemb_last_error", "ttemb_workspace_bytes"):
+        if name not in ("ttemb_last_error", "ttemb_workspace_bytes", "ttemb_plan_bytes"):
             fn.restype = ctypes.c_int
     if lib.ttemb_abi_version() != 1:
         raise ImportError("libttemb_hip.so ABI version mismatch")
@@ -161,45 +163,63 @@ def workspace_bytes(shape: Optional[Shape], op: int, nnz: int, B: int) -> int:
     return int(n)
 
 
+def plan_bytes(shape: Shape, nnz: int) -> int:
+    n = LIB.ttemb_plan_bytes(ctypes.byref(shape), nnz)
+    if n < 0:
+        _check(int(n))
+    return int(n)
+
+
+def new_plan(shape: Shape, nnz: int, device: torch.device) -> Optional[torch.Tensor]:
+    """Buffer in which forward leaves its id grouping for the matching backward (None if unused)."""
+    n = plan_bytes(shape, nnz)
+    return torch.empty(n, dtype=torch.uint8, device=device) if n > 0 else None
+
+
+def _plan_args(plan: Optional[torch.Tensor]):
+    return (None, 0) if plan is None else (plan.data_ptr(), plan.numel())
+
+
 def forward(shape: Shape, cores: Sequence[torch.Tensor], indices: torch.Tensor, rowidx: torch.Tensor,
             offsets: Optional[torch.Tensor], nnz: int, nnz_dev: Optional[torch.Tensor], B: int,
-            output: torch.Tensor, ws: Workspace) -> None:
+            output: torch.Tensor, ws: Workspace, plan: Optional[torch.Tensor] = None) -> None:
     dev = output.device
     w = ws.get(workspace_bytes(shape, OP_FORWARD, nnz, B), dev)
     with torch.cuda.device(dev):
         _check(LIB.ttemb_forward(ctypes.byref(shape), _ptr_array(cores), _ptr(indices), _ptr(rowidx),
                                  _ptr(offsets), nnz, _ptr(nnz_dev), B, _ptr(output), _ptr(w), w.numel(),
-                                 _stream(output)))
+                                 *_plan_args(plan), _stream(output)))
 
 
 def backward_dense(shape: Shape, cores: Sequence[torch.Tensor], indices, rowidx, nnz: int, nnz_dev, B: int,
-                   d_output: torch.Tensor, d_cores: Sequence[torch.Tensor], ws: Workspace) -> None:
+                   d_output: torch.Tensor, d_cores: Sequence[torch.Tensor], ws: Workspace,
+                   plan: Optional[torch.Tensor] = None) -> None:
     dev = d_output.device
     w = ws.get(workspace_bytes(shape, OP_BACKWARD, nnz, B), dev)
     with torch.cuda.device(dev):
         _check(LIB.ttemb_backward_dense(ctypes.byref(shape), _ptr_array(cores), _ptr(indices), _ptr(rowidx),
                                         nnz, _ptr(nnz_dev), B, _ptr(d_output), _ptr_array(d_cores), _ptr(w),
-                                        w.numel(), _stream(d_output)))
+                                        w.numel(), *_plan_args(plan), _stream(d_output)))
 
 
 def backward_sgd(shape: Shape, cores, indices, rowidx, nnz: int, nnz_dev, B: int, d_output, lr: float,
-                 ws: Workspace) -> None:
+                 ws: Workspace, plan: Optional[torch.Tensor] = None) -> None:
     dev = d_output.device
     w = ws.get(workspace_bytes(shape, OP_BACKWARD, nnz, B), dev)
     with torch.cuda.device(dev):
         _check(LIB.ttemb_backward_sgd(ctypes.byref(shape), _ptr_array(cores), _ptr(indices), _ptr(rowidx), nnz,
                                       _ptr(nnz_dev), B, _ptr(d_output), lr, _ptr(w), w.numel(),
-                                      _stream(d_output)))
+                                      *_plan_args(plan), _stream(d_output)))
 
 
 def backward_adagrad(shape: Shape, cores, opt_state, indices, rowidx, nnz: int, nnz_dev, B: int, d_output,
-                     lr: float, eps: float, ws: Workspace) -> None:
+                     lr: float, eps: float, ws: Workspace, plan: Optional[torch.Tensor] = None) -> None:
     dev = d_output.device
     w = ws.get(workspace_bytes(shape, OP_BACKWARD, nnz, B), dev)
     with torch.cuda.device(dev):
         _check(LIB.ttemb_backward_adagrad(ctypes.byref(shape), _ptr_array(cores), _ptr_array(opt_state),
                                           _ptr(indices), _ptr(rowidx), nnz, _ptr(nnz_dev), B, _ptr(d_output),
-                                          lr, eps, _ptr(w), w.numel(), _stream(d_output)))
+                                          lr, eps, _ptr(w), w.numel(), *_plan_args(plan), _stream(d_output)))
 
 
 def sgd_step(weights: torch.Tensor, grads: torch.Tensor, lr: float) -> None:

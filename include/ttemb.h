@@ -56,7 +56,8 @@ enum {
 
 /* Kernel-selection knob for forward/backward (tests drive both; 0 is the default). */
 enum {
-  TTEMB_PATH_AUTO = 0,          /* fastest path the shape supports                 */
+  TTEMB_PATH_AUTO = 0,          /* fast path when the shape supports it and the batch has
+                                   at least ~2 ids per (i0,i1) group, else generic      */
   TTEMB_PATH_GENERIC = 1,       /* shape-generic wave-per-id kernels (T = 2..4)    */
   TTEMB_PATH_FAST3 = 2          /* sorted / grouped MFMA path, T == 3 only         */
 };
@@ -66,6 +67,11 @@ const char* ttemb_last_error(void);   /* thread-local, valid until the next call
 
 /* Bytes of scratch the op needs for `nnz` ids and `B` bags (0 is a valid answer). */
 int64_t ttemb_workspace_bytes(const ttemb_shape_t* shape, int32_t op, int64_t nnz, int64_t B);
+
+/* Bytes of an id-grouping plan for `nnz` ids (0 when the selected kernel family needs none).
+ * ttemb_forward leaves its grouping of the ids in a caller buffer of this size; passing the same
+ * buffer to the backward of the SAME (indices, rowidx, nnz, nnz_dev) skips the regrouping. */
+int64_t ttemb_plan_bytes(const ttemb_shape_t* shape, int64_t nnz);
 
 /* Select the kernel family used by later calls, process-wide (TTEMB_PATH_*). */
 int ttemb_set_path(int32_t path);
@@ -88,12 +94,14 @@ int ttemb_profile_read(int32_t which, float* ms_host);
  * `offsets` (int64[B+1]) may be passed when indices[0:nnz] are exactly the concatenated
  * bags (no cache partition): then only bags whose length is not 1 are zero-filled before
  * the lookups; with offsets == NULL the whole output is zero-filled first.
+ * `plan` (nullable, ttemb_plan_bytes() bytes) receives the id grouping for the backward.
  * There is no batch_count chunking: intermediates never leave the chip.
  * ------------------------------------------------------------------------------- */
 int ttemb_forward(const ttemb_shape_t* shape, const float* const* cores,
                   const int64_t* indices, const int64_t* rowidx, const int64_t* offsets,
                   int64_t nnz, const int32_t* nnz_dev, int64_t B, float* output,
-                  void* workspace, int64_t workspace_bytes, void* stream);
+                  void* workspace, int64_t workspace_bytes, void* plan, int64_t plan_bytes,
+                  void* stream);
 
 /* ---------------------------------------------------------------------------------
  * tt_dense_backward  (tt_embeddings.tt_dense_backward -- tt_embeddings.cpp:133-136,
@@ -104,7 +112,8 @@ int ttemb_backward_dense(const ttemb_shape_t* shape, const float* const* cores,
                          const int64_t* indices, const int64_t* rowidx, int64_t nnz,
                          const int32_t* nnz_dev, int64_t B, const float* d_output,
                          float* const* d_cores,
-                         void* workspace, int64_t workspace_bytes, void* stream);
+                         void* workspace, int64_t workspace_bytes, const void* plan, int64_t plan_bytes,
+                         void* stream);
 
 /* tt_sgd_backward (tt_embeddings.cpp:137-138, tt_embeddings_cuda.cu:688-719):
  * cores[t] -= lr * d_core_t, every row (the reference's grid defect at :633-651 is
@@ -112,7 +121,8 @@ int ttemb_backward_dense(const ttemb_shape_t* shape, const float* const* cores,
 int ttemb_backward_sgd(const ttemb_shape_t* shape, float* const* cores,
                        const int64_t* indices, const int64_t* rowidx, int64_t nnz,
                        const int32_t* nnz_dev, int64_t B, const float* d_output, float lr,
-                       void* workspace, int64_t workspace_bytes, void* stream);
+                       void* workspace, int64_t workspace_bytes, const void* plan, int64_t plan_bytes,
+                       void* stream);
 
 /* tt_adagrad_backward (tt_embeddings.cpp:139-142, tt_embeddings_cuda.cu:721-754,
  * 399-419): state += g*g ; core -= lr * g / (sqrt(state) + eps). */
@@ -121,7 +131,8 @@ int ttemb_backward_adagrad(const ttemb_shape_t* shape, float* const* cores,
                            const int64_t* indices, const int64_t* rowidx, int64_t nnz,
                            const int32_t* nnz_dev, int64_t B, const float* d_output,
                            float lr, float eps,
-                           void* workspace, int64_t workspace_bytes, void* stream);
+                           void* workspace, int64_t workspace_bytes, const void* plan, int64_t plan_bytes,
+                           void* stream);
 
 /* Flat optimiser epilogues over n floats (used after the data-parallel all-reduce of
  * the flattened core gradients; same arithmetic as tt_embeddings_cuda.cu:381-419). */
