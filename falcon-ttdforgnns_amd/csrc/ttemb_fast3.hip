@@ -91,6 +91,8 @@ struct GroupPlan {           // device pointers into the caller's workspace
   uint32_t* gstart;          // [G+1] first grouped position of each group; [G] = live ids
   float* etab;               // [nnz][ROW2] dG2 contribution rows, in grouped order
   float* dptab;              // [G][M2*R2] dP of every non-empty group
+  float* g2part;             // [tiles][p2][ROW2] per-tile partial dG2
+  float* g0part;             // [G][ROW0] per-group contribution to dG0
 };
 
 __global__ __launch_bounds__(kTile) void fast3_prep_kernel(
@@ -560,13 +562,11 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(
 
 // B. dG2 reduce.  A workgroup takes kRowsB consecutive E rows, buckets them by i2 inside LDS
 // (a tile-local counting sort of row numbers), then each wave sums the rows of "its" i2 values
-// in registers and adds one (r2 q2)-float row per touched i2 to dG2.  E rows are read exactly
-// once, 16 bytes per lane; the only float atomics are the per-tile row flushes.
-constexpr int kRowsB = 2048;
-constexpr int NWB = 16;
-template <int ROW2>
-__global__ __launch_bounds__(NWB * 64) void fast3_dg2_reduce_kernel(GroupPlan plan, int G, uint32_t p2,
-                                                                     float* __restrict__ dG2) {
+// in registers and stores one (r2 q2)-float row per i2 into the tile's slab of partial sums
+// (plain stores: atomics from every tile onto the 45 KB of dG2 ran at ~0.1 TB/s).  E rows are
+// read exactly once, 16 bytes per lane.  fast3_finalize_kernel adds the slabs up.
+template <int ROW2, int kRowsB, int NWB>
+__global__ __launch_bounds__(NWB * 64) void fast3_dg2_reduce_kernel(GroupPlan plan, int G, uint32_t p2) {
   extern __shared__ uint32_t lds_u[];   // [p2 + 1] bucket starts | [p2] cursors | [kRowsB] row list (uint16)
   uint32_t* bstart = lds_u;
   uint32_t* cursor = lds_u + p2 + 1;
@@ -576,8 +576,8 @@ __global__ __launch_bounds__(NWB * 64) void fast3_dg2_reduce_kernel(GroupPlan pl
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const uint32_t total = plan.gstart[G];
   const uint32_t s0 = blockIdx.x * kRowsB;
-  if (s0 >= total) return;
-  const uint32_t n_rows = s0 + kRowsB < total ? kRowsB : total - s0;
+  const uint32_t n_rows = s0 >= total ? 0u : (s0 + kRowsB < total ? kRowsB : total - s0);
+  float* slab = plan.g2part + (size_t)blockIdx.x * p2 * ROW2;  // this tile's partial dG2, every row written
   for (uint32_t e = tid; e <= p2; e += NWB * 64) bstart[e] = 0;
   __syncthreads();
   // histogram of i2 over the tile (integer LDS atomics; 8 ids per thread)
@@ -617,18 +617,20 @@ __global__ __launch_bounds__(NWB * 64) void fast3_dg2_reduce_kernel(GroupPlan pl
   const int sub = lane / F4, c4 = lane - sub * F4;
   for (uint32_t i2 = wave; i2 < p2; i2 += NWB) {
     const uint32_t b0 = bstart[i2], b1 = bstart[i2 + 1];
-    if (b0 == b1) continue;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (sub < SUB) {
       // several independent row loads in flight per lane group (the loop is latency-bound otherwise)
       constexpr int U = 6;
       for (uint32_t j = b0 + sub; j < b1; j += U * SUB) {
+        uint32_t rr[U];
         float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) rr[u] = j + u * SUB < b1 ? rows[j + u * SUB] : 0xffffffffu;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-          const uint32_t jj = j + u * SUB;
-          if (jj < b1) v[u] = *reinterpret_cast<const float4*>(plan.etab + (size_t)(s0 + rows[jj]) * ROW2 + 4 * c4);
+          if (rr[u] != 0xffffffffu)
+            v[u] = *reinterpret_cast<const float4*>(plan.etab + (size_t)(s0 + rr[u]) * ROW2 + 4 * c4);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -643,13 +645,7 @@ __global__ __launch_bounds__(NWB * 64) void fast3_dg2_reduce_kernel(GroupPlan pl
       const float z = __shfl(acc.z, src, kWave), w = __shfl(acc.w, src, kWave);
       if (lane < F4) { acc.x += x; acc.y += y; acc.z += z; acc.w += w; }
     }
-    if (lane < F4) {
-      float* dst = dG2 + (size_t)i2 * ROW2 + 4 * lane;
-      atomicAdd(dst + 0, acc.x);
-      atomicAdd(dst + 1, acc.y);
-      atomicAdd(dst + 2, acc.z);
-      atomicAdd(dst + 3, acc.w);
-    }
+    if (lane < F4) *reinterpret_cast<float4*>(slab + (size_t)i2 * ROW2 + 4 * lane) = acc;
   }
 }
 
@@ -658,7 +654,7 @@ constexpr int kGroupsC = 8;
 template <int Q0, int Q1, int Q2, int R1, int R2>
 __global__ __launch_bounds__(64) void fast3_group_epilogue_kernel(
     const float* __restrict__ G0, const float* __restrict__ G1, uint32_t p0, uint32_t G, GroupPlan plan,
-    float* __restrict__ dG0, float* __restrict__ dG1) {
+    float* __restrict__ dG1) {
   using C = Cfg<Q0, Q1, Q2, R1, R2>;
   __shared__ __attribute__((aligned(16))) float dpbuf[C::P_FLOATS];
   __shared__ __attribute__((aligned(16))) float g1buf[R1 * C::LDG];
@@ -688,18 +684,48 @@ __global__ __launch_bounds__(64) void fast3_group_epilogue_kernel(
       }
   };
 
-  for (uint32_t g = g_begin; g < g_end; ++g) {
-    if (plan.counts[g] == 0) continue;  // wave-uniform
-    const uint32_t i1 = g / p0, i0 = g - i1 * p0;
-    // dP of the group -> LDS matrix [m2][c2]
-    {
-      const float* src = plan.dptab + (size_t)g * (C::M2 * R2);
+  // which of this wave's groups are non-empty (one lane per group), then walk them with the next
+  // group's dP and G0 operand already requested while the current one is being multiplied
+  const uint32_t cnt_l = (lane < kGroupsC && g_begin + lane < g_end) ? plan.counts[g_begin + lane] : 0u;
+  unsigned long long live = __ballot(cnt_l != 0);
+  if (!live) return;
+  constexpr int PER = (C::M2 * R2 + kWave - 1) / kWave;
+  constexpr int KS0 = (Q0 + 3) / 4;
+  float nxt[PER], nxt_g0[KS0][C::RT1];
+  auto request = [&](uint32_t g) {
+    const float* src = plan.dptab + (size_t)g * (C::M2 * R2);
 #pragma unroll
-      for (int i = 0; i < (C::M2 * R2 + kWave - 1) / kWave; ++i) {
-        const int e = i * kWave + lane;
-        if (e < C::M2 * R2) dpbuf[(e / R2) * C::LDA + e % R2] = src[e];
-      }
+    for (int i = 0; i < PER; ++i) {
+      const int e = i * kWave + lane;
+      nxt[i] = e < C::M2 * R2 ? src[e] : 0.f;
     }
+    const uint32_t i1n = g / p0;
+    const float* g0 = G0 + (size_t)(g - i1n * p0) * C::ROW0;
+#pragma unroll
+    for (int s = 0; s < KS0; ++s)
+#pragma unroll
+      for (int t = 0; t < C::RT1; ++t) {
+        const int a = 4 * s + hi;
+        nxt_g0[s][t] = (a < Q0 && 16 * t + lo < R1) ? g0[a * R1 + 16 * t + lo] : 0.f;
+      }
+  };
+  request(g_begin + __builtin_ctzll(live));
+  while (live) {
+    const uint32_t g = g_begin + __builtin_ctzll(live);
+    live &= live - 1;
+    const uint32_t i1 = g / p0;
+    // dP of the group -> LDS matrix [m2][c2]
+    float g0v[KS0][C::RT1];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int e = i * kWave + lane;
+      if (e < C::M2 * R2) dpbuf[(e / R2) * C::LDA + e % R2] = nxt[i];
+    }
+#pragma unroll
+    for (int s = 0; s < KS0; ++s)
+#pragma unroll
+      for (int t = 0; t < C::RT1; ++t) g0v[s][t] = nxt_g0[s][t];
+    if (live) request(g_begin + __builtin_ctzll(live));
     if (i1 != cur_i1) {
       if (cur_i1 != 0xffffffffu) flush_g1();
       cur_i1 = i1;
@@ -712,20 +738,16 @@ __global__ __launch_bounds__(64) void fast3_group_epilogue_kernel(
     }
     __syncthreads();
     // dG1[i1] += G0[i0]^T (r1 x q0) . dP (q0 x q1 r2)
-    const float* g0 = G0 + (size_t)i0 * C::ROW0;
 #pragma unroll
-    for (int s = 0; s < (Q0 + 3) / 4; ++s) {
+    for (int s = 0; s < KS0; ++s) {
       const int a = 4 * s + hi;
-      float av[C::RT1];
-#pragma unroll
-      for (int t = 0; t < C::RT1; ++t) av[t] = (a < Q0 && 16 * t + lo < R1) ? g0[a * R1 + 16 * t + lo] : 0.f;
 #pragma unroll
       for (int nt = 0; nt < C::NT1; ++nt) {
         const int n = 16 * nt + lo;
         const float bv = a < Q0 ? dpbuf[(a * Q1 + n / R2) * C::LDA + n % R2] : 0.f;
 #pragma unroll
         for (int t = 0; t < C::RT1; ++t)
-          g1acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv, g1acc[t][nt], 0, 0, 0);
+          g1acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(g0v[s][t], bv, g1acc[t][nt], 0, 0, 0);
       }
     }
     // dG0[i0] += dP (q0 x q1 r2) . G1[i1]^T (q1 r2 x r1); four interleaved accumulation chains
@@ -744,19 +766,52 @@ __global__ __launch_bounds__(64) void fast3_group_epilogue_kernel(
         g0part[s & 3][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, g0part[s & 3][t], 0, 0, 0);
       }
     }
-    float* dst0 = dG0 + (size_t)i0 * C::ROW0;
+    float* dst0 = plan.g0part + (size_t)g * C::ROW0;  // summed over i1 by fast3_finalize_kernel
 #pragma unroll
     for (int t = 0; t < C::RT1; ++t) {
       const f32x4 sum = (g0part[0][t] + g0part[1][t]) + (g0part[2][t] + g0part[3][t]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int a = 4 * hi + r;
-        if (a < Q0 && 16 * t + lo < R1) atomicAdd(dst0 + a * R1 + 16 * t + lo, sum[r]);
+        if (a < Q0 && 16 * t + lo < R1) dst0[a * R1 + 16 * t + lo] = sum[r];
       }
     }
     __syncthreads();
   }
   if (cur_i1 != 0xffffffffu) flush_g1();
+}
+
+// D. finalize: dG2 = sum of the per-tile slabs; dG0[i0] = sum over i1 of the per-group
+// contributions of the non-empty groups.  A workgroup owns 32 consecutive outputs; its 8 lane
+// rows split the terms, so every load instruction reads 128 contiguous bytes per row and many
+// are in flight; the 8 partial sums meet in LDS.  Every output is written exactly once.
+__global__ __launch_bounds__(256) void fast3_finalize_kernel(GroupPlan plan, int tiles, int p0, int p1,
+                                                             int g2_floats, int row0,
+                                                             float* __restrict__ dG0, float* __restrict__ dG2) {
+  __shared__ float part[8][33];
+  const int x = threadIdx.x & 31, y = threadIdx.x >> 5;
+  const int e = blockIdx.x * 32 + x;
+  const int n0 = p0 * row0;
+  float s = 0.f;
+  if (e < g2_floats) {
+    for (int t = y; t < tiles; t += 8) s += plan.g2part[(size_t)t * g2_floats + e];
+  } else if (e < g2_floats + n0) {
+    const int o = e - g2_floats;
+    const int i0 = o / row0, c = o - i0 * row0;
+    for (int i1 = y; i1 < p1; i1 += 8) {
+      const int g = i1 * p0 + i0;
+      if (plan.counts[g]) s += plan.g0part[(size_t)g * row0 + c];
+    }
+  }
+  part[y][x] = s;
+  __syncthreads();
+  if (y == 0) {
+    float tot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tot += part[k][x];
+    if (e < g2_floats) dG2[e] = tot;
+    else if (e < g2_floats + n0) dG0[e - g2_floats] = tot;
+  }
 }
 
 // ---------------------------------------------------------------------------------
@@ -785,6 +840,10 @@ static int64_t num_groups(const DevShape& s) { return (int64_t)s.p[0] * s.p[1]; 
 static int64_t scan_temp_bytes(int64_t G) { return 64 * 1024 + (G + 1) / 8; }
 
 bool fast3_pays(const DevShape& s, int64_t nnz) { return nnz >= 2 * num_groups(s); }
+
+constexpr int kRowsB = 2048;  // E rows per workgroup of the dG2 reduce
+constexpr int NWB = 16;
+static int64_t reduce_tiles(int64_t nnz) { return (nnz + kRowsB - 1) / kRowsB; }
 
 // The grouping that forward and backward share ("plan"): grouped keys / values and the group
 // sizes / starts.  It lives in a caller buffer when one is given, else in the workspace.
@@ -829,9 +888,13 @@ static int64_t carve_workspace(const DevShape& s, int64_t nnz, bool bwd, bool pl
   if (bwd) {
     float* e = (float*)take(nnz * (int64_t)s.row_len[2] * 4);
     float* d = (float*)take(G * (int64_t)s.q[0] * s.q[1] * s.R[2] * 4);
+    float* g2 = (float*)take(reduce_tiles(nnz) * (int64_t)s.p[2] * s.row_len[2] * 4);
+    float* g0 = (float*)take(G * (int64_t)s.row_len[0] * 4);
     if (pl) {
       pl->etab = e;
       pl->dptab = d;
+      pl->g2part = g2;
+      pl->g0part = g0;
     }
   }
   return off;
@@ -934,24 +997,33 @@ static int run_backward(const DevShape& s, const CorePtrs& cores, const GroupPla
                      cores.c[1], cores.c[2], nnz, nnz_dev, (uint32_t)s.p[0], (uint32_t)s.p[2], d_output, plan);
   int rc = check_hip(hipGetLastError(), "fast3_bwd_chunk_kernel");
   if (rc) return rc;
-  hipLaunchKernelGGL((fast3_dg2_reduce_kernel<C::ROW2>), dim3((unsigned)((nnz + kRowsB - 1) / kRowsB)),
-                     dim3(NWB * 64), (size_t)(2 * s.p[2] + 1) * 4 + kRowsB * 2, st, plan, (int)num_groups(s),
-                     (uint32_t)s.p[2], d_cores.c[2]);
+  const int tiles = (int)reduce_tiles(nnz);
+  hipLaunchKernelGGL((fast3_dg2_reduce_kernel<C::ROW2, kRowsB, NWB>), dim3((unsigned)tiles), dim3(NWB * 64),
+                     (size_t)(2 * s.p[2] + 1) * 4 + kRowsB * 2, st, plan, (int)num_groups(s), (uint32_t)s.p[2]);
   rc = check_hip(hipGetLastError(), "fast3_dg2_reduce_kernel");
   if (rc) return rc;
   const int64_t G = num_groups(s);
   hipLaunchKernelGGL((fast3_group_epilogue_kernel<Q0, Q1, Q2, R1, R2>), dim3((unsigned)((G + kGroupsC - 1) / kGroupsC)),
-                     dim3(64), 0, st, cores.c[0], cores.c[1], (uint32_t)s.p[0], (uint32_t)G, plan, d_cores.c[0],
-                     d_cores.c[1]);
+                     dim3(64), 0, st, cores.c[0], cores.c[1], (uint32_t)s.p[0], (uint32_t)G, plan, d_cores.c[1]);
+  rc = check_hip(hipGetLastError(), "fast3_group_epilogue_kernel");
+  if (rc) return rc;
+  {
+    const int g2_floats = s.p[2] * C::ROW2;
+    const int outs = g2_floats + s.p[0] * C::ROW0;
+    hipLaunchKernelGGL(fast3_finalize_kernel, dim3((unsigned)((outs + 31) / 32)), dim3(256), 0, st, plan, tiles,
+                       s.p[0], s.p[1], g2_floats, (int)C::ROW0, d_cores.c[0], d_cores.c[2]);
+  }
   profile_end(1, st);
-  return check_hip(hipGetLastError(), "fast3_group_epilogue_kernel");
+  return check_hip(hipGetLastError(), "fast3_finalize_kernel");
 }
 
 int launch_backward_fast3(const DevShape& s, const CorePtrs& cores, const int64_t* indices,
                           const int64_t* rowidx, int64_t nnz, const int32_t* nnz_dev,
                           const float* d_output, const CorePtrsMut& d_cores, void* ws, int64_t ws_bytes,
                           const void* plan_buf, int64_t plan_bytes, hipStream_t st) {
+  // dG1 is accumulated with float atomics; dG0 and dG2 are written whole by the finalize kernel
   for (int t = 0; t < s.T; ++t) {
+    if (nnz > 0 && t != 1) continue;
     int rc = check_hip(hipMemsetAsync(d_cores.c[t], 0, (size_t)s.p[t] * s.row_len[t] * 4, st), "memset d_core");
     if (rc) return rc;
   }
