@@ -106,25 +106,34 @@ def main():
 
     result = None
     if rank == 0:
-        # roofline leg: the chain kernels bracketed by HIP events on their own stream
+        # roofline leg: kernels bracketed by HIP events on the stream they are launched on.
+        # slot 0 = forward chain kernel (all 13 440 nominal flops of a lookup), slot 2 = backward chunk
+        # kernel (P recompute + dP + dG2 rows: F0 + 2 F1 = 16 640 nominal flops), slot 1 = all backward
+        # chain kernels (37 120 nominal flops; dG1/dG0 run once per (i0,i1) group in the epilogue kernel)
         nat.profile_enable(True)
-        fwd_ms, bwd_ms = [], []
+        fwd_ms, bwd_ms, chunk_ms = [], [], []
         for i in range(10):
             step(i)
             fwd_ms.append(nat.profile_read(0))
             bwd_ms.append(nat.profile_read(1))
+            chunk_ms.append(nat.profile_read(2))
         nat.profile_enable(False)
-        fwd, bwd = float(np.mean(fwd_ms)), float(np.mean(bwd_ms))
-        dom_name, dom_ms, dom_flops = ("tt_backward_chain", bwd, BWD_FLOPS) if bwd >= fwd else \
-                                      ("tt_forward_chain", fwd, FWD_FLOPS)
+        fwd, bwd, chunk = float(np.mean(fwd_ms)), float(np.mean(bwd_ms)), float(np.mean(chunk_ms))
+        chunk_flops = F0 + 2 * F1
+        dom_name, dom_ms, dom_flops = ("fast3_bwd_chunk_kernel", chunk, chunk_flops) if chunk >= fwd else \
+                                      ("fast3_forward_kernel", fwd, FWD_FLOPS)
         achieved = N * dom_flops / (dom_ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 3),
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                     "kernel_ms": round(dom_ms, 4), "flops_per_lookup": dom_flops,
-                    "fwd_kernel_ms": round(fwd, 4), "bwd_kernel_ms": round(bwd, 4),
+                    "fwd_kernel_ms": round(fwd, 4), "bwd_chunk_kernel_ms": round(chunk, 4),
+                    "bwd_chain_ms": round(bwd, 4),
                     "fwd_achieved_tflops": round(N * FWD_FLOPS / (fwd * 1e-3) / 1e12, 3),
-                    "fwd_output_gbs": round(N * (8 + 4 * D) / (fwd * 1e-3) / 1e9, 1),
+                    "fwd_frac": round(N * FWD_FLOPS / (fwd * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                    "bwd_chain_achieved_tflops": round(N * BWD_FLOPS / (bwd * 1e-3) / 1e12, 3),
+                    "bwd_chain_frac": round(N * BWD_FLOPS / (bwd * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                    "fwd_row_store_gbs": round(N * (8 + 4 * D) / (fwd * 1e-3) / 1e9, 1),
                     "peak_hbm_gbs": PEAK_HBM_GBS}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:

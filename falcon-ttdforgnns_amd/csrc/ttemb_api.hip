@@ -31,8 +31,8 @@ int check_hip(hipError_t e, const char* what) {
 int current_path() { return g_path.load(); }
 
 static std::atomic<bool> g_prof_on{false};
-static hipEvent_t g_prof_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
-static std::atomic<bool> g_prof_valid[2] = {{false}, {false}};
+static hipEvent_t g_prof_ev[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+static std::atomic<bool> g_prof_valid[3] = {{false}, {false}, {false}};
 
 void profile_begin(int which, hipStream_t st) {
   if (!g_prof_on) return;
@@ -134,6 +134,48 @@ __global__ void adagrad_step_kernel(float* __restrict__ w, float* __restrict__ s
   w[i] -= lr * gv / (sqrtf(s2) + eps);
 }
 
+struct Seg3 {
+  float* w[TTEMB_MAX_CORES];
+  float* st[TTEMB_MAX_CORES];
+  const float* g[TTEMB_MAX_CORES];
+  long long n[TTEMB_MAX_CORES];
+};
+
+// one launch for every core: blockIdx.y selects the core
+__global__ void fused_step_kernel(Seg3 seg, float lr, float eps, int adagrad) {
+  const int t = blockIdx.y;
+  float* __restrict__ w = seg.w[t];
+  const float* __restrict__ g = seg.g[t];
+  const long long n = seg.n[t];
+  for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n;
+       i += (long long)gridDim.x * blockDim.x * 4) {
+    if (i + 3 < n) {
+      float4 wv = *reinterpret_cast<float4*>(w + i);
+      const float4 gv = *reinterpret_cast<const float4*>(g + i);
+      if (adagrad) {
+        float4 sv = *reinterpret_cast<float4*>(seg.st[t] + i);
+        sv.x += gv.x * gv.x; sv.y += gv.y * gv.y; sv.z += gv.z * gv.z; sv.w += gv.w * gv.w;
+        *reinterpret_cast<float4*>(seg.st[t] + i) = sv;
+        wv.x -= lr * gv.x / (sqrtf(sv.x) + eps); wv.y -= lr * gv.y / (sqrtf(sv.y) + eps);
+        wv.z -= lr * gv.z / (sqrtf(sv.z) + eps); wv.w -= lr * gv.w / (sqrtf(sv.w) + eps);
+      } else {
+        wv.x -= lr * gv.x; wv.y -= lr * gv.y; wv.z -= lr * gv.z; wv.w -= lr * gv.w;
+      }
+      *reinterpret_cast<float4*>(w + i) = wv;
+    } else {
+      for (long long j = i; j < n; ++j) {
+        if (adagrad) {
+          const float s2 = seg.st[t][j] + g[j] * g[j];
+          seg.st[t][j] = s2;
+          w[j] -= lr * g[j] / (sqrtf(s2) + eps);
+        } else {
+          w[j] -= lr * g[j];
+        }
+      }
+    }
+  }
+}
+
 static int run_sgd(float* w, const float* g, int64_t n, float lr, hipStream_t st) {
   if (n <= 0) return TTEMB_OK;
   if ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(g)) & 15)
@@ -198,7 +240,7 @@ int ttemb_profile_enable(int32_t on) {
 }
 
 int ttemb_profile_read(int32_t which, float* ms_host) {
-  if (which < 0 || which > 1 || ms_host == nullptr) return fail(TTEMB_E_BADARG, "bad profile slot");
+  if (which < 0 || which > 2 || ms_host == nullptr) return fail(TTEMB_E_BADARG, "bad profile slot");
   if (!g_prof_valid[which]) return fail(TTEMB_E_BADARG, "no profiled launch recorded for slot %d", which);
   int rc = check_hip(hipEventSynchronize(g_prof_ev[which][1]), "hipEventSynchronize");
   if (rc) return rc;
@@ -324,13 +366,24 @@ static int fused_backward(const ttemb_shape_t* shape, float* const* cores, float
   rc = backward_into(ds, cp, indices, rowidx, nnz, nnz_dev, d_output, gp, ws + off, workspace_bytes - off, plan,
                      plan_bytes, st);
   if (rc) return rc;
+  Seg3 seg;
+  memset(&seg, 0, sizeof(seg));
+  int64_t nmax = 0;
+  bool aligned = true;
   for (int t = 0; t < ds.T; ++t) {
-    const int64_t n = (int64_t)ds.p[t] * ds.row_len[t];
-    rc = opt_state ? run_adagrad(cores[t], opt_state[t], gp.c[t], n, lr, eps, st)
-                   : run_sgd(cores[t], gp.c[t], n, lr, st);
-    if (rc) return rc;
+    seg.w[t] = cores[t];
+    seg.st[t] = opt_state ? opt_state[t] : nullptr;
+    seg.g[t] = gp.c[t];
+    seg.n[t] = (long long)ds.p[t] * ds.row_len[t];
+    nmax = seg.n[t] > nmax ? seg.n[t] : nmax;
+    aligned = aligned && ((reinterpret_cast<uintptr_t>(cores[t]) | (opt_state ? reinterpret_cast<uintptr_t>(opt_state[t]) : 0)) & 15) == 0;
   }
-  return TTEMB_OK;
+  if (!aligned) return fail(TTEMB_E_BADARG, "cores / optimizer state must be 16-byte aligned");
+  int64_t blocks = (nmax / 4 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+  hipLaunchKernelGGL(fused_step_kernel, dim3((unsigned)blocks, (unsigned)ds.T), dim3(256), 0, st, seg, lr, eps,
+                     opt_state ? 1 : 0);
+  return check_hip(hipGetLastError(), "fused_step_kernel");
 }
 
 int ttemb_backward_sgd(const ttemb_shape_t* shape, float* const* cores, const int64_t* indices,

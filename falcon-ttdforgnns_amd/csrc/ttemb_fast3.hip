@@ -52,6 +52,7 @@ struct Cfg {
   static constexpr int B_FLOATS = kChunk * LDB;
   static constexpr int O_FLOATS = kChunk * LDO;
   // the output rows reuse the staged-G2 region (every G2 read precedes every row write)
+  static constexpr int PB_FLOATS = ((M2 * LDA + 3) / 4) * 4;  // backward reads only the M2 real rows of P
   static constexpr int BO_FLOATS = B_FLOATS > O_FLOATS ? B_FLOATS : O_FLOATS;
   static constexpr int WAVE_FLOATS = P_FLOATS + BO_FLOATS;
   // backward: [P | staged G2 rows, later dP | staged d_output rows, later G1[i1]]
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(
   const int lane = threadIdx.x;
   const int hi = lane >> 4, lo = lane & 15;
   float* pbuf = smem;
-  float* bbuf = pbuf + C::P_FLOATS;   // staged G2 rows
+  float* bbuf = pbuf + C::PB_FLOATS;  // staged G2 rows
   float* dbuf = bbuf + C::B_FLOATS;   // staged d_output rows, later the chunk's E rows
 
   // A wavefront owns the groups that START inside its 64-id window [begin, end): it skips a
@@ -474,6 +475,7 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(
       const int b = f / F4D, c4 = f - b * F4D;
       if (f < kChunk * F4D) *reinterpret_cast<float4*>(dbuf + b * C::LDO + 4 * c4) = pre_d[it];
     }
+    __builtin_amdgcn_sched_barrier(0);  // the row registers are free again only after the stores above
     // ---- request the next chunk's rows now; they land while this chunk computes ----
     const int64_t here = pos;
     const int len = cur.len;
@@ -503,8 +505,8 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(
 #pragma unroll
           for (int t = 0; t < C::RT2; ++t)
             dp[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv[t], dp[mt][t], 0, 0, 0);
+        if (kk == Q2 - 1) __builtin_amdgcn_sched_barrier(0);  // keeps operand loads from piling up in registers
       }
-    __builtin_amdgcn_sched_barrier(0);
 
     // ---- E = P^T (r2 x q0q1) . dO (q0q1 x 16 q2) ----
     f32x4 e[C::RT2][C::NT2];
@@ -527,6 +529,7 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(
         for (int t = 0; t < C::RT2; ++t)
           e[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv, e[t][nt], 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();  // every dO read is done: the region now takes the E rows
@@ -990,11 +993,13 @@ static int run_backward(const DevShape& s, const CorePtrs& cores, const GroupPla
                         const int32_t* nnz_dev, const float* d_output, const CorePtrsMut& d_cores,
                         hipStream_t st) {
   using C = Cfg<Q0, Q1, Q2, R1, R2>;
-  const size_t lds = (size_t)(C::P_FLOATS + C::B_FLOATS + C::O_FLOATS) * sizeof(float);
+  const size_t lds = (size_t)(C::PB_FLOATS + C::B_FLOATS + C::O_FLOATS) * sizeof(float);
   const unsigned ranges = (unsigned)((nnz + kRange - 1) / kRange);
   profile_begin(1, st);
+  profile_begin(2, st);
   hipLaunchKernelGGL((fast3_bwd_chunk_kernel<Q0, Q1, Q2, R1, R2>), dim3(ranges), dim3(64), lds, st, cores.c[0],
                      cores.c[1], cores.c[2], nnz, nnz_dev, (uint32_t)s.p[0], (uint32_t)s.p[2], d_output, plan);
+  profile_end(2, st);
   int rc = check_hip(hipGetLastError(), "fast3_bwd_chunk_kernel");
   if (rc) return rc;
   const int tiles = (int)reduce_tiles(nnz);

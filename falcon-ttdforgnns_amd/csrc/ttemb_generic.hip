@@ -189,8 +189,10 @@ int launch_backward_generic(const DevShape& s, const CorePtrs& cores, const int6
   if (lds > 64 * 1024) return fail(TTEMB_E_UNSUPPORTED, "backward partials of %lld bytes exceed the LDS budget", (long long)lds);
   const int64_t grid = nnz < 262144 ? nnz : 262144;
   profile_begin(1, st);
+  profile_begin(2, st);
   hipLaunchKernelGGL(bwd_generic_kernel, dim3((unsigned)grid), dim3(kWave), (size_t)lds, st, s,
                      cores, indices, rowidx, nnz, nnz_dev, d_output, d_cores);
+  profile_end(2, st);
   profile_end(1, st);
   return check_hip(hipGetLastError(), "bwd_generic_kernel");
 }

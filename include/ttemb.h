@@ -79,8 +79,8 @@ int ttemb_set_path(int32_t path);
 /* Measurement hook (bench.py's roofline leg).  While enabled (process-wide), the
  * main chain kernel of every ttemb_forward / ttemb_backward_* call is bracketed by
  * hipEvents on the call's stream.  ttemb_profile_read waits for the most recent bracket of
- * `which` (0 = forward chain kernel, 1 = backward chain kernel) and returns its
- * duration in milliseconds.  Off by default; costs two event records per call when on. */
+ * `which` (0 = forward chain kernel, 1 = all backward chain kernels, 2 = the backward chunk
+ * kernel alone) and returns its duration in milliseconds.  Off by default; costs two event records per call when on. */
 int ttemb_profile_enable(int32_t on);
 int ttemb_profile_read(int32_t which, float* ms_host);
 
