@@ -123,9 +123,18 @@ def main():
         dom_name, dom_ms, dom_flops = ("fast3_bwd_chunk_kernel", chunk, chunk_flops) if chunk >= fwd else \
                                       ("fast3_forward_kernel", fwd, FWD_FLOPS)
         achieved = N * dom_flops / (dom_ms * 1e-3) / 1e12
+        # HBM bytes per launch of that kernel from the committed PMC passes (profiles/r01_traffic.json;
+        # FETCH_SIZE/WRITE_SIZE cannot be read from inside the process), valid for the default workload
+        traffic = None
+        try:
+            if N == 409600 and args.path == "auto":
+                with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
+                    traffic = json.load(fh)["kernels"][dom_name]["hbm_bytes"]
+        except (OSError, KeyError, ValueError):
+            traffic = None
         roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 3),
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                     "kernel_ms": round(dom_ms, 4), "flops_per_lookup": dom_flops,
                     "fwd_kernel_ms": round(fwd, 4), "bwd_chunk_kernel_ms": round(chunk, 4),
                     "bwd_chain_ms": round(bwd, 4),

@@ -296,3 +296,32 @@ def test_cache_rowwise_adagrad(ops, orc):
     w2, st2 = orc.cache_backward_rowwise_adagrad(g, loc, rowidx, 0.05, 1e-10, st, w)
     np.testing.assert_allclose(stt.cpu().numpy(), st2, rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(wt.cpu().numpy(), w2, rtol=1e-5, atol=1e-6)
+
+
+def test_eff_tt_embedding_api(ops, orc):
+    """Second API of the reference (Efficient_TT/efficient_tt.py:214-307): 2-D cores, one row per id,
+    fused SGD in backward with the constructor's learning rate."""
+    from Efficient_TT.efficient_tt import Eff_TTEmbedding
+    torch.manual_seed(9)
+    p, q, r = [125, 140, 140], [4, 5, 5], [16, 16]
+    emb = Eff_TTEmbedding(2449029, 100, r, p, q, learning_rate=0.05, device=0)
+    assert [tuple(c.shape) for c in emb.tt_cores] == [(125, 64), (140, 1280), (140, 80)]
+    for c in emb.tt_cores:
+        c.data.mul_(8.0)
+    cores = [c.detach().cpu().numpy().copy() for c in emb.tt_cores]
+    rng = np.random.default_rng(9)
+    ids = rng.integers(0, 2449029, size=50000, dtype=np.int64)  # duplicates included, fast path engaged
+    ids[:4] = [0, 2449028, 7, 7]
+    out = emb(torch.tensor(ids).cuda(), None, None, None)
+    R = [1] + r + [1]
+    pick = rng.choice(ids.shape[0], size=400, replace=False)
+    np.testing.assert_allclose(out.detach().cpu().numpy()[pick], orc.tt_rows(ids[pick], cores, p, q, R), rtol=1e-5,
+                               atol=1e-4)
+    d_out = ((torch.rand_like(out) - 0.5) * 0.01)
+    out.backward(d_out)
+    assert all(c.grad is None for c in emb.tt_cores)
+    sub = np.arange(0, ids.shape[0])  # full oracle backward on 50k ids is fine (vectorised)
+    g = orc.tt_dense_backward(ids[sub], np.arange(sub.shape[0] + 1), d_out.cpu().numpy(), cores, p, q, R)
+    for c, c0, gr in zip(emb.tt_cores, cores, g):
+        np.testing.assert_allclose(c.detach().cpu().numpy(), c0 - np.float32(0.05) * gr, rtol=0,
+                                   atol=1e-5 + 1e-4 * float(np.abs(0.05 * gr).max()))

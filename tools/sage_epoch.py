@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""SAGE epoch harness: the caller contract of the TT layer.
+
+DGL and OGB are not available here, so the pieces of `sage_dgl_partition.py:train()` that surround the
+embedding layer are restated in plain PyTorch on a synthetic graph:
+
+  * graph: n nodes, random in-neighbour lists (CSR on the GPU), a fraction `--locality` of the edges
+    short-range (|src - dst| < 2000) to imitate the id locality a METIS reorder produces;
+  * sampler: `MultiLayerNeighborSampler([5, 10, 15])`-style uniform sampling with replacement, from the
+    2048 seeds outwards; frontier ids are unique, seeds first (gnn_model.py:211 relies on that);
+  * model: 3 mean-SAGEConv layers (hidden 256), Adam lr 3e-3 on the GNN weights, cross-entropy on
+    random labels;
+  * input features: `TTEmbeddingBag(ids, arange(N+1))` exactly as `SAGE.forward` calls it
+    (gnn_model.py:198-204), sparse fused-SGD mode; or a fixed dense feature matrix (`--emb dense`).
+
+Prints epoch time and the split sampler / embedding forward / GNN forward+backward / embedding backward.
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "falcon-ttdforgnns_amd")):
+    sys.path.insert(0, p)
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def build_graph(n, avg_deg, locality, dev, gen):
+    E = n * avg_deg
+    dst = torch.randint(0, n, (E,), device=dev, generator=gen)
+    far = torch.randint(0, n, (E,), device=dev, generator=gen)
+    near = (dst + torch.randint(-2000, 2001, (E,), device=dev, generator=gen)).clamp_(0, n - 1)
+    src = torch.where(torch.rand(E, device=dev, generator=gen) < locality, near, far)
+    order = torch.argsort(dst)
+    dst, src = dst[order], src[order]
+    indptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    indptr[1:] = torch.cumsum(torch.bincount(dst, minlength=n), 0)
+    return indptr, src
+
+
+def sample_blocks(indptr, indices, seeds, fanouts, gen, lut):
+    """Returns (input_nodes, blocks); blocks[i] = (src_local, dst_local, n_dst) from the input side.
+    `lut` is a persistent int64[n] scratch filled with -1."""
+    blocks = []
+    nodes = seeds
+    for fan in reversed(fanouts):  # seed layer first
+        start = indptr[nodes]
+        deg = indptr[nodes + 1] - start
+        r = torch.rand(nodes.numel(), fan, device=nodes.device, generator=gen)
+        pick = (start[:, None] + (r * deg[:, None].clamp(min=1)).long()).clamp_(max=indices.numel() - 1)
+        nbr = torch.where(deg[:, None] > 0, indices[pick], nodes[:, None]).reshape(-1)
+        dst_local = torch.arange(nodes.numel(), device=nodes.device).repeat_interleave(fan)
+        # unique frontier with the dst nodes first (DGL block convention, gnn_model.py:211)
+        lut[nodes] = torch.arange(nodes.numel(), device=nodes.device)
+        extra = torch.unique(nbr)
+        extra = extra[lut[extra] < 0]
+        lut[extra] = torch.arange(nodes.numel(), nodes.numel() + extra.numel(), device=nodes.device)
+        frontier = torch.cat([nodes, extra])
+        src_local = lut[nbr]
+        lut[frontier] = -1
+        blocks.append((src_local, dst_local, nodes.numel()))
+        nodes = frontier
+    blocks.reverse()
+    return nodes, blocks
+
+
+class MeanSAGE(nn.Module):
+    def __init__(self, d_in, d_out):
+        super().__init__()
+        self.self_lin = nn.Linear(d_in, d_out)
+        self.neigh_lin = nn.Linear(d_in, d_out, bias=False)
+
+    def forward(self, h, block):
+        src_local, dst_local, n_dst = block
+        agg = torch.zeros(n_dst, h.shape[1], device=h.device, dtype=h.dtype)
+        agg.index_add_(0, dst_local, h[src_local])
+        deg = torch.bincount(dst_local, minlength=n_dst).clamp(min=1).unsqueeze(1)
+        return self.self_lin(h[:n_dst]) + self.neigh_lin(agg / deg)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--nodes", type=int, default=2449029)
+    ap.add_argument("--avg-degree", type=int, default=25)
+    ap.add_argument("--locality", type=float, default=0.5)
+    ap.add_argument("--train-nodes", type=int, default=196615)
+    ap.add_argument("--batch", type=int, default=2048)
+    ap.add_argument("--fan-out", default="5,10,15")
+    ap.add_argument("--hidden", type=int, default=256)
+    ap.add_argument("--classes", type=int, default=47)
+    ap.add_argument("--emb", default="tt", choices=["tt", "dense"])
+    ap.add_argument("--epochs", type=int, default=2)
+    ap.add_argument("--max-steps", type=int, default=0)
+    a = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(0)
+    fanouts = [int(x) for x in a.fan_out.split(",")]
+    t0 = time.perf_counter()
+    indptr, indices = build_graph(a.nodes, a.avg_degree, a.locality, dev, gen)
+    torch.cuda.synchronize()
+    print(f"graph: {a.nodes} nodes, {indices.numel()} edges, built in {time.perf_counter() - t0:.1f} s", flush=True)
+    train = torch.randperm(a.nodes, device=dev, generator=gen)[: a.train_nodes]
+    labels = torch.randint(0, a.classes, (a.nodes,), device=dev, generator=gen)
+    D = 100
+    if a.emb == "tt":
+        from FBTT.tt_embeddings_ops import TTEmbeddingBag
+        emb = TTEmbeddingBag(a.nodes, D, [16, 16], [125, 140, 140], [4, 5, 5], sparse=True, use_cache=False,
+                             weight_dist="normal", learning_rate=0.01)
+        for c in emb.tt_cores:
+            c.data.mul_(30.0)
+    else:
+        feat = torch.randn(a.nodes, D, device=dev, generator=gen)
+    layers = nn.ModuleList([MeanSAGE(D, a.hidden), MeanSAGE(a.hidden, a.hidden), MeanSAGE(a.hidden, a.classes)]).to(dev)
+    opt = torch.optim.Adam(layers.parameters(), lr=3e-3)
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    lut = torch.full((a.nodes,), -1, dtype=torch.int64, device=dev)
+    for epoch in range(a.epochs):
+        perm = train[torch.randperm(train.numel(), device=dev, generator=gen)]
+        steps = (perm.numel() + a.batch - 1) // a.batch
+        if a.max_steps:
+            steps = min(steps, a.max_steps)
+        split = {"sample": 0.0, "emb_fwd": 0.0, "gnn": 0.0, "emb_bwd+opt": 0.0}
+        frontier = 0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s in range(steps):
+            e = [ev() for _ in range(5)]
+            seeds = perm[s * a.batch:(s + 1) * a.batch]
+            e[0].record()
+            input_nodes, blocks = sample_blocks(indptr, indices, seeds, fanouts, gen, lut)
+            e[1].record()
+            if a.emb == "tt":
+                offsets = torch.arange(input_nodes.numel() + 1, device=dev)
+                h = emb(input_nodes, offsets)
+            else:
+                h = feat[input_nodes]
+            e[2].record()
+            x = h
+            for li, (layer, block) in enumerate(zip(layers, blocks)):
+                x = layer(x, block)
+                if li != len(layers) - 1:
+                    x = F.relu(x)
+            loss = F.cross_entropy(x, labels[seeds])
+            opt.zero_grad(set_to_none=True)
+            if a.emb == "tt":  # stamp the moment the gradient reaches the embedding output
+                h.register_hook(lambda g, ev3=e[3]: (ev3.record(), g)[1])
+                loss.backward()
+            else:
+                loss.backward()
+                e[3].record()
+            opt.step()
+            e[4].record()
+            torch.cuda.synchronize()
+            for k, (i, j) in zip(split, ((0, 1), (1, 2), (2, 3), (3, 4))):
+                split[k] += e[i].elapsed_time(e[j])
+            frontier += input_nodes.numel()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        msg = ", ".join(f"{k} {v / steps:.2f} ms" for k, v in split.items())
+        print(f"epoch {epoch}: {steps} steps in {wall:.2f} s ({wall / steps * 1e3:.1f} ms/step, "
+              f"{frontier / steps:.0f} frontier ids/step, loss {loss.item():.3f}); per step: {msg}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
