@@ -325,3 +325,44 @@ def test_eff_tt_embedding_api(ops, orc):
     for c, c0, gr in zip(emb.tt_cores, cores, g):
         np.testing.assert_allclose(c.detach().cpu().numpy(), c0 - np.float32(0.05) * gr, rtol=0,
                                    atol=1e-5 + 1e-4 * float(np.abs(0.05 * gr).max()))
+
+
+def test_cache_live_on_the_fast_path(ops, orc):
+    """Cache switched on with a batch large enough for the grouped MFMA path: the TT/cached split count
+    stays on the device (nnz_dev) and both kernel families must honour it, forward and backward."""
+    torch.manual_seed(11)
+    rng = np.random.default_rng(11)
+    p, q, r = [125, 140, 140], [4, 5, 5], [16, 16]
+    n, D, lr = 2449029, 100, 0.05
+    emb = ops.TTEmbeddingBag(n, D, r, p, q, sparse=True, use_cache=True, cache_size=20000, hashtbl_size=n,
+                             weight_dist="normal", learning_rate=lr)
+    for c in emb.tt_cores:
+        c.data.mul_(300.0)
+    hot = rng.choice(n, size=15000, replace=False)
+    for _ in range(3):
+        batch = np.concatenate([rng.choice(hot, size=30000), rng.integers(0, n, size=30000)])
+        emb(torch.tensor(batch).cuda(), torch.arange(batch.shape[0] + 1).cuda())
+    emb.cache_populate()
+    batch = np.concatenate([rng.choice(hot, size=30000), rng.integers(0, n, size=70000)])
+    rng.shuffle(batch)
+    idx = torch.tensor(batch).cuda()
+    offs = torch.arange(batch.shape[0] + 1).cuda()
+    R = [1] + r + [1]
+    cores_np = [c.detach()[0].cpu().numpy().copy() for c in emb.tt_cores]
+    cache_before = emb.cache_weight.detach().cpu().numpy().copy()
+    out = emb(idx, offs)
+    pick = rng.choice(batch.shape[0], size=2000, replace=False)
+    np.testing.assert_allclose(out.detach().cpu().numpy()[pick], orc.tt_rows(batch[pick], cores_np, p, q, R),
+                               rtol=1e-5, atol=1e-4)
+    d_out = (torch.rand_like(out) - 0.5) * 0.02
+    out.backward(d_out)
+    is_tt, loc = orc.cache_lookup(batch, emb.hashtbl.cpu().numpy(), emb.cache_state.cpu().numpy())
+    assert 10000 < (~is_tt).sum() < 40000
+    rows = np.arange(batch.shape[0])
+    g_cache = orc.cache_backward_dense(d_out.cpu().numpy(), loc[~is_tt], rows[~is_tt], 20000, D)
+    np.testing.assert_allclose(emb.cache_weight.detach().cpu().numpy(), cache_before - lr * g_cache, rtol=0, atol=1e-5)
+    tt_ids = batch[is_tt]
+    g = orc.tt_dense_backward(tt_ids, np.arange(tt_ids.shape[0] + 1), d_out.cpu().numpy()[is_tt], cores_np, p, q, R)
+    for c, c0, gr in zip(emb.tt_cores, cores_np, g):
+        np.testing.assert_allclose(c.detach()[0].cpu().numpy(), c0 - np.float32(lr) * gr, rtol=0,
+                                   atol=1e-5 + 2e-4 * float(np.abs(lr * gr).max()))

@@ -15,7 +15,8 @@ from conftest import ROW_CASES, TINY_CASES, golden_cores, load_golden, seeded_co
 
 pytestmark = pytest.mark.gpu
 
-PATHS = ["generic", "auto"]
+PATHS = ["generic", "auto", "fast3"]
+FAST3_SHAPES = {(4, 5, 5, 16, 16), (4, 4, 8, 8, 8), (8, 4, 4, 32, 32)}  # (q0, q1, q2, r1, r2) of the MFMA path
 
 
 @pytest.fixture(scope="module")
@@ -38,7 +39,12 @@ def dev(x, dtype=None):
     return t.cuda()
 
 
-def set_path(nat, path):
+def set_path(nat, path, q=None, R=None):
+    """Select the kernel family; forcing the MFMA path on a shape it does not cover skips the test."""
+    if path == "fast3":
+        key = (tuple(int(x) for x in q) + tuple(int(x) for x in R[1:-1])) if q is not None and len(q) == 3 else None
+        if key not in FAST3_SHAPES:
+            pytest.skip("shape outside the fast 3-core path")
     nat.set_path({"auto": nat.PATH_AUTO, "generic": nat.PATH_GENERIC, "fast3": nat.PATH_FAST3}[path])
 
 
@@ -84,7 +90,7 @@ def assert_grads_close(got, want, rel=1e-4):
 @pytest.mark.parametrize("name", TINY_CASES)
 def test_forward_golden(nat, name, path):
     g = load_golden(name)
-    set_path(nat, path)
+    set_path(nat, path, g["q"], g["R"])
     out, rowidx = run_forward(nat, g["p"], g["q"], g["R"], golden_cores(g), g["indices"], g["offsets"])
     np.testing.assert_allclose(out, g["out"], rtol=1e-5, atol=1e-4)
     from oracle import tt_oracle
@@ -95,7 +101,7 @@ def test_forward_golden(nat, name, path):
 @pytest.mark.parametrize("name", ROW_CASES)
 def test_rows_of_baseline_configs(nat, name, path):
     g = load_golden(name)
-    set_path(nat, path)
+    set_path(nat, path, g["q"], g["R"])
     cores = seeded_cores(g["p"], g["q"], g["R"], g["seed"], g["core_scale"])
     n = g["indices"].shape[0]
     out, _ = run_forward(nat, g["p"], g["q"], g["R"], cores, g["indices"], np.arange(n + 1))
@@ -106,7 +112,7 @@ def test_rows_of_baseline_configs(nat, name, path):
 @pytest.mark.parametrize("name", TINY_CASES)
 def test_backward_dense_golden(nat, name, path):
     g = load_golden(name)
-    set_path(nat, path)
+    set_path(nat, path, g["q"], g["R"])
     grads = run_backward_dense(nat, g["p"], g["q"], g["R"], golden_cores(g), g["indices"], g["offsets"],
                                g["d_output"])
     assert_grads_close(grads, [g[f"grad{t}"] for t in range(len(grads))])
@@ -116,7 +122,7 @@ def test_backward_dense_golden(nat, name, path):
 @pytest.mark.parametrize("name", TINY_CASES)
 def test_fused_sgd_and_adagrad_golden(nat, name, path):
     g = load_golden(name)
-    set_path(nat, path)
+    set_path(nat, path, g["q"], g["R"])
     p, q, R = g["p"], g["q"], g["R"]
     shape = nat.make_shape(p, q, R)
     ws = nat.Workspace()
@@ -188,7 +194,7 @@ def random_case(cfg, n_bags, mean_len, seed, unique=False):
     ("products", 63, None), ("products", 65, 1.0),
 ])
 def test_forward_backward_vs_oracle(nat, orc, cfg, n_bags, mean_len, path):
-    set_path(nat, path)
+    set_path(nat, path, CONFIGS[cfg][1], CONFIGS[cfg][2])
     p, q, R, cores, idx, offsets, d_out = random_case(cfg, n_bags, mean_len, seed=sum(map(ord, cfg)) + n_bags)
     out, _ = run_forward(nat, p, q, R, cores, idx, offsets)
     want = orc.tt_forward(idx, offsets, cores, p, q, R)
@@ -199,8 +205,8 @@ def test_forward_backward_vs_oracle(nat, orc, cfg, n_bags, mean_len, path):
 
 @pytest.mark.parametrize("path", PATHS)
 def test_empty_and_degenerate_inputs(nat, orc, path):
-    set_path(nat, path)
     p, q, R, _ = CONFIGS["products"]
+    set_path(nat, path, q, R)
     _, _, _, cores, _, _, _ = random_case("products", 4, None, seed=5)
     # no ids at all: output is all zeros, grads are all zeros
     out, _ = run_forward(nat, p, q, R, cores, np.zeros(0, np.int64), np.zeros(6, np.int64))
@@ -236,6 +242,33 @@ def test_flat_optimizer_steps(nat):
 # ---------------------------------------------------------------------------------------
 # full-size properties (BASELINE.json sizes; the oracle is too slow / big here)
 # ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg,n_ids", [("arxiv", 40000), ("products", 60000), ("papers", 30000)])
+def test_fast_path_medium_batches_with_duplicates_and_bags(nat, orc, cfg, n_ids):
+    """The grouped MFMA path on batches big enough to have full chunks, several chunks per group,
+    duplicate ids and multi-id bags (atomic row accumulation), against the oracle."""
+    p, q, R, n_emb = CONFIGS[cfg]
+    set_path(nat, "fast3", q, R)
+    rng = np.random.default_rng(5 + n_ids)
+    cores = [(rng.standard_normal((p[t], R[t] * q[t] * R[t + 1])) * 0.3).astype(np.float32) for t in range(3)]
+    # half the ids from 300 dense windows (big groups), half uniform; then duplicates
+    starts = rng.integers(0, n_emb - 400, size=300)
+    local = (starts[:, None] + rng.integers(0, 400, size=(300, n_ids // 600))).reshape(-1)
+    idx = np.concatenate([local, rng.integers(0, n_emb, size=n_ids - local.shape[0])]).astype(np.int64)
+    idx[:1000] = idx[1000:2000]
+    rng.shuffle(idx)
+    lens = rng.integers(0, 4, size=n_ids)
+    lens = lens[np.cumsum(lens) <= n_ids]
+    idx = idx[: int(lens.sum())]
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    B = offsets.shape[0] - 1
+    D = int(np.prod(q))
+    out, _ = run_forward(nat, p, q, R, cores, idx, offsets)
+    np.testing.assert_allclose(out, orc.tt_forward(idx, offsets, cores, p, q, R), rtol=1e-5, atol=2e-4)
+    d_out = ((rng.random((B, D)) - 0.5) * 0.1).astype(np.float32)
+    grads = run_backward_dense(nat, p, q, R, cores, idx, offsets, d_out)
+    assert_grads_close(grads, orc.tt_dense_backward(idx, offsets, d_out, cores, p, q, R), rel=2e-4)
+
+
 @pytest.mark.parametrize("path", ["auto"])
 def test_full_size_properties_products(nat, orc, path):
     set_path(nat, path)
