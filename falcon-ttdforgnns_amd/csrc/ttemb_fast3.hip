@@ -28,6 +28,13 @@ namespace ttemb {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef TTEMB_FWD_VARIANT
+#define TTEMB_FWD_VARIANT 0
+#endif
+#ifndef TTEMB_FWD_WAVES
+#define TTEMB_FWD_WAVES 1   // wavefronts per forward workgroup (each is independent)
+#endif
+
 constexpr int kChunk = 16;        // ids per stage-2 GEMM (N = 16 * q2 columns)
 constexpr int kRange = 64;        // sorted ids walked by one wavefront
 constexpr uint32_t kMultiBit = 0x80000000u;
@@ -132,67 +139,82 @@ __global__ __launch_bounds__(kTile) void fast3_scatter_kernel(int64_t nnz, const
 // forward
 // ---------------------------------------------------------------------------------
 template <int Q0, int Q1, int Q2, int R1, int R2>
-__global__ __launch_bounds__(256) void fast3_forward_kernel(
+__global__ __launch_bounds__(64 * TTEMB_FWD_WAVES) void fast3_forward_kernel(
     const float* __restrict__ G0, const float* __restrict__ G1, const float* __restrict__ G2,
     const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, int64_t nnz,
     const int32_t* __restrict__ nnz_dev, uint32_t p0, uint32_t p2, float* __restrict__ out) {
   using C = Cfg<Q0, Q1, Q2, R1, R2>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
   const int hi = lane >> 4, lo = lane & 15;
   float* pbuf = smem + wave * C::WAVE_FLOATS;
   float* bbuf = pbuf + C::P_FLOATS;
   float* obuf = bbuf;
 
   const int64_t cnt = live_count(nnz, nnz_dev);
-  const int64_t begin = ((int64_t)blockIdx.x * 4 + wave) * kRange;
+  const int64_t begin = ((int64_t)blockIdx.x * TTEMB_FWD_WAVES + wave) * kRange;
   if (begin >= cnt) return;
   const int range = (int)(begin + kRange < cnt ? kRange : cnt - begin);
-  // the whole range's (key, value) pairs live in registers: one lane per sorted id
-  uint32_t key_r = 0xffffffffu, val_r = 0;
+  // the whole window's (group, i2, value) triples live in registers: one lane per grouped id
+  uint32_t grp_r = 0xffffffffu, i2_r = 0, val_r = 0;
   if (lane < range) {
-    key_r = keys[begin + lane];
+    const uint32_t key = keys[begin + lane];
+    grp_r = key / p2;
+    i2_r = key - grp_r * p2;
     val_r = vals[begin + lane];
   }
 
+  constexpr int F4G = C::ROW2 / 4, NLG = (kChunk * F4G + kWave - 1) / kWave;
+  constexpr int D4 = C::D / 4, NLO = (kChunk * D4 + kWave - 1) / kWave;
+  struct Chunk {
+    int len;
+    uint32_t group, i2, val;
+  };
+  // chunk = leading run (<= 16) of ids that share the group of the id at `at`
+  auto discover = [&](int at) {
+    Chunk c;
+    c.len = 0;
+    c.group = 0xffffffffu;
+    c.i2 = 0;
+    c.val = 0;
+    if (at >= range) return c;
+    const uint32_t g = __shfl(grp_r, (at + lo) & 63, kWave);
+    c.val = __shfl(val_r, (at + lo) & 63, kWave);
+    c.group = __shfl(grp_r, at, kWave);
+    const unsigned long long same = __ballot(hi == 0 && at + lo < range && g == c.group);
+    c.len = __builtin_ctzll(~same);
+    const uint32_t i2 = __shfl(i2_r, (at + lo) & 63, kWave);
+    c.i2 = lo < c.len ? i2 : 0u;  // row 0 stands in for unused slots
+    return c;
+  };
+  // the chunk's G2 rows are requested one chunk ahead (registers), so their L2 latency hides
+  // behind the previous chunk's MFMAs
+  float4 pre_g[NLG];
+  auto request_rows = [&](const Chunk& c) {
+#pragma unroll
+    for (int it = 0; it < NLG; ++it) {
+      const int f = it * kWave + lane;
+      const int b = f / F4G, c4 = f - b * F4G;
+      const uint32_t row2 = __shfl(c.i2, b < kChunk ? b : 0, kWave);
+      pre_g[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (f < kChunk * F4G) pre_g[it] = *reinterpret_cast<const float4*>(G2 + (size_t)row2 * C::ROW2 + 4 * c4);
+    }
+  };
+
   uint32_t cur_group = 0xffffffffu;
   int pos = 0;
-  while (pos < range) {
-    // ---- chunk = leading run (<= 16) of ids that share the group of the id at `pos` ----
-    const uint32_t key = __shfl(key_r, (pos + lo) & 63, kWave);
-    const uint32_t val = __shfl(val_r, (pos + lo) & 63, kWave);
-    const uint32_t group0 = __shfl(key_r, pos, kWave) / p2;
-    const uint32_t my_group = key / p2;
-    const unsigned long long same = __ballot(hi == 0 && pos + lo < range && my_group == group0);
-    const int len = __builtin_ctzll(~same);
-    const uint32_t i2 = lo < len ? key - my_group * p2 : 0u;  // lanes lo..lo+48 hold copies
-
-    // ---- stage the chunk's G2 rows (row 0 stands in for unused slots) ----
-    {
-      constexpr int F4 = C::ROW2 / 4;  // float4 per row
-#pragma unroll
-      for (int it = 0; it < (kChunk * F4 + kWave - 1) / kWave; ++it) {
-        const int f = it * kWave + lane;
-        const int b = f / F4, c4 = f - b * F4;
-        const uint32_t row2 = __shfl(i2, b < kChunk ? b : 0, kWave);
-        if (f < kChunk * F4) {
-          const float4 v = *reinterpret_cast<const float4*>(G2 + (size_t)row2 * C::ROW2 + 4 * c4);
-          *reinterpret_cast<float4*>(bbuf + b * C::LDB + 4 * c4) = v;
-        }
-      }
-    }
-
+  Chunk cur = discover(pos);
+  if (cur.len) request_rows(cur);
+  while (cur.len) {
     // ---- stage 1 (once per group): P = G0[i0] . G1[i1] -> LDS ----
-    if (group0 != cur_group) {
-      cur_group = group0;
-      const uint32_t i1 = group0 / p0;
-      const uint32_t i0 = group0 - i1 * p0;
+    if (cur.group != cur_group) {
+      cur_group = cur.group;
+      const uint32_t i1 = cur_group / p0;
+      const uint32_t i0 = cur_group - i1 * p0;
       const float* g0 = G0 + (size_t)i0 * C::ROW0;
       const float* g1 = G1 + (size_t)i1 * C::ROW1;
       f32x4 acc[C::NT1];
-#pragma unroll
-      for (int nt = 0; nt < C::NT1; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < C::KS1; ++s) {
         const int k = 4 * s + hi;
@@ -200,7 +222,7 @@ __global__ __launch_bounds__(256) void fast3_forward_kernel(
 #pragma unroll
         for (int nt = 0; nt < C::NT1; ++nt) {
           const float b = g1[k * C::N1 + 16 * nt + lo];
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, s == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[nt], 0, 0, 0);
         }
       }
       // accumulator (row 4*hi + r, col 16*nt + lo) -> P as a (q0 q1) x r2 matrix
@@ -215,10 +237,27 @@ __global__ __launch_bounds__(256) void fast3_forward_kernel(
         }
       }
     }
+    // ---- the chunk's G2 rows: registers -> LDS ----
+#pragma unroll
+    for (int it = 0; it < NLG; ++it) {
+      const int f = it * kWave + lane;
+      const int b = f / F4G, c4 = f - b * F4G;
+      if (f < kChunk * F4G) *reinterpret_cast<float4*>(bbuf + b * C::LDB + 4 * c4) = pre_g[it];
+    }
+#if TTEMB_FWD_VARIANT != 1
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    const int len = cur.len;
+    const uint32_t val = cur.val;
+    pos += len;
+    cur = discover(pos);
+    if (cur.len) request_rows(cur);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#if TTEMB_FWD_VARIANT != 1
     __builtin_amdgcn_sched_barrier(0);
+#endif
 
     // ---- stage 2: (q0 q1 x r2) . (r2 x 16 q2), one 16-row tile of P at a time ----
     float bv[C::KS2][C::NT2];
@@ -235,13 +274,11 @@ __global__ __launch_bounds__(256) void fast3_forward_kernel(
     for (int mt = 0; mt < C::MT2; ++mt) {
       f32x4 acc[C::NT2];
 #pragma unroll
-      for (int nt = 0; nt < C::NT2; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
       for (int s = 0; s < C::KS2; ++s) {
         const float a = pbuf[(16 * mt + lo) * C::LDA + 4 * s + hi];
 #pragma unroll
         for (int nt = 0; nt < C::NT2; ++nt)
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[s][nt], acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[s][nt], s == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[nt], 0, 0, 0);
       }
       // rows -> LDS, id-major
 #pragma unroll
@@ -259,30 +296,26 @@ __global__ __launch_bounds__(256) void fast3_forward_kernel(
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // ---- 16-byte global stores of whole rows ----
-    {
-      constexpr int D4 = C::D / 4;
 #pragma unroll
-      for (int it = 0; it < (kChunk * D4 + kWave - 1) / kWave; ++it) {
-        const int f = it * kWave + lane;
-        const int b = f / D4, c4 = f - b * D4;
-        const uint32_t v = __shfl(val, b < kChunk ? b : 0, kWave);
-        if (f < kChunk * D4 && b < len) {
-          const float4 x = *reinterpret_cast<const float4*>(obuf + b * C::LDO + 4 * c4);
-          float* dst = out + (size_t)(v & ~kMultiBit) * C::D + 4 * c4;
-          if (v & kMultiBit) {
-            atomicAdd(dst + 0, x.x);
-            atomicAdd(dst + 1, x.y);
-            atomicAdd(dst + 2, x.z);
-            atomicAdd(dst + 3, x.w);
-          } else {
-            *reinterpret_cast<float4*>(dst) = x;
-          }
+    for (int it = 0; it < NLO; ++it) {
+      const int f = it * kWave + lane;
+      const int b = f / D4, c4 = f - b * D4;
+      const uint32_t v = __shfl(val, b < kChunk ? b : 0, kWave);
+      if (f < kChunk * D4 && b < len) {
+        const float4 x = *reinterpret_cast<const float4*>(obuf + b * C::LDO + 4 * c4);
+        float* dst = out + (size_t)(v & ~kMultiBit) * C::D + 4 * c4;
+        if (v & kMultiBit) {
+          atomicAdd(dst + 0, x.x);
+          atomicAdd(dst + 1, x.y);
+          atomicAdd(dst + 2, x.z);
+          atomicAdd(dst + 3, x.w);
+        } else {
+          *reinterpret_cast<float4*>(dst) = x;
         }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    pos += len;
   }
 }
 
@@ -954,19 +987,10 @@ template <int Q0, int Q1, int Q2, int R1, int R2>
 static int run_forward(const DevShape& s, const CorePtrs& cores, const GroupPlan& ids, int64_t nnz,
                        const int32_t* nnz_dev, float* output, hipStream_t st) {
   using C = Cfg<Q0, Q1, Q2, R1, R2>;
-  const size_t lds = 4 * C::WAVE_FLOATS * sizeof(float);
-  const int64_t waves = (nnz + kRange - 1) / kRange;
-  const unsigned blocks = (unsigned)((waves + 3) / 4);
-  static bool attr_set = false;
-  if (!attr_set) {
-    int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&fast3_forward_kernel<Q0, Q1, Q2, R1, R2>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                       "hipFuncSetAttribute");
-    if (rc) return rc;
-    attr_set = true;
-  }
+  const size_t lds = TTEMB_FWD_WAVES * C::WAVE_FLOATS * sizeof(float);
+  const unsigned blocks = (unsigned)((nnz + kRange * TTEMB_FWD_WAVES - 1) / (kRange * TTEMB_FWD_WAVES));
   profile_begin(0, st);
-  hipLaunchKernelGGL((fast3_forward_kernel<Q0, Q1, Q2, R1, R2>), dim3(blocks), dim3(256), lds, st, cores.c[0],
+  hipLaunchKernelGGL((fast3_forward_kernel<Q0, Q1, Q2, R1, R2>), dim3(blocks), dim3(64 * TTEMB_FWD_WAVES), lds, st, cores.c[0],
                      cores.c[1], cores.c[2], ids.keys, ids.vals, nnz, nnz_dev, (uint32_t)s.p[0],
                      (uint32_t)s.p[2], output);
   profile_end(0, st);

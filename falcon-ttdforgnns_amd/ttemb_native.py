@@ -18,7 +18,7 @@ from typing import List, Optional, Sequence
 import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first, so we share one HIP runtime)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libttemb_hip.so")
+LIB_PATH = os.environ.get("TTEMB_LIB") or os.path.join(_HERE, "lib", "libttemb_hip.so")
 
 MAX_CORES = 4
 OP_FORWARD, OP_BACKWARD, OP_PREPROCESS, OP_CACHE_POPULATE = 0, 1, 2, 3
