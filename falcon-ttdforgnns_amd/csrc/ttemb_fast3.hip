@@ -402,7 +402,7 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(
 
   // ---- chunk discovery over a sliding 64-id register window ----
   int64_t win = -kWave;
-  uint32_t key_r = 0xffffffffu, val_r = 0;
+  uint32_t grp_r = 0xffffffffu, i2_r = 0, val_r = 0;
   struct Chunk {
     int len;            // ids in the chunk, 0 = nothing left for this wavefront
     uint32_t group, i2, val;
@@ -414,23 +414,25 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(
     c.i2 = 0;
     c.val = 0;
     if (at >= cnt) return c;
-    if (at + kChunk > win + kWave) {  // slide the window
+    if (at + kChunk > win + kWave) {  // slide the window; (group, i2) are decoded once per id here
       win = at;
-      key_r = 0xffffffffu;
+      grp_r = 0xffffffffu;
       if (win + lane < cnt) {
-        key_r = plan.keys[win + lane];
+        const uint32_t key = plan.keys[win + lane];
+        grp_r = key / p2;
+        i2_r = key - grp_r * p2;
         val_r = plan.vals[win + lane];
       }
     }
     const int off = (int)(at - win);
-    const uint32_t key = __shfl(key_r, (off + lo) & 63, kWave);
+    const uint32_t g = __shfl(grp_r, (off + lo) & 63, kWave);
     c.val = __shfl(val_r, (off + lo) & 63, kWave);
-    c.group = __shfl(key_r, off, kWave) / p2;
+    c.group = __shfl(grp_r, off, kWave);
     if (at >= end && c.group != open_group) return c;  // past the window: only the open group continues
-    const uint32_t my_group = key / p2;
-    const unsigned long long same = __ballot(hi == 0 && at + lo < cnt && my_group == c.group);
+    const unsigned long long same = __ballot(hi == 0 && at + lo < cnt && g == c.group);
     c.len = __builtin_ctzll(~same);
-    c.i2 = lo < c.len ? key - my_group * p2 : 0u;
+    const uint32_t i2 = __shfl(i2_r, (off + lo) & 63, kWave);
+    c.i2 = lo < c.len ? i2 : 0u;
     return c;
   };
   // the chunk's G2 rows and d_output rows travel through registers: they are requested one

@@ -366,3 +366,61 @@ def test_cache_live_on_the_fast_path(ops, orc):
     for c, c0, gr in zip(emb.tt_cores, cores_np, g):
         np.testing.assert_allclose(c.detach()[0].cpu().numpy(), c0 - np.float32(lr) * gr, rtol=0,
                                    atol=1e-5 + 2e-4 * float(np.abs(lr * gr).max()))
+
+
+def _dp_gpu_worker(rank, world, port, out_dir):
+    import os
+    import sys
+    from conftest import PKG, ROOT
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # both ranks share the one GPU of the box
+    from FBTT.tt_embeddings_ops import TTEmbeddingBag
+    from ttemb_dist import TTDataParallel
+    torch.cuda.set_device(0)
+    torch.manual_seed(50 + rank)
+    p, q, r = [125, 140, 140], [4, 5, 5], [16, 16]
+    emb = TTEmbeddingBag(2449029, 100, r, p, q, sparse=False, use_cache=False, weight_dist="normal", learning_rate=0.2)
+    for c in emb.tt_cores:
+        c.data.mul_(300.0)
+    dp = TTDataParallel(emb)
+    dp.broadcast_parameters(0)
+    start = [c.detach().cpu().clone() for c in emb.tt_cores]
+    g = torch.Generator().manual_seed(7 + rank)
+    ids = torch.randperm(2449029, generator=g)[:60000]
+    d_out = (torch.rand(60000, 100, generator=g) - 0.5) * 0.02
+    out = emb(ids.cuda(), torch.arange(60001).cuda())
+    out.backward(d_out.cuda())
+    dp.step()
+    torch.cuda.synchronize()
+    torch.save({"start": start, "ids": ids, "d_out": d_out, "end": [c.detach().cpu().clone() for c in emb.tt_cores]},
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_step_two_ranks_on_gpu(orc, tmp_path):
+    """TTDataParallel end to end with the real kernels: two ranks (gloo carries the GPU tensors; RCCL needs
+    one GPU per rank), dense backward -> ONE all-reduce of the flattened core gradients -> fused SGD."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_dp_gpu_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r = [torch.load(tmp_path / f"rank{k}.pt") for k in range(2)]
+    p, q, R = [125, 140, 140], [4, 5, 5], [1, 16, 16, 1]
+    cores = [c[0].numpy() for c in r[0]["start"]]
+    grads = [orc.tt_dense_backward(r[k]["ids"].numpy(), np.arange(60001), r[k]["d_out"].numpy(), cores, p, q, R)
+             for k in range(2)]
+    for t in range(3):
+        assert torch.equal(r[0]["start"][t], r[1]["start"][t])
+        want = cores[t] - np.float32(0.2) * (grads[0][t] + grads[1][t]) / 2
+        for k in range(2):
+            np.testing.assert_allclose(r[k]["end"][t][0].numpy(), want, rtol=0,
+                                       atol=1e-5 + 2e-4 * float(np.abs(0.1 * (grads[0][t] + grads[1][t])).max()))
+        assert torch.equal(r[0]["end"][t], r[1]["end"][t])  # replicas stay bit-identical
