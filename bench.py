@@ -144,6 +144,22 @@ def main():
                     "bwd_chain_frac": round(N * BWD_FLOPS / (bwd * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                     "fwd_row_store_gbs": round(N * (8 + 4 * D) / (fwd * 1e-3) / 1e9, 1),
                     "peak_hbm_gbs": PEAK_HBM_GBS}
+        # latency regime of the metric's "batch 2048": 2048 unique ids per step (sparse batch -> generic
+        # wave-per-id kernels), same fwd + bwd + SGD step through the class
+        small = None
+        if world == 1:
+            ids_s = torch.from_numpy(rng.choice(N_EMB, size=2048, replace=False).astype(np.int64)).cuda()
+            offs_s = torch.arange(2049, dtype=torch.int64, device="cuda")
+            d_s = d_out[:2048]
+            for _ in range(20):
+                emb(ids_s, offs_s).backward(d_s)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(200):
+                emb(ids_s, offs_s).backward(d_s)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / 200
+            small = {"ids": 2048, "us_per_step": round(dt * 1e6, 1), "lookups_per_s": round(2048 / dt, 1)}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             from oracle import cpu_einsum
@@ -162,7 +178,7 @@ def main():
                                    "2048-seed batch = 409600 unique uniform ids per GPU, bag length 1",
                        "p": P, "q": Q, "tt_ranks": RANKS, "num_embeddings": N_EMB, "ids_per_gpu_step": N,
                        "parallelism": f"dp{world}", "kernel_path": args.path},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "batch2048_step": small,
         }
     if world > 1:
         dist.barrier()

@@ -688,7 +688,10 @@ __global__ __launch_bounds__(NWB * 64) void fast3_dg2_reduce_kernel(GroupPlan pl
 }
 
 // C. group epilogue: one wavefront per kGroupsC consecutive groups (empty ones are skipped)
-constexpr int kGroupsC = 8;
+#ifndef TTEMB_GROUPS_C
+#define TTEMB_GROUPS_C 8
+#endif
+constexpr int kGroupsC = TTEMB_GROUPS_C;
 template <int Q0, int Q1, int Q2, int R1, int R2>
 __global__ __launch_bounds__(64) void fast3_group_epilogue_kernel(
     const float* __restrict__ G0, const float* __restrict__ G1, uint32_t p0, uint32_t G, GroupPlan plan,
@@ -879,7 +882,10 @@ static int64_t scan_temp_bytes(int64_t G) { return 64 * 1024 + (G + 1) / 8; }
 
 bool fast3_pays(const DevShape& s, int64_t nnz) { return nnz >= 2 * num_groups(s); }
 
-constexpr int kRowsB = 2048;  // E rows per workgroup of the dG2 reduce
+#ifndef TTEMB_ROWS_B
+#define TTEMB_ROWS_B 2048
+#endif
+constexpr int kRowsB = TTEMB_ROWS_B;  // E rows per workgroup of the dG2 reduce
 constexpr int NWB = 16;
 static int64_t reduce_tiles(int64_t nnz) { return (nnz + kRowsB - 1) / kRowsB; }
 
