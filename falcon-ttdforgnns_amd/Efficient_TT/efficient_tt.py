@@ -36,22 +36,22 @@ class TT_core_function(torch.autograd.Function):
     def forward(ctx, module: "Eff_TTEmbedding", indices: torch.Tensor, *tt_cores: torch.Tensor) -> torch.Tensor:
         n = indices.numel()
         dev = indices.device
-        rowidx, offsets = module._iota(n, dev)
+        _, offsets = module._iota(n, dev)
         ctx.module = module
-        ctx.save_for_backward(indices, rowidx)
+        ctx.save_for_backward(indices, offsets)
         out = torch.empty((n, module.embedding_dim), dtype=torch.float32, device=dev)
         ctx.plan = _nat.new_plan(module._shape, n, dev)
-        _nat.forward(module._shape, _nat.core_views(tt_cores), indices, rowidx, offsets, n, None, n, out, module._ws,
+        _nat.forward(module._shape, _nat.core_views(tt_cores), indices, None, offsets, n, None, n, out, module._ws,
                      ctx.plan)
         return out
 
     @staticmethod
     def backward(ctx, grad_output: torch.Tensor):
         m = ctx.module
-        indices, rowidx = ctx.saved_tensors
+        indices, offsets = ctx.saved_tensors
         n = indices.numel()
-        _nat.backward_sgd(m._shape, _nat.core_views(m.tt_cores), indices, rowidx, n, None, n,
-                          grad_output.contiguous().float(), float(m.learning_rate), m._ws, ctx.plan)
+        _nat.backward_sgd(m._shape, _nat.core_views(m.tt_cores), indices, None, n, None, n,
+                          grad_output.contiguous().float(), float(m.learning_rate), m._ws, ctx.plan, offsets)
         return (None, None) + (None,) * len(m.tt_cores)
 
 

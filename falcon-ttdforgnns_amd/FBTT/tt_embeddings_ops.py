@@ -207,7 +207,7 @@ class TTLookupFunction(torch.autograd.Function):
                 *tt_cores: torch.Tensor) -> torch.Tensor:
         ctx.module, ctx.table, ctx.B = module, table, B
         ctx.live_cache = cache_loc is not None
-        ctx.save_for_backward(indices, rowidx, nnz_dev, cache_loc)
+        ctx.save_for_backward(indices, rowidx, nnz_dev, cache_loc, offsets)
         cores = _nat.core_views(tt_cores, table)
         nnz = indices.numel()
         out = torch.empty((B, module.embedding_dim), dtype=torch.float32, device=indices.device)
@@ -221,7 +221,7 @@ class TTLookupFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_output: torch.Tensor):
         m, table, B = ctx.module, ctx.table, ctx.B
-        indices, rowidx, nnz_dev, cache_loc = ctx.saved_tensors
+        indices, rowidx, nnz_dev, cache_loc, offsets = ctx.saved_tensors
         nnz = indices.numel()
         d_output = d_output.contiguous().float()
         cores = _nat.core_views(m.tt_cores, table)
@@ -229,21 +229,22 @@ class TTLookupFunction(torch.autograd.Function):
         if m.sparse:
             if m.optimizer in _SGD_LIKE:
                 _nat.backward_sgd(m._shape, cores, indices, rowidx, nnz, nnz_dev, B, d_output,
-                                  float(m.learning_rate), m._ws, ctx.plan)
+                                  float(m.learning_rate), m._ws, ctx.plan, offsets)
                 if ctx.live_cache and nnz > 0:
                     _nat.cache_backward_sgd(cache_loc, rowidx, 0, nnz_dev, nnz, d_output,
                                             float(m.learning_rate), m.cache_weight.data)
             else:
                 state = _nat.core_views(list(m.optimizer_state), table)
                 _nat.backward_adagrad(m._shape, cores, state, indices, rowidx, nnz, nnz_dev, B, d_output,
-                                      float(m.learning_rate), float(m.eps), m._ws, ctx.plan)
+                                      float(m.learning_rate), float(m.eps), m._ws, ctx.plan, offsets)
                 if ctx.live_cache and nnz > 0:
                     _nat.cache_backward_rowwise_adagrad(cache_loc, rowidx, 0, nnz_dev, nnz, d_output,
                                                         float(m.learning_rate), float(m.eps),
                                                         m.cache_optimizer_state, m.cache_weight.data)
             return (None,) * (n_fixed + len(cores))
         grads = [torch.empty_like(c) for c in cores]
-        _nat.backward_dense(m._shape, cores, indices, rowidx, nnz, nnz_dev, B, d_output, grads, m._ws, ctx.plan)
+        _nat.backward_dense(m._shape, cores, indices, rowidx, nnz, nnz_dev, B, d_output, grads, m._ws, ctx.plan,
+                            offsets)
         d_cache = None
         if ctx.live_cache:
             d_cache = torch.empty_like(m.cache_weight.data)
@@ -389,11 +390,10 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         nnz = indices.numel()
         dev = indices.device
         live = self.use_cache and not self.warmup
-        rowidx = torch.empty(nnz, dtype=torch.int64, device=dev)
-        if not live:
-            _nat.preprocess(indices, offsets, B, True, None, None, None, rowidx, None, None, self._ws)
-            return TTLookupFunction.apply(self, table, B, indices, rowidx, offsets, None, None, None,
+        if not live:  # rows are derived from `offsets` inside the native calls: no separate launch, no tensor
+            return TTLookupFunction.apply(self, table, B, indices, None, offsets, None, None, None,
                                           *self.tt_cores)
+        rowidx = torch.empty(nnz, dtype=torch.int64, device=dev)
         part = torch.empty_like(indices)
         loc = torch.empty(nnz, dtype=torch.int32, device=dev)
         nnz_tt = torch.empty(1, dtype=torch.int32, device=dev)

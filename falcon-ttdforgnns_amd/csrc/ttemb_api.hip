@@ -202,6 +202,25 @@ static int check_lookup_args(const void* cores, const void* indices, int64_t nnz
   return TTEMB_OK;
 }
 
+// rows of the ids: the caller's rowidx, or (rowidx == NULL) derived from offsets into the head
+// of the workspace; *ws / *ws_bytes are advanced past the part used
+static int resolve_rowidx(const int64_t** rowidx, const int64_t* offsets, int64_t nnz, int64_t B, char** ws,
+                          int64_t* ws_bytes, hipStream_t st) {
+  const int64_t need = align256(nnz * 8);
+  char* base = *ws;
+  if (base != nullptr && *ws_bytes >= need) {
+    *ws = base + need;
+    *ws_bytes -= need;
+  } else if (*rowidx == nullptr && nnz > 0) {
+    return fail(TTEMB_E_WORKSPACE, "workspace too small for the row index (%lld bytes)", (long long)need);
+  }
+  if (*rowidx != nullptr || nnz == 0) return TTEMB_OK;
+  if (offsets == nullptr) return fail(TTEMB_E_BADARG, "rowidx and offsets are both null");
+  int rc = launch_rowidx(offsets, B, nnz, reinterpret_cast<int64_t*>(base), st);
+  *rowidx = reinterpret_cast<const int64_t*>(base);
+  return rc;
+}
+
 // shared body of the three backward entry points: gradient of the live ids into `dst`
 static int backward_into(const DevShape& ds, const CorePtrs& cp, const int64_t* indices,
                          const int64_t* rowidx, int64_t nnz, const int32_t* nnz_dev,
@@ -256,9 +275,9 @@ int64_t ttemb_workspace_bytes(const ttemb_shape_t* shape, int32_t op, int64_t nn
   const bool f3 = use_fast3(ds, op == TTEMB_OP_CACHE_POPULATE ? B : nnz);
   switch (op) {
     case TTEMB_OP_FORWARD:
-      return f3 ? fast3_workspace_bytes(ds, op, nnz, B) : 0;
+      return align256(nnz * 8) + (f3 ? fast3_workspace_bytes(ds, op, nnz, B) : 0);
     case TTEMB_OP_BACKWARD:
-      return grad_scratch_bytes(ds) + (f3 ? fast3_workspace_bytes(ds, op, nnz, B) : 0);
+      return grad_scratch_bytes(ds) + align256(nnz * 8) + (f3 ? fast3_workspace_bytes(ds, op, nnz, B) : 0);
     case TTEMB_OP_CACHE_POPULATE: {
       const int64_t sort = populate_workspace_bytes(nnz);
       if (sort < 0) return fail(TTEMB_E_HIP, "rocprim size query failed");
@@ -288,8 +307,12 @@ int ttemb_forward(const ttemb_shape_t* shape, const float* const* cores, const i
   if (rc) return rc;
   if (B == 0) return TTEMB_OK;
   if (output == nullptr) return fail(TTEMB_E_BADARG, "output is null");
-  if (nnz > 0 && rowidx == nullptr) return fail(TTEMB_E_BADARG, "rowidx is null");
+  if (B >= 0x7fffffffll) return fail(TTEMB_E_BADARG, "B exceeds int32 range");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  char* ws = reinterpret_cast<char*>(workspace);
+  rc = resolve_rowidx(&rowidx, offsets, nnz, B, &ws, &workspace_bytes, st);
+  if (rc) return rc;
+  workspace = ws;
   if (offsets != nullptr && nnz_dev == nullptr && nnz > 0) {
     const int threads = 256;
     hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)((B + threads - 1) / threads)), dim3(threads), 0,
@@ -309,7 +332,7 @@ int ttemb_forward(const ttemb_shape_t* shape, const float* const* cores, const i
 }
 
 int ttemb_backward_dense(const ttemb_shape_t* shape, const float* const* cores,
-                         const int64_t* indices, const int64_t* rowidx, int64_t nnz,
+                         const int64_t* indices, const int64_t* rowidx, const int64_t* offsets, int64_t nnz,
                          const int32_t* nnz_dev, int64_t B, const float* d_output,
                          float* const* d_cores, void* workspace, int64_t workspace_bytes,
                          const void* plan, int64_t plan_bytes, void* stream) {
@@ -319,7 +342,7 @@ int ttemb_backward_dense(const ttemb_shape_t* shape, const float* const* cores,
   rc = check_lookup_args(cores, indices, nnz, B);
   if (rc) return rc;
   if (d_cores == nullptr) return fail(TTEMB_E_BADARG, "d_cores is null");
-  if (nnz > 0 && (rowidx == nullptr || d_output == nullptr)) return fail(TTEMB_E_BADARG, "rowidx/d_output is null");
+  if (nnz > 0 && d_output == nullptr) return fail(TTEMB_E_BADARG, "d_output is null");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   CorePtrs cp;
   CorePtrsMut dp;
@@ -330,13 +353,15 @@ int ttemb_backward_dense(const ttemb_shape_t* shape, const float* const* cores,
   // the gradient scratch region at the head of the workspace is unused in dense mode
   const int64_t skip = grad_scratch_bytes(ds);
   char* ws = reinterpret_cast<char*>(workspace);
-  const int64_t rest = workspace_bytes > skip ? workspace_bytes - skip : 0;
-  return backward_into(ds, cp, indices, rowidx, nnz, nnz_dev, d_output, dp, ws ? ws + skip : nullptr, rest, plan,
-                       plan_bytes, st);
+  int64_t rest = workspace_bytes > skip ? workspace_bytes - skip : 0;
+  ws = ws ? ws + skip : nullptr;
+  rc = resolve_rowidx(&rowidx, offsets, nnz, B, &ws, &rest, st);
+  if (rc) return rc;
+  return backward_into(ds, cp, indices, rowidx, nnz, nnz_dev, d_output, dp, ws, rest, plan, plan_bytes, st);
 }
 
 static int fused_backward(const ttemb_shape_t* shape, float* const* cores, float* const* opt_state,
-                          const int64_t* indices, const int64_t* rowidx, int64_t nnz,
+                          const int64_t* indices, const int64_t* rowidx, const int64_t* offsets, int64_t nnz,
                           const int32_t* nnz_dev, int64_t B, const float* d_output, float lr, float eps,
                           void* workspace, int64_t workspace_bytes, const void* plan, int64_t plan_bytes,
                           void* stream) {
@@ -346,7 +371,7 @@ static int fused_backward(const ttemb_shape_t* shape, float* const* cores, float
   rc = check_lookup_args(cores, indices, nnz, B);
   if (rc) return rc;
   if (nnz == 0) return TTEMB_OK;  // zero gradient: SGD is a no-op, Adagrad adds 0 and divides 0
-  if (rowidx == nullptr || d_output == nullptr) return fail(TTEMB_E_BADARG, "rowidx/d_output is null");
+  if (d_output == nullptr) return fail(TTEMB_E_BADARG, "d_output is null");
   const int64_t need = grad_scratch_bytes(ds);
   if (workspace == nullptr || workspace_bytes < need)
     return fail(TTEMB_E_WORKSPACE, "backward needs %lld workspace bytes, got %lld", (long long)need, (long long)workspace_bytes);
@@ -363,8 +388,11 @@ static int fused_backward(const ttemb_shape_t* shape, float* const* cores, float
       off += align256((int64_t)ds.p[t] * ds.row_len[t] * 4);
     }
   }
-  rc = backward_into(ds, cp, indices, rowidx, nnz, nnz_dev, d_output, gp, ws + off, workspace_bytes - off, plan,
-                     plan_bytes, st);
+  char* rest_ws = ws + off;
+  int64_t rest = workspace_bytes - off;
+  rc = resolve_rowidx(&rowidx, offsets, nnz, B, &rest_ws, &rest, st);
+  if (rc) return rc;
+  rc = backward_into(ds, cp, indices, rowidx, nnz, nnz_dev, d_output, gp, rest_ws, rest, plan, plan_bytes, st);
   if (rc) return rc;
   Seg3 seg;
   memset(&seg, 0, sizeof(seg));
@@ -387,20 +415,20 @@ static int fused_backward(const ttemb_shape_t* shape, float* const* cores, float
 }
 
 int ttemb_backward_sgd(const ttemb_shape_t* shape, float* const* cores, const int64_t* indices,
-                       const int64_t* rowidx, int64_t nnz, const int32_t* nnz_dev, int64_t B,
+                       const int64_t* rowidx, const int64_t* offsets, int64_t nnz, const int32_t* nnz_dev, int64_t B,
                        const float* d_output, float lr, void* workspace, int64_t workspace_bytes,
                        const void* plan, int64_t plan_bytes, void* stream) {
-  return fused_backward(shape, cores, nullptr, indices, rowidx, nnz, nnz_dev, B, d_output, lr, 0.f,
+  return fused_backward(shape, cores, nullptr, indices, rowidx, offsets, nnz, nnz_dev, B, d_output, lr, 0.f,
                         workspace, workspace_bytes, plan, plan_bytes, stream);
 }
 
 int ttemb_backward_adagrad(const ttemb_shape_t* shape, float* const* cores, float* const* opt_state,
-                           const int64_t* indices, const int64_t* rowidx, int64_t nnz,
+                           const int64_t* indices, const int64_t* rowidx, const int64_t* offsets, int64_t nnz,
                            const int32_t* nnz_dev, int64_t B, const float* d_output, float lr,
                            float eps, void* workspace, int64_t workspace_bytes, const void* plan,
                            int64_t plan_bytes, void* stream) {
   if (opt_state == nullptr) return fail(TTEMB_E_BADARG, "opt_state is null");
-  return fused_backward(shape, cores, opt_state, indices, rowidx, nnz, nnz_dev, B, d_output, lr, eps,
+  return fused_backward(shape, cores, opt_state, indices, rowidx, offsets, nnz, nnz_dev, B, d_output, lr, eps,
                         workspace, workspace_bytes, plan, plan_bytes, stream);
 }
 

@@ -76,9 +76,9 @@ def _load() -> ctypes.CDLL:
     lib.ttemb_plan_bytes.restype = i64
     lib.ttemb_plan_bytes.argtypes = [shp, i64]
     lib.ttemb_forward.argtypes = [shp, vp, vp, vp, vp, i64, vp, i64, vp, vp, i64, vp, i64, vp]
-    lib.ttemb_backward_dense.argtypes = [shp, vp, vp, vp, i64, vp, i64, vp, vp, vp, i64, vp, i64, vp]
-    lib.ttemb_backward_sgd.argtypes = [shp, vp, vp, vp, i64, vp, i64, vp, f32, vp, i64, vp, i64, vp]
-    lib.ttemb_backward_adagrad.argtypes = [shp, vp, vp, vp, vp, i64, vp, i64, vp, f32, f32, vp, i64, vp, i64, vp]
+    lib.ttemb_backward_dense.argtypes = [shp, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, i64, vp, i64, vp]
+    lib.ttemb_backward_sgd.argtypes = [shp, vp, vp, vp, vp, i64, vp, i64, vp, f32, vp, i64, vp, i64, vp]
+    lib.ttemb_backward_adagrad.argtypes = [shp, vp, vp, vp, vp, vp, i64, vp, i64, vp, f32, f32, vp, i64, vp, i64, vp]
     lib.ttemb_sgd_step.argtypes = [vp, vp, i64, f32, vp]
     lib.ttemb_adagrad_step.argtypes = [vp, vp, vp, i64, f32, f32, vp]
     lib.ttemb_cache_update.argtypes = [vp, i64, vp, vp, i64, vp]
@@ -124,8 +124,29 @@ def _ptr_array(ts: Sequence[torch.Tensor]):
     return arr
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(ref: torch.Tensor) -> int:
+    """Raw hipStream_t of torch's current stream on the tensor's device."""
+    if _raw_stream is not None:
+        return _raw_stream(ref.device.index)
     return torch.cuda.current_stream(ref.device).cuda_stream
+
+
+class _on_device:
+    """`with torch.cuda.device(dev)` only when dev is not already current (the common case costs ~0)."""
+
+    def __init__(self, dev: torch.device) -> None:
+        self.ctx = None if dev.index == torch.cuda.current_device() else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
 
 
 class Workspace:
@@ -185,7 +206,7 @@ def forward(shape: Shape, cores: Sequence[torch.Tensor], indices: torch.Tensor, 
             output: torch.Tensor, ws: Workspace, plan: Optional[torch.Tensor] = None) -> None:
     dev = output.device
     w = ws.get(workspace_bytes(shape, OP_FORWARD, nnz, B), dev)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         _check(LIB.ttemb_forward(ctypes.byref(shape), _ptr_array(cores), _ptr(indices), _ptr(rowidx),
                                  _ptr(offsets), nnz, _ptr(nnz_dev), B, _ptr(output), _ptr(w), w.numel(),
                                  *_plan_args(plan), _stream(output)))
@@ -193,42 +214,45 @@ def forward(shape: Shape, cores: Sequence[torch.Tensor], indices: torch.Tensor, 
 
 def backward_dense(shape: Shape, cores: Sequence[torch.Tensor], indices, rowidx, nnz: int, nnz_dev, B: int,
                    d_output: torch.Tensor, d_cores: Sequence[torch.Tensor], ws: Workspace,
-                   plan: Optional[torch.Tensor] = None) -> None:
+                   plan: Optional[torch.Tensor] = None, offsets: Optional[torch.Tensor] = None) -> None:
     dev = d_output.device
     w = ws.get(workspace_bytes(shape, OP_BACKWARD, nnz, B), dev)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         _check(LIB.ttemb_backward_dense(ctypes.byref(shape), _ptr_array(cores), _ptr(indices), _ptr(rowidx),
-                                        nnz, _ptr(nnz_dev), B, _ptr(d_output), _ptr_array(d_cores), _ptr(w),
+                                        _ptr(offsets), nnz, _ptr(nnz_dev), B, _ptr(d_output), _ptr_array(d_cores), _ptr(w),
                                         w.numel(), *_plan_args(plan), _stream(d_output)))
 
 
 def backward_sgd(shape: Shape, cores, indices, rowidx, nnz: int, nnz_dev, B: int, d_output, lr: float,
-                 ws: Workspace, plan: Optional[torch.Tensor] = None) -> None:
+                 ws: Workspace, plan: Optional[torch.Tensor] = None, offsets: Optional[torch.Tensor] = None) -> None:
     dev = d_output.device
     w = ws.get(workspace_bytes(shape, OP_BACKWARD, nnz, B), dev)
-    with torch.cuda.device(dev):
-        _check(LIB.ttemb_backward_sgd(ctypes.byref(shape), _ptr_array(cores), _ptr(indices), _ptr(rowidx), nnz,
+    with _on_device(dev):
+        _check(LIB.ttemb_backward_sgd(ctypes.byref(shape), _ptr_array(cores), _ptr(indices), _ptr(rowidx),
+                                      _ptr(offsets), nnz,
                                       _ptr(nnz_dev), B, _ptr(d_output), lr, _ptr(w), w.numel(),
                                       *_plan_args(plan), _stream(d_output)))
 
 
 def backward_adagrad(shape: Shape, cores, opt_state, indices, rowidx, nnz: int, nnz_dev, B: int, d_output,
-                     lr: float, eps: float, ws: Workspace, plan: Optional[torch.Tensor] = None) -> None:
+                     lr: float, eps: float, ws: Workspace, plan: Optional[torch.Tensor] = None,
+                     offsets: Optional[torch.Tensor] = None) -> None:
     dev = d_output.device
     w = ws.get(workspace_bytes(shape, OP_BACKWARD, nnz, B), dev)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         _check(LIB.ttemb_backward_adagrad(ctypes.byref(shape), _ptr_array(cores), _ptr_array(opt_state),
-                                          _ptr(indices), _ptr(rowidx), nnz, _ptr(nnz_dev), B, _ptr(d_output),
+                                          _ptr(indices), _ptr(rowidx), _ptr(offsets), nnz, _ptr(nnz_dev), B,
+                                          _ptr(d_output),
                                           lr, eps, _ptr(w), w.numel(), *_plan_args(plan), _stream(d_output)))
 
 
 def sgd_step(weights: torch.Tensor, grads: torch.Tensor, lr: float) -> None:
-    with torch.cuda.device(weights.device):
+    with _on_device(weights.device):
         _check(LIB.ttemb_sgd_step(_ptr(weights), _ptr(grads), weights.numel(), lr, _stream(weights)))
 
 
 def adagrad_step(weights, state, grads, lr: float, eps: float) -> None:
-    with torch.cuda.device(weights.device):
+    with _on_device(weights.device):
         _check(LIB.ttemb_adagrad_step(_ptr(weights), _ptr(state), _ptr(grads), weights.numel(), lr, eps,
                                       _stream(weights)))
 
@@ -236,7 +260,7 @@ def adagrad_step(weights, state, grads, lr: float, eps: float) -> None:
 def cache_update(indices: torch.Tensor, hashtbl: torch.Tensor, cache_freq: torch.Tensor) -> None:
     if indices.numel() == 0:
         return
-    with torch.cuda.device(indices.device):
+    with _on_device(indices.device):
         _check(LIB.ttemb_cache_update(_ptr(indices), indices.numel(), _ptr(hashtbl), _ptr(cache_freq),
                                       hashtbl.numel(), _stream(indices)))
 
@@ -245,7 +269,7 @@ def cache_populate(shape: Shape, cores, hashtbl, cache_freq, cache_state, cache_
     dev = hashtbl.device
     H, C = hashtbl.numel(), cache_weight.shape[0]
     w = ws.get(workspace_bytes(shape, OP_CACHE_POPULATE, H, C), dev)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         _check(LIB.ttemb_cache_populate(ctypes.byref(shape), _ptr_array(cores), _ptr(hashtbl), _ptr(cache_freq),
                                         _ptr(cache_state), H, _ptr(cache_weight), C, _ptr(w), w.numel(),
                                         _stream(hashtbl)))
@@ -258,7 +282,7 @@ def preprocess(indices, offsets, B: int, warmup: bool, hashtbl, cache_state, ind
     H = 0 if hashtbl is None else hashtbl.numel()
     need = 0 if (warmup or H == 0) else workspace_bytes(None, OP_PREPROCESS, nnz, B)
     w = ws.get(need, dev)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         _check(LIB.ttemb_preprocess(_ptr(indices), _ptr(offsets), nnz, B, 1 if warmup else 0, _ptr(hashtbl),
                                     _ptr(cache_state), H, _ptr(indices_out), _ptr(rowidx_out),
                                     _ptr(cache_loc_out), _ptr(nnz_tt_dev), _ptr(w), w.numel(),
@@ -266,7 +290,7 @@ def preprocess(indices, offsets, B: int, warmup: bool, hashtbl, cache_state, ind
 
 
 def cache_forward(cache_loc, rowidx, start: int, start_dev, nnz: int, cache_weight, output) -> None:
-    with torch.cuda.device(output.device):
+    with _on_device(output.device):
         _check(LIB.ttemb_cache_forward(_ptr(cache_loc), _ptr(rowidx), start, _ptr(start_dev), nnz,
                                        _ptr(cache_weight), cache_weight.shape[1], _ptr(output),
                                        _stream(output)))
@@ -274,7 +298,7 @@ def cache_forward(cache_loc, rowidx, start: int, start_dev, nnz: int, cache_weig
 
 def cache_backward_sgd(cache_loc, rowidx, start: int, start_dev, nnz: int, d_output, lr: float,
                        cache_weight) -> None:
-    with torch.cuda.device(d_output.device):
+    with _on_device(d_output.device):
         _check(LIB.ttemb_cache_backward_sgd(_ptr(cache_loc), _ptr(rowidx), start, _ptr(start_dev), nnz,
                                             _ptr(d_output), cache_weight.shape[1], lr, _ptr(cache_weight),
                                             _stream(d_output)))
@@ -282,7 +306,7 @@ def cache_backward_sgd(cache_loc, rowidx, start: int, start_dev, nnz: int, d_out
 
 def cache_backward_dense(cache_loc, rowidx, start: int, start_dev, nnz: int, d_output,
                          d_cache_weight) -> None:
-    with torch.cuda.device(d_output.device):
+    with _on_device(d_output.device):
         _check(LIB.ttemb_cache_backward_dense(_ptr(cache_loc), _ptr(rowidx), start, _ptr(start_dev), nnz,
                                               _ptr(d_output), d_cache_weight.shape[1],
                                               d_cache_weight.shape[0], _ptr(d_cache_weight),
@@ -291,7 +315,7 @@ def cache_backward_dense(cache_loc, rowidx, start: int, start_dev, nnz: int, d_o
 
 def cache_backward_rowwise_adagrad(cache_loc, rowidx, start: int, start_dev, nnz: int, d_output, lr: float,
                                    eps: float, state_sum, cache_weight) -> None:
-    with torch.cuda.device(d_output.device):
+    with _on_device(d_output.device):
         _check(LIB.ttemb_cache_backward_rowwise_adagrad(_ptr(cache_loc), _ptr(rowidx), start, _ptr(start_dev),
                                                         nnz, _ptr(d_output), cache_weight.shape[1], lr, eps,
                                                         _ptr(state_sum), _ptr(cache_weight),

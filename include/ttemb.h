@@ -15,7 +15,10 @@
  *   - ids are int64, decomposed with L = [p1*p2.., .., 1] by repeated div/mod
  *     (FBTT/tt_embeddings_cuda.cu:796-802);
  *   - `rowidx[n]` is the bag (output row) of position n, non-decreasing inside the
- *     TT part and inside the cached part (what preprocess produces);
+ *     TT part and inside the cached part (what preprocess produces).  Where a function
+ *     takes both `rowidx` and `offsets`, rowidx may be NULL when offsets (int64[B+1]) is
+ *     given and the ids are exactly the concatenated bags: the rows are then derived
+ *     from offsets inside the call (no separate ttemb_preprocess launch needed);
  *   - return value: 0 = ok, <0 = error (TTEMB_E_*), text via ttemb_last_error().
  */
 #ifndef TTEMB_H_
@@ -109,7 +112,7 @@ int ttemb_forward(const ttemb_shape_t* shape, const float* const* cores,
  * overwritten with the gradient of sum(output * d_output) w.r.t. cores[t].
  * ------------------------------------------------------------------------------- */
 int ttemb_backward_dense(const ttemb_shape_t* shape, const float* const* cores,
-                         const int64_t* indices, const int64_t* rowidx, int64_t nnz,
+                         const int64_t* indices, const int64_t* rowidx, const int64_t* offsets, int64_t nnz,
                          const int32_t* nnz_dev, int64_t B, const float* d_output,
                          float* const* d_cores,
                          void* workspace, int64_t workspace_bytes, const void* plan, int64_t plan_bytes,
@@ -119,7 +122,7 @@ int ttemb_backward_dense(const ttemb_shape_t* shape, const float* const* cores,
  * cores[t] -= lr * d_core_t, every row (the reference's grid defect at :633-651 is
  * not reproduced).  The gradient lives in the workspace only. */
 int ttemb_backward_sgd(const ttemb_shape_t* shape, float* const* cores,
-                       const int64_t* indices, const int64_t* rowidx, int64_t nnz,
+                       const int64_t* indices, const int64_t* rowidx, const int64_t* offsets, int64_t nnz,
                        const int32_t* nnz_dev, int64_t B, const float* d_output, float lr,
                        void* workspace, int64_t workspace_bytes, const void* plan, int64_t plan_bytes,
                        void* stream);
@@ -128,7 +131,7 @@ int ttemb_backward_sgd(const ttemb_shape_t* shape, float* const* cores,
  * 399-419): state += g*g ; core -= lr * g / (sqrt(state) + eps). */
 int ttemb_backward_adagrad(const ttemb_shape_t* shape, float* const* cores,
                            float* const* opt_state,
-                           const int64_t* indices, const int64_t* rowidx, int64_t nnz,
+                           const int64_t* indices, const int64_t* rowidx, const int64_t* offsets, int64_t nnz,
                            const int32_t* nnz_dev, int64_t B, const float* d_output,
                            float lr, float eps,
                            void* workspace, int64_t workspace_bytes, const void* plan, int64_t plan_bytes,
