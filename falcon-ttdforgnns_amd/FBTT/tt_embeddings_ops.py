@@ -242,7 +242,8 @@ class TTLookupFunction(torch.autograd.Function):
                                                         float(m.learning_rate), float(m.eps),
                                                         m.cache_optimizer_state, m.cache_weight.data)
             return (None,) * (n_fixed + len(cores))
-        grads = [torch.empty_like(c) for c in cores]
+        # a data-parallel wrapper may have provided one flat bucket for the gradients (ttemb_dist)
+        grads = getattr(m, "_dense_grad_out", None) or [torch.empty_like(c) for c in cores]
         _nat.backward_dense(m._shape, cores, indices, rowidx, nnz, nnz_dev, B, d_output, grads, m._ws, ctx.plan,
                             offsets)
         d_cache = None
@@ -341,6 +342,7 @@ class TableBatchedTTEmbeddingBag(nn.Module):
             self.cache_optimizer_state = None
             self.cache_weight = None
         self.warmup = True
+        self._dense_grad_out = None
         self._shape = _nat.make_shape(self.tt_p_shapes, self.tt_q_shapes, self.tt_ranks)
         self._ws = _nat.Workspace()
 

@@ -46,7 +46,14 @@ def default_apply(weight: torch.Tensor, grad: torch.Tensor, lr: float) -> None:
 
 
 class TTDataParallel:
-    """Wrap a dense-mode (``sparse=False``) TT module for data-parallel SGD."""
+    """Wrap a dense-mode (``sparse=False``) TT module for data-parallel SGD.
+
+    The core gradients are produced by the backward kernels directly inside one flat bucket
+    (no packing copy), summed with ONE all-reduce, and applied by ONE fused SGD launch over a
+    flat weight buffer the cores are views of.  If a caller re-points ``tt_cores[t].data``
+    (the reference's initialisers do, gnn_model.py:142-178) the step falls back to per-core
+    launches until ``adopt_parameters()`` is called again.
+    """
 
     def __init__(self, module, process_group: Optional[dist.ProcessGroup] = None,
                  apply_fn: Callable[[torch.Tensor, torch.Tensor, float], None] = default_apply) -> None:
@@ -58,19 +65,51 @@ class TTDataParallel:
         if getattr(module, "cache_weight", None) is not None:
             params.append(module.cache_weight)
         self.bucket = FlatGradBucket(params)
+        self.n_cores = len(module.tt_cores)
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.flat_weights: Optional[torch.Tensor] = None
+        self.weight_views: List[torch.Tensor] = []
+        self.adopt_parameters()
+        # the backward kernels write the core gradients straight into the bucket
+        module._dense_grad_out = [v[0] if v.dim() == 3 and v.shape[0] == 1 else v
+                                  for v in self.bucket.views[: self.n_cores]] if module.num_tables == 1 else None
+
+    def adopt_parameters(self) -> None:
+        """Move the parameters into one flat buffer (same layout as the gradient bucket)."""
+        b = self.bucket
+        self.flat_weights = torch.zeros_like(b.flat)
+        self.weight_views = [self.flat_weights[o:o + n].view_as(p) for o, n, p in zip(b.offsets, b.sizes, b.params)]
+        with torch.no_grad():
+            for v, p in zip(self.weight_views, b.params):
+                v.copy_(p.data)
+                p.data = v
+
+    def _flat_ok(self) -> bool:
+        return all(p.data.data_ptr() == v.data_ptr() for p, v in zip(self.bucket.params, self.weight_views))
 
     def broadcast_parameters(self, src: int = 0) -> None:
         if self.world > 1:
-            for p in self.bucket.params:
-                dist.broadcast(p.data, src, group=self.group)
+            if self._flat_ok():
+                dist.broadcast(self.flat_weights, src, group=self.group)
+            else:
+                for p in self.bucket.params:
+                    dist.broadcast(p.data, src, group=self.group)
 
     def step(self, lr: Optional[float] = None) -> None:
         """Call after ``loss.backward()``: all-reduce(sum) once, then w -= lr/world * g."""
         lr = float(self.module.learning_rate if lr is None else lr)
-        self.bucket.pack()
+        b = self.bucket
+        for v, p in zip(b.views, b.params):  # gradients that did not land in the bucket are packed
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                v.copy_(p.grad)
         if self.world > 1:
-            dist.all_reduce(self.bucket.flat, op=dist.ReduceOp.SUM, group=self.group)
-        for p, g in zip(self.bucket.params, self.bucket.views):
-            self.apply_fn(p.data, g, lr / self.world)
+            dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group)
+        if self._flat_ok():
+            self.apply_fn(self.flat_weights, b.flat, lr / self.world)
+        else:
+            for p, g in zip(b.params, b.views):
+                self.apply_fn(p.data, g, lr / self.world)
+        for p in b.params:
             p.grad = None

@@ -32,6 +32,7 @@ def _worker(rank, world, port, out_dir):
     m = TTEmbeddingBag(1000, 16, [4, 4], [10, 10, 10], [2, 2, 4], sparse=False, use_cache=False,
                        weight_dist="normal", learning_rate=0.5)
     dp = TTDataParallel(m, apply_fn=lambda w, g, lr: w.sub_(lr * g.view_as(w)))
+    assert dp._flat_ok() and all(c.data.data_ptr() == v.data_ptr() for c, v in zip(m.tt_cores, dp.weight_views))
     dp.broadcast_parameters(0)
     start = [c.detach().clone() for c in m.tt_cores]
     g = torch.Generator().manual_seed(7 + rank)
