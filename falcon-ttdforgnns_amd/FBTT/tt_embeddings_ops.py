@@ -215,7 +215,7 @@ class TTLookupFunction(torch.autograd.Function):
         ctx.plan = _nat.new_plan(module._shape, nnz, indices.device)
         _nat.forward(module._shape, cores, indices, rowidx, offsets, nnz, nnz_dev, B, out, module._ws, ctx.plan)
         if ctx.live_cache and nnz > 0:
-            _nat.cache_forward(cache_loc, rowidx, 0, nnz_dev, nnz, cache_weight.data, out)
+            _nat.cache_forward(cache_loc, rowidx, 0, nnz_dev, nnz, cache_weight.data, out, offsets)
         return out
 
     @staticmethod
@@ -401,7 +401,7 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         nnz_tt = torch.empty(1, dtype=torch.int32, device=dev)
         _nat.preprocess(indices, offsets, B, False, self.hashtbl, self.cache_state, part, rowidx, loc, nnz_tt,
                         self._ws)
-        return TTLookupFunction.apply(self, table, B, part, rowidx, None, nnz_tt, loc, self.cache_weight,
+        return TTLookupFunction.apply(self, table, B, part, rowidx, offsets, nnz_tt, loc, self.cache_weight,
                                       *self.tt_cores)
 
     def forward(self, indices: torch.Tensor, offsets: torch.Tensor, warmup: bool = True) -> torch.Tensor:

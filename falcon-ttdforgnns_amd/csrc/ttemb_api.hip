@@ -313,7 +313,7 @@ int ttemb_forward(const ttemb_shape_t* shape, const float* const* cores, const i
   rc = resolve_rowidx(&rowidx, offsets, nnz, B, &ws, &workspace_bytes, st);
   if (rc) return rc;
   workspace = ws;
-  if (offsets != nullptr && nnz_dev == nullptr && nnz > 0) {
+  if (offsets != nullptr) {
     const int threads = 256;
     hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)((B + threads - 1) / threads)), dim3(threads), 0,
                        st, offsets, B, ds.D, output);
@@ -325,10 +325,10 @@ int ttemb_forward(const ttemb_shape_t* shape, const float* const* cores, const i
   CorePtrs cp;
   for (int t = 0; t < TTEMB_MAX_CORES; ++t) cp.c[t] = t < ds.T ? cores[t] : nullptr;
   if (use_fast3(ds, nnz))
-    return launch_forward_fast3(ds, cp, indices, rowidx, nnz, nnz_dev, output, workspace, workspace_bytes, plan,
-                                plan_bytes, st);
+    return launch_forward_fast3(ds, cp, indices, rowidx, offsets, nnz, nnz_dev, output, workspace, workspace_bytes,
+                                plan, plan_bytes, st);
   if (current_path() == TTEMB_PATH_FAST3) return fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
-  return launch_forward_generic(ds, cp, indices, rowidx, nnz, nnz_dev, output, st);
+  return launch_forward_generic(ds, cp, indices, rowidx, offsets, nnz, nnz_dev, output, st);
 }
 
 int ttemb_backward_dense(const ttemb_shape_t* shape, const float* const* cores,
@@ -470,7 +470,7 @@ int ttemb_cache_populate(const ttemb_shape_t* shape, const float* const* cores, 
   CorePtrs cp;
   for (int t = 0; t < TTEMB_MAX_CORES; ++t) cp.c[t] = t < ds.T ? cores[t] : nullptr;
   // rows of the C hottest ids straight into cache_weight (reference: prefetch in chunks of 200)
-  return launch_forward_generic(ds, cp, sorted_keys, nullptr, C, nullptr, cache_weight, st);
+  return launch_forward_generic(ds, cp, sorted_keys, nullptr, nullptr, C, nullptr, cache_weight, st);
 }
 
 int ttemb_preprocess(const int64_t* indices, const int64_t* offsets, int64_t nnz, int64_t B,
@@ -507,13 +507,13 @@ static int check_cache_args(const void* loc, const void* rowidx, int64_t start, 
   return TTEMB_OK;
 }
 
-int ttemb_cache_forward(const int32_t* cache_loc, const int64_t* rowidx, int64_t start,
+int ttemb_cache_forward(const int32_t* cache_loc, const int64_t* rowidx, const int64_t* offsets, int64_t start,
                         const int32_t* start_dev, int64_t nnz, const float* cache_weight, int64_t D,
                         float* output, void* stream) {
   int rc = check_cache_args(cache_loc, rowidx, start, nnz, D);
   if (rc) return rc;
   if (nnz > 0 && (!cache_weight || !output)) return fail(TTEMB_E_BADARG, "null buffer");
-  return launch_cache_forward(cache_loc, rowidx, start, start_dev, nnz, cache_weight, D, output,
+  return launch_cache_forward(cache_loc, rowidx, offsets, start, start_dev, nnz, cache_weight, D, output,
                               reinterpret_cast<hipStream_t>(stream));
 }
 

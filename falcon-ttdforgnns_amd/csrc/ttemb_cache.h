@@ -18,7 +18,7 @@ int launch_partition(const int64_t* indices, const int64_t* offsets, int64_t nnz
                      const int64_t* hashtbl, const int32_t* state, int64_t H, int64_t* indices_out,
                      int64_t* rowidx_out, int32_t* loc_out, int32_t* nnz_tt_dev, void* ws,
                      int64_t ws_bytes, hipStream_t st);
-int launch_cache_forward(const int32_t* loc, const int64_t* rowidx, int64_t start,
+int launch_cache_forward(const int32_t* loc, const int64_t* rowidx, const int64_t* offsets, int64_t start,
                          const int32_t* start_dev, int64_t nnz, const float* weight, int64_t D,
                          float* out, hipStream_t st);
 int launch_cache_scatter_add(const int32_t* loc, const int64_t* rowidx, int64_t start,

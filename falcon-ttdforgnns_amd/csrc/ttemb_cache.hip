@@ -67,8 +67,12 @@ __global__ void cache_update_kernel(const int64_t* __restrict__ indices, int64_t
   const int64_t key = indices[n];
   uint32_t s = hash_slot(key, H);
   for (int probe = 0; probe < kMaxProbes; ++probe) {
-    const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[s]),
-                                             (unsigned long long)kEmptyKey, (unsigned long long)key);
+    // a slot never changes once it holds a real key (until populate evicts), so a plain read that
+    // already sees `key` makes the CAS unnecessary: one atomic request per id instead of two
+    unsigned long long old = (unsigned long long)__builtin_nontemporal_load(&keys[s]);
+    if (old != (unsigned long long)key)
+      old = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[s]), (unsigned long long)kEmptyKey,
+                      (unsigned long long)key);
     if (old == (unsigned long long)kEmptyKey || old == (unsigned long long)key) {
       atomicAdd(reinterpret_cast<unsigned long long*>(&freq[s]), 1ull);
       return;
@@ -266,36 +270,57 @@ __device__ __forceinline__ int64_t live_start(int64_t start, const int32_t* star
   return start > nnz ? nnz : start;
 }
 
+// One wavefront walks kIdsPerWave cached ids; per id lanes 0..D/4-1 move one float4 each.
+// single-id bags: plain store when the caller vouches (offsets) that no TT id shares the row,
+// read-modify-write when only the cached part is known to be alone in it; else float atomics.
+constexpr int kIdsPerWave = 8;
+
 __global__ __launch_bounds__(256) void cache_forward_kernel(const int32_t* __restrict__ loc,
                                                             const int64_t* __restrict__ rowidx,
+                                                            const int64_t* __restrict__ offsets,
                                                             int64_t start, const int32_t* start_dev,
                                                             int64_t nnz,
                                                             const float* __restrict__ weight, int D,
                                                             float* __restrict__ out) {
   const int64_t s0 = live_start(start, start_dev, nnz);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t n = s0 + (int64_t)blockIdx.x * 4 + wave;
-  if (n >= nnz) return;
-  const int64_t row = rowidx[n];
-  const bool single = (n == s0 || rowidx[n - 1] != row) && (n + 1 >= nnz || rowidx[n + 1] != row);
-  const float4* w = reinterpret_cast<const float4*>(weight + (int64_t)loc[n] * D);
-  float* o = out + row * D;
-  for (int c = lane; c * 4 < D; c += kWave) {
-    const float4 v = w[c];
-    if (single) {
-      float4 cur = reinterpret_cast<float4*>(o)[c];
-      cur.x += v.x; cur.y += v.y; cur.z += v.z; cur.w += v.w;
-      reinterpret_cast<float4*>(o)[c] = cur;
+  const int64_t first = s0 + ((int64_t)blockIdx.x * 4 + wave) * kIdsPerWave;
+  const int D4 = D >> 2;
+#pragma unroll 2
+  for (int k = 0; k < kIdsPerWave; ++k) {
+    const int64_t n = first + k;
+    if (n >= nnz) return;
+    const int64_t row = rowidx[n];
+    bool alone, store_only = false;
+    if (offsets != nullptr) {
+      alone = offsets[row + 1] - offsets[row] == 1;
+      store_only = alone;
     } else {
-      atomicAdd(&o[4 * c + 0], v.x);
-      atomicAdd(&o[4 * c + 1], v.y);
-      atomicAdd(&o[4 * c + 2], v.z);
-      atomicAdd(&o[4 * c + 3], v.w);
+      alone = (n == s0 || rowidx[n - 1] != row) && (n + 1 >= nnz || rowidx[n + 1] != row);
+    }
+    const float4* w = reinterpret_cast<const float4*>(weight + (int64_t)loc[n] * D);
+    float* o = out + row * D;
+    for (int c = lane; c < D4; c += kWave) {
+      const float4 v = w[c];
+      if (store_only) {
+        reinterpret_cast<float4*>(o)[c] = v;
+      } else if (alone) {
+        float4 cur = reinterpret_cast<float4*>(o)[c];
+        cur.x += v.x; cur.y += v.y; cur.z += v.z; cur.w += v.w;
+        reinterpret_cast<float4*>(o)[c] = cur;
+      } else {
+        atomicAdd(&o[4 * c + 0], v.x);
+        atomicAdd(&o[4 * c + 1], v.y);
+        atomicAdd(&o[4 * c + 2], v.z);
+        atomicAdd(&o[4 * c + 3], v.w);
+      }
     }
   }
 }
 
-// scale == -lr : cache_backward_sgd ; scale == 1 : cache_backward_dense (target pre-zeroed)
+// scale == -lr : cache_backward_sgd ; scale == 1 : cache_backward_dense (target pre-zeroed).
+// Duplicate ids may hit one cache row, so the adds are float atomics -- issued as whole rows of
+// consecutive floats (64 lanes = 256 contiguous bytes per instruction, the full-rate shape).
 __global__ __launch_bounds__(256) void cache_scatter_add_kernel(const int32_t* __restrict__ loc,
                                                                 const int64_t* __restrict__ rowidx,
                                                                 int64_t start, const int32_t* start_dev,
@@ -304,16 +329,14 @@ __global__ __launch_bounds__(256) void cache_scatter_add_kernel(const int32_t* _
                                                                 float scale, float* __restrict__ target) {
   const int64_t s0 = live_start(start, start_dev, nnz);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t n = s0 + (int64_t)blockIdx.x * 4 + wave;
-  if (n >= nnz) return;
-  const float4* g = reinterpret_cast<const float4*>(grad + rowidx[n] * D);
-  float* t = target + (int64_t)loc[n] * D;
-  for (int c = lane; c * 4 < D; c += kWave) {
-    const float4 v = g[c];
-    atomicAdd(&t[4 * c + 0], v.x * scale);
-    atomicAdd(&t[4 * c + 1], v.y * scale);
-    atomicAdd(&t[4 * c + 2], v.z * scale);
-    atomicAdd(&t[4 * c + 3], v.w * scale);
+  const int64_t first = s0 + ((int64_t)blockIdx.x * 4 + wave) * kIdsPerWave;
+#pragma unroll 2
+  for (int k = 0; k < kIdsPerWave; ++k) {
+    const int64_t n = first + k;
+    if (n >= nnz) return;
+    const float* g = grad + rowidx[n] * D;
+    float* t = target + (int64_t)loc[n] * D;
+    for (int e = lane; e < D; e += kWave) atomicAdd(&t[e], g[e] * scale);
   }
 }
 
@@ -351,14 +374,15 @@ __global__ __launch_bounds__(256) void cache_rowwise_adagrad_kernel(
 }
 
 static inline unsigned wave_blocks(int64_t nnz) { return (unsigned)((nnz + 3) / 4); }
+static inline unsigned multi_blocks(int64_t nnz) { return (unsigned)((nnz + 4 * kIdsPerWave - 1) / (4 * kIdsPerWave)); }
 
-int launch_cache_forward(const int32_t* loc, const int64_t* rowidx, int64_t start,
+int launch_cache_forward(const int32_t* loc, const int64_t* rowidx, const int64_t* offsets, int64_t start,
                          const int32_t* start_dev, int64_t nnz, const float* weight, int64_t D,
                          float* out, hipStream_t st) {
   const int64_t span = start_dev ? nnz : nnz - start;
   if (span <= 0) return TTEMB_OK;
-  hipLaunchKernelGGL(cache_forward_kernel, dim3(wave_blocks(span)), dim3(256), 0, st, loc, rowidx, start,
-                     start_dev, nnz, weight, (int)D, out);
+  hipLaunchKernelGGL(cache_forward_kernel, dim3(multi_blocks(span)), dim3(256), 0, st, loc, rowidx, offsets,
+                     start, start_dev, nnz, weight, (int)D, out);
   return check_hip(hipGetLastError(), "cache_forward_kernel");
 }
 
@@ -367,7 +391,7 @@ int launch_cache_scatter_add(const int32_t* loc, const int64_t* rowidx, int64_t 
                              float scale, float* target, hipStream_t st) {
   const int64_t span = start_dev ? nnz : nnz - start;
   if (span <= 0) return TTEMB_OK;
-  hipLaunchKernelGGL(cache_scatter_add_kernel, dim3(wave_blocks(span)), dim3(256), 0, st, loc, rowidx,
+  hipLaunchKernelGGL(cache_scatter_add_kernel, dim3(multi_blocks(span)), dim3(256), 0, st, loc, rowidx,
                      start, start_dev, nnz, grad, (int)D, scale, target);
   return check_hip(hipGetLastError(), "cache_scatter_add_kernel");
 }

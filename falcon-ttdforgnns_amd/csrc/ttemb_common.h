@@ -45,8 +45,8 @@ void profile_end(int which, hipStream_t st);
 int64_t generic_fwd_lds_bytes(const DevShape& s);
 int64_t generic_bwd_lds_bytes(const DevShape& s);
 int launch_forward_generic(const DevShape& s, const CorePtrs& cores, const int64_t* indices,
-                           const int64_t* rowidx, int64_t nnz, const int32_t* nnz_dev,
-                           float* output, hipStream_t st);
+                           const int64_t* rowidx, const int64_t* offsets, int64_t nnz,
+                           const int32_t* nnz_dev, float* output, hipStream_t st);
 int launch_backward_generic(const DevShape& s, const CorePtrs& cores, const int64_t* indices,
                             const int64_t* rowidx, int64_t nnz, const int32_t* nnz_dev,
                             const float* d_output, const CorePtrsMut& d_cores, hipStream_t st);
@@ -57,9 +57,9 @@ bool fast3_pays(const DevShape& s, int64_t nnz);  // enough ids per group for th
 int64_t fast3_workspace_bytes(const DevShape& s, int32_t op, int64_t nnz, int64_t B);
 int64_t fast3_plan_bytes(const DevShape& s, int64_t nnz);
 int launch_forward_fast3(const DevShape& s, const CorePtrs& cores, const int64_t* indices,
-                         const int64_t* rowidx, int64_t nnz, const int32_t* nnz_dev,
-                         float* output, void* ws, int64_t ws_bytes, void* plan, int64_t plan_bytes,
-                         hipStream_t st);
+                         const int64_t* rowidx, const int64_t* offsets, int64_t nnz,
+                         const int32_t* nnz_dev, float* output, void* ws, int64_t ws_bytes, void* plan,
+                         int64_t plan_bytes, hipStream_t st);
 int launch_backward_fast3(const DevShape& s, const CorePtrs& cores, const int64_t* indices,
                           const int64_t* rowidx, int64_t nnz, const int32_t* nnz_dev,
                           const float* d_output, const CorePtrsMut& d_cores, void* ws,
@@ -68,6 +68,15 @@ int launch_backward_fast3(const DevShape& s, const CorePtrs& cores, const int64_
 // ---------------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------------
+// does the bag of position n hold exactly one id?  With `offsets` the answer comes from the bag
+// lengths of the original id list; otherwise from the neighbouring rows of the live range.
+__device__ __forceinline__ bool bag_is_single(const int64_t* __restrict__ rowidx,
+                                              const int64_t* __restrict__ offsets, int64_t n, int64_t cnt,
+                                              int64_t row) {
+  if (offsets != nullptr) return offsets[row + 1] - offsets[row] == 1;
+  return (n == 0 || rowidx[n - 1] != row) && (n + 1 >= cnt || rowidx[n + 1] != row);
+}
+
 __device__ __forceinline__ int64_t live_count(int64_t nnz, const int32_t* nnz_dev) {
   if (nnz_dev == nullptr) return nnz;
   int64_t c = *nnz_dev;

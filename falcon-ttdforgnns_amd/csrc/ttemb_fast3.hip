@@ -104,7 +104,8 @@ struct GroupPlan {           // device pointers into the caller's workspace
 };
 
 __global__ __launch_bounds__(kTile) void fast3_prep_kernel(
-    const int64_t* __restrict__ indices, const int64_t* __restrict__ rowidx, int64_t nnz,
+    const int64_t* __restrict__ indices, const int64_t* __restrict__ rowidx,
+    const int64_t* __restrict__ offsets, int64_t nnz,
     const int32_t* __restrict__ nnz_dev, uint32_t sentinel, uint32_t p0, uint32_t p1, uint32_t p2,
     GroupPlan plan) {
   const int64_t n = (int64_t)blockIdx.x * kTile + threadIdx.x;
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(kTile) void fast3_prep_kernel(
   int64_t id = indices[n];
   id = id < 0 ? 0 : (id >= (int64_t)sentinel ? (int64_t)sentinel - 1 : id);
   const int64_t row = rowidx[n];
-  const bool multi = (n > 0 && rowidx[n - 1] == row) || (n + 1 < cnt && rowidx[n + 1] == row);
+  const bool multi = !bag_is_single(rowidx, offsets, n, cnt, row);
   const uint32_t u = (uint32_t)id;
   const uint32_t i0 = u / (p1 * p2);
   const uint32_t rem = u - i0 * (p1 * p2);
@@ -950,8 +951,8 @@ int64_t fast3_workspace_bytes(const DevShape& s, int32_t op, int64_t nnz, int64_
 }
 
 // fill plan->{keys, vals, counts, gstart} from the ids
-static int group_ids(const DevShape& s, const int64_t* indices, const int64_t* rowidx, int64_t nnz,
-                     const int32_t* nnz_dev, GroupPlan* plan, char* scan_tmp, hipStream_t st) {
+static int group_ids(const DevShape& s, const int64_t* indices, const int64_t* rowidx, const int64_t* offsets,
+                     int64_t nnz, const int32_t* nnz_dev, GroupPlan* plan, char* scan_tmp, hipStream_t st) {
   const int64_t G = num_groups(s);
   size_t tmp_bytes = 0;
   uint32_t* nul = nullptr;
@@ -962,7 +963,7 @@ static int group_ids(const DevShape& s, const int64_t* indices, const int64_t* r
   int rc = check_hip(hipMemsetAsync(plan->counts, 0, (size_t)(G + 1) * 4, st), "memset counts");
   if (rc) return rc;
   const unsigned tiles = (unsigned)((nnz + kTile - 1) / kTile);
-  hipLaunchKernelGGL(fast3_prep_kernel, dim3(tiles), dim3(kTile), 0, st, indices, rowidx, nnz, nnz_dev, sentinel,
+  hipLaunchKernelGGL(fast3_prep_kernel, dim3(tiles), dim3(kTile), 0, st, indices, rowidx, offsets, nnz, nnz_dev, sentinel,
                      (uint32_t)s.p[0], (uint32_t)s.p[1], (uint32_t)s.p[2], *plan);
   rc = check_hip(hipGetLastError(), "fast3_prep_kernel");
   if (rc) return rc;
@@ -975,8 +976,8 @@ static int group_ids(const DevShape& s, const int64_t* indices, const int64_t* r
 }
 
 // resolve where the plan lives, carve the workspace, group the ids unless a ready plan was passed
-static int prepare(const DevShape& s, bool bwd, const int64_t* indices, const int64_t* rowidx, int64_t nnz,
-                   const int32_t* nnz_dev, void* ws, int64_t ws_bytes, void* plan_buf, int64_t plan_bytes,
+static int prepare(const DevShape& s, bool bwd, const int64_t* indices, const int64_t* rowidx,
+                   const int64_t* offsets, int64_t nnz, const int32_t* nnz_dev, void* ws, int64_t ws_bytes, void* plan_buf, int64_t plan_bytes,
                    bool plan_ready, GroupPlan* plan, hipStream_t st) {
   memset(plan, 0, sizeof(*plan));
   const bool external = plan_buf != nullptr && plan_bytes >= fast3_plan_bytes(s, nnz);
@@ -988,7 +989,7 @@ static int prepare(const DevShape& s, bool bwd, const int64_t* indices, const in
     return fail(TTEMB_E_WORKSPACE, "fast path needs %lld workspace bytes, got %lld", (long long)need, (long long)ws_bytes);
   if (external) carve_plan_part(s, nnz, reinterpret_cast<char*>(plan_buf), plan);
   if (reuse) return TTEMB_OK;
-  return group_ids(s, indices, rowidx, nnz, nnz_dev, plan, scan_tmp, st);
+  return group_ids(s, indices, rowidx, offsets, nnz, nnz_dev, plan, scan_tmp, st);
 }
 
 template <int Q0, int Q1, int Q2, int R1, int R2>
@@ -1006,11 +1007,12 @@ static int run_forward(const DevShape& s, const CorePtrs& cores, const GroupPlan
 }
 
 int launch_forward_fast3(const DevShape& s, const CorePtrs& cores, const int64_t* indices,
-                         const int64_t* rowidx, int64_t nnz, const int32_t* nnz_dev, float* output,
-                         void* ws, int64_t ws_bytes, void* plan_buf, int64_t plan_bytes, hipStream_t st) {
+                         const int64_t* rowidx, const int64_t* offsets, int64_t nnz, const int32_t* nnz_dev,
+                         float* output, void* ws, int64_t ws_bytes, void* plan_buf, int64_t plan_bytes,
+                         hipStream_t st) {
   if (nnz <= 0) return TTEMB_OK;
   GroupPlan ids;
-  int rc = prepare(s, false, indices, rowidx, nnz, nnz_dev, ws, ws_bytes, plan_buf, plan_bytes, false, &ids, st);
+  int rc = prepare(s, false, indices, rowidx, offsets, nnz, nnz_dev, ws, ws_bytes, plan_buf, plan_bytes, false, &ids, st);
   if (rc) return rc;
   switch (classify(s)) {
     case kProducts: return run_forward<4, 5, 5, 16, 16>(s, cores, ids, nnz, nnz_dev, output, st);
@@ -1066,7 +1068,7 @@ int launch_backward_fast3(const DevShape& s, const CorePtrs& cores, const int64_
   }
   if (nnz <= 0) return TTEMB_OK;
   GroupPlan plan;
-  int rc = prepare(s, true, indices, rowidx, nnz, nnz_dev, ws, ws_bytes, const_cast<void*>(plan_buf), plan_bytes,
+  int rc = prepare(s, true, indices, rowidx, nullptr, nnz, nnz_dev, ws, ws_bytes, const_cast<void*>(plan_buf), plan_bytes,
                    plan_buf != nullptr, &plan, st);
   if (rc) return rc;
   switch (classify(s)) {

@@ -31,6 +31,7 @@ int64_t generic_bwd_lds_bytes(const DevShape& s) {
 __global__ __launch_bounds__(64) void fwd_generic_kernel(DevShape s, CorePtrs cores,
                                                          const int64_t* __restrict__ indices,
                                                          const int64_t* __restrict__ rowidx,
+                                                         const int64_t* __restrict__ offsets,
                                                          int64_t nnz,
                                                          const int32_t* __restrict__ nnz_dev,
                                                          float* __restrict__ output) {
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(64) void fwd_generic_kernel(DevShape s, CorePtrs co
     bool single = true;
     if (rowidx != nullptr) {
       row = rowidx[n];
-      single = (n == 0 || rowidx[n - 1] != row) && (n + 1 >= cnt || rowidx[n + 1] != row);
+      single = bag_is_single(rowidx, offsets, n, cnt, row);
     }
     const float* g0 = cores.c[0] + (int64_t)it[0] * s.row_len[0];
     for (int e = lane; e < s.row_len[0]; e += kWave) buf0[e] = g0[e];
@@ -83,15 +84,15 @@ __global__ __launch_bounds__(64) void fwd_generic_kernel(DevShape s, CorePtrs co
 }
 
 int launch_forward_generic(const DevShape& s, const CorePtrs& cores, const int64_t* indices,
-                           const int64_t* rowidx, int64_t nnz, const int32_t* nnz_dev,
-                           float* output, hipStream_t st) {
+                           const int64_t* rowidx, const int64_t* offsets, int64_t nnz,
+                           const int32_t* nnz_dev, float* output, hipStream_t st) {
   if (nnz <= 0) return TTEMB_OK;
   const int64_t lds = generic_fwd_lds_bytes(s);
   if (lds > 64 * 1024) return fail(TTEMB_E_UNSUPPORTED, "partial product of %d floats exceeds the LDS budget", s.part_max);
   const int64_t grid = nnz < 262144 ? nnz : 262144;
   profile_begin(0, st);
   hipLaunchKernelGGL(fwd_generic_kernel, dim3((unsigned)grid), dim3(kWave), (size_t)lds, st, s,
-                     cores, indices, rowidx, nnz, nnz_dev, output);
+                     cores, indices, rowidx, offsets, nnz, nnz_dev, output);
   profile_end(0, st);
   return check_hip(hipGetLastError(), "fwd_generic_kernel");
 }

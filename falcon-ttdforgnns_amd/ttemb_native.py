@@ -84,7 +84,7 @@ def _load() -> ctypes.CDLL:
     lib.ttemb_cache_update.argtypes = [vp, i64, vp, vp, i64, vp]
     lib.ttemb_cache_populate.argtypes = [shp, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp]
     lib.ttemb_preprocess.argtypes = [vp, vp, i64, i64, i32, vp, vp, i64, vp, vp, vp, vp, vp, i64, vp]
-    lib.ttemb_cache_forward.argtypes = [vp, vp, i64, vp, i64, vp, i64, vp, vp]
+    lib.ttemb_cache_forward.argtypes = [vp, vp, vp, i64, vp, i64, vp, i64, vp, vp]
     lib.ttemb_cache_backward_sgd.argtypes = [vp, vp, i64, vp, i64, vp, i64, f32, vp, vp]
     lib.ttemb_cache_backward_dense.argtypes = [vp, vp, i64, vp, i64, vp, i64, i64, vp, vp]
     lib.ttemb_cache_backward_rowwise_adagrad.argtypes = [vp, vp, i64, vp, i64, vp, i64, f32, f32, vp, vp, vp]
@@ -289,9 +289,10 @@ def preprocess(indices, offsets, B: int, warmup: bool, hashtbl, cache_state, ind
                                     _stream(indices)))
 
 
-def cache_forward(cache_loc, rowidx, start: int, start_dev, nnz: int, cache_weight, output) -> None:
+def cache_forward(cache_loc, rowidx, start: int, start_dev, nnz: int, cache_weight, output,
+                  offsets: Optional[torch.Tensor] = None) -> None:
     with _on_device(output.device):
-        _check(LIB.ttemb_cache_forward(_ptr(cache_loc), _ptr(rowidx), start, _ptr(start_dev), nnz,
+        _check(LIB.ttemb_cache_forward(_ptr(cache_loc), _ptr(rowidx), _ptr(offsets), start, _ptr(start_dev), nnz,
                                        _ptr(cache_weight), cache_weight.shape[1], _ptr(output),
                                        _stream(output)))
 

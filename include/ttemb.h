@@ -94,9 +94,10 @@ int ttemb_profile_read(int32_t which, float* ms_host);
  * for bags with no id in that range.  `nnz_dev`, when non-null, points at a device
  * int32 holding the live count (<= nnz); the launch is sized by nnz and the kernels
  * read the count themselves, so no host sync is needed after ttemb_preprocess.
- * `offsets` (int64[B+1]) may be passed when indices[0:nnz] are exactly the concatenated
- * bags (no cache partition): then only bags whose length is not 1 are zero-filled before
- * the lookups; with offsets == NULL the whole output is zero-filled first.
+ * `offsets` (int64[B+1]) describes the bags of the ORIGINAL id list: with it only bags whose
+ * length is not 1 are zero-filled before the lookups (a bag of one id has exactly one writer,
+ * this call or ttemb_cache_forward(offsets)); with offsets == NULL the whole output is
+ * zero-filled first and single-id detection falls back to neighbouring rowidx values.
  * `plan` (nullable, ttemb_plan_bytes() bytes) receives the id grouping for the backward.
  * There is no batch_count chunking: intermediates never leave the chip.
  * ------------------------------------------------------------------------------- */
@@ -177,8 +178,10 @@ int ttemb_preprocess(const int64_t* indices, const int64_t* offsets, int64_t nnz
 
 /* cache_forward (tt_embeddings.cpp:151, tt_embeddings_cuda.cu:1509-1583):
  * output[rowidx[n]] += cache_weight[cache_loc[n]] for n in [start, nnz).  `start` is
- * the host value, or *start_dev when start_dev is non-null. */
-int ttemb_cache_forward(const int32_t* cache_loc, const int64_t* rowidx, int64_t start,
+ * the host value, or *start_dev when start_dev is non-null.  With `offsets` (the same
+ * int64[B+1] given to ttemb_forward) a bag of exactly one id is written with a plain
+ * store -- ttemb_forward(offsets) left such rows untouched, so nothing is read or zeroed. */
+int ttemb_cache_forward(const int32_t* cache_loc, const int64_t* rowidx, const int64_t* offsets, int64_t start,
                         const int32_t* start_dev, int64_t nnz, const float* cache_weight,
                         int64_t D, float* output, void* stream);
 
