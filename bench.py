@@ -45,6 +45,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--ids", type=int, default=409600, help="frontier ids per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the batch-2048 and METIS-like legs (keeps a rocprofv3 summary to the headline workload)")
     ap.add_argument("--path", default="auto", choices=["auto", "generic", "fast3"])
     args = ap.parse_args()
 
@@ -147,7 +149,7 @@ def main():
         # latency regime of the metric's "batch 2048": 2048 unique ids per step (sparse batch -> generic
         # wave-per-id kernels), same fwd + bwd + SGD step through the class
         small = None
-        if world == 1:
+        if world == 1 and not args.no_extras:
             ids_s = torch.from_numpy(rng.choice(N_EMB, size=2048, replace=False).astype(np.int64)).cuda()
             offs_s = torch.arange(2049, dtype=torch.int64, device="cuda")
             d_s = d_out[:2048]
@@ -160,6 +162,21 @@ def main():
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t1) / 200
             small = {"ids": 2048, "us_per_step": round(dt * 1e6, 1), "lookups_per_s": round(2048 / dt, 1)}
+        # the same step on a frontier with METIS-like id locality (2048 windows of 200 consecutive ids:
+        # what `--partition 125` reordering produces, SURVEY.md §8d cfg-B3), reported next to the uniform one
+        local = None
+        if world == 1 and not args.no_extras:
+            starts = rng.choice(N_EMB // 200 - 1, size=(N + 199) // 200, replace=False) * 200
+            ids_l = torch.from_numpy((starts[:, None] + np.arange(200)[None, :]).reshape(-1)[:N].astype(np.int64)).cuda()
+            for _ in range(5):
+                emb(ids_l, offsets).backward(d_out)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(20):
+                emb(ids_l, offsets).backward(d_out)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / 20
+            local = {"ids": N, "ms_per_step": round(dt * 1e3, 4), "lookups_per_s": round(N / dt, 1)}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             from oracle import cpu_einsum
@@ -178,7 +195,7 @@ def main():
                                    "2048-seed batch = 409600 unique uniform ids per GPU, bag length 1",
                        "p": P, "q": Q, "tt_ranks": RANKS, "num_embeddings": N_EMB, "ids_per_gpu_step": N,
                        "parallelism": f"dp{world}", "kernel_path": args.path},
-            "roofline": roofline, "cpu_baseline": cpu, "batch2048_step": small,
+            "roofline": roofline, "cpu_baseline": cpu, "batch2048_step": small, "metis_like_step": local,
         }
     if world > 1:
         dist.barrier()

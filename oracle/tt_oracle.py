@@ -6,7 +6,7 @@ Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
 ``cpu_baseline`` leg may import anything under ``oracle/``.
 
 Parity pin: the forward/backward restatements below are checked, in
-``oracle/make_golden.py`` (run in the build container, where /root/reference is
+``tests/golden/make_golden.py`` (run in the build container, where /root/reference is
 mounted), against the reference's own pure-PyTorch ``tt_matrix_to_full``
 (FBTT/tt_embeddings_ops.py:80-127) and autograd through it.  The resulting
 vectors are committed under ``tests/golden/``.  The reference ships no
