@@ -345,6 +345,14 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         self._dense_grad_out = None
         self._shape = _nat.make_shape(self.tt_p_shapes, self.tt_q_shapes, self.tt_ranks)
         self._ws = _nat.Workspace()
+        self.register_load_state_dict_post_hook(TableBatchedTTEmbeddingBag._after_load)
+
+    @staticmethod
+    def _after_load(module, incompatible_keys) -> None:
+        """Checkpoint load path (the reference has none): `warmup` is not part of the
+        state dict, so it is re-derived -- a populated cache (`cache_state` holds ranks) is live."""
+        if module.use_cache and module.cache_state.numel():
+            module.warmup = not bool((module.cache_state >= 0).any().item())
 
     # ---- weights ------------------------------------------------------------------
     def full_weight(self) -> torch.Tensor:

@@ -65,17 +65,35 @@ __global__ void cache_update_kernel(const int64_t* __restrict__ indices, int64_t
   const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= nnz) return;
   const int64_t key = indices[n];
-  uint32_t s = hash_slot(key, H);
+  const uint32_t s0 = hash_slot(key, H);
+  // Pass 1, reads only: is the key already in one of its probe slots?  The reference probes and
+  // inserts in one sweep (hashtbl_cuda_utils.cuh:102-133), which after cache_populate's evictions
+  // re-inserts a cached id into a hole in front of its own slot; the id then resolves to the new slot
+  // (cache_state -1) and silently leaves the cache, for a thread-order-dependent set of ids.  Finding
+  // first keeps every tracked key in one slot; before any eviction the two are the same table.
+  // (A slot never changes once it holds a real key until populate evicts, so what pass 1 saw occupied
+  // stays occupied: pass 2 only needs a CAS on the slots it saw empty -- one atomic per id.)
+  unsigned long long seen[kMaxProbes];
+  uint32_t s = s0;
+#pragma unroll
   for (int probe = 0; probe < kMaxProbes; ++probe) {
-    // a slot never changes once it holds a real key (until populate evicts), so a plain read that
-    // already sees `key` makes the CAS unnecessary: one atomic request per id instead of two
-    unsigned long long old = (unsigned long long)__builtin_nontemporal_load(&keys[s]);
-    if (old != (unsigned long long)key)
-      old = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[s]), (unsigned long long)kEmptyKey,
-                      (unsigned long long)key);
-    if (old == (unsigned long long)kEmptyKey || old == (unsigned long long)key) {
+    seen[probe] = (unsigned long long)__builtin_nontemporal_load(&keys[s]);
+    if (seen[probe] == (unsigned long long)key) {
       atomicAdd(reinterpret_cast<unsigned long long*>(&freq[s]), 1ull);
       return;
+    }
+    s = (s + 1 == H) ? 0 : s + 1;
+  }
+  s = s0;
+#pragma unroll
+  for (int probe = 0; probe < kMaxProbes; ++probe) {
+    if (seen[probe] == (unsigned long long)kEmptyKey) {
+      const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[s]),
+                                               (unsigned long long)kEmptyKey, (unsigned long long)key);
+      if (old == (unsigned long long)kEmptyKey || old == (unsigned long long)key) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(&freq[s]), 1ull);
+        return;
+      }
     }
     s = (s + 1 == H) ? 0 : s + 1;
   }

@@ -98,3 +98,105 @@ def init_cores(mod, weight_dist: str) -> None:
                 _assign(c, _tail_normal(tuple(c.shape)) * np.float32(scale))
         else:
             _approx_uniform(mod)
+
+
+# ---------------------------------------------------------------------------------------------
+# Initialisers the GNN drivers apply on top of the layer (tt_utils.py:117-201, selected by
+# `--init ortho|dortho|eigen` in gnn_model.py:127-181).  Written for any 2..4-core shape (the reference
+# hard-codes 3 cores and q = [4, 5, 5]) and as torch linear algebra on whatever device the caller asks
+# for, so that the 2.45 M x 100 decomposition runs on the MI355X instead of in numpy.
+# ---------------------------------------------------------------------------------------------
+
+
+def _full_ranks(tt_ranks, T):
+    r = [int(x) for x in tt_ranks]
+    if len(r) == T - 1:
+        r = [1] + r + [1]
+    assert len(r) == T + 1 and r[0] == 1 and r[-1] == 1, "tt_ranks must be the T-1 inner ranks or [1, ..., 1]"
+    return r
+
+
+def _rows_from_core4(core4: torch.Tensor) -> torch.Tensor:
+    """[R, p, q, R'] -> [1, p, R*q*R'] (storage layout of `tt_cores`)."""
+    R, p, q, R2 = core4.shape
+    return core4.permute(1, 0, 2, 3).reshape(1, p, R * q * R2).contiguous()
+
+
+def ortho_cores(tt_ranks, tt_p_shapes, tt_q_shapes, device="cpu", generator=None):
+    """Cores whose (r_in, q) slices are orthonormal vectors over (p, r_out)  (`get_ortho`, tt_utils.py:117-157).
+
+    For core t the reference takes the first R_t*q_t rows of the Q factor of a random
+    (p_t R_{t+1}) x (p_t R_{t+1}) matrix; an orthonormal R_t*q_t-frame of that space has the same
+    distribution and only needs the reduced QR of a tall (p_t R_{t+1}) x (R_t q_t) matrix.
+    Returns a list of float32 tensors [1, p_t, R_t q_t R_{t+1}].
+    """
+    T = len(tt_p_shapes)
+    R = _full_ranks(tt_ranks, T)
+    out = []
+    for t in range(T):
+        p, q = int(tt_p_shapes[t]), int(tt_q_shapes[t])
+        n, k = p * R[t + 1], R[t] * q
+        if k > n:
+            raise ValueError(f"core {t}: needs {k} orthonormal vectors in a {n}-dimensional space")
+        m = torch.randn(n, k, device=device, dtype=torch.float32, generator=generator)
+        frame, _ = torch.linalg.qr(m, mode="reduced")            # n x k, orthonormal columns
+        core4 = frame.t().reshape(R[t], q, p, R[t + 1]).permute(0, 2, 1, 3)   # [R, p, q, R']
+        out.append(_rows_from_core4(core4))
+    return out
+
+
+def tt_svd_cores(matrix, tt_ranks, tt_p_shapes, tt_q_shapes):
+    """TT-SVD of a dense [prod(p), prod(q)] table into cores  (`tt_matrix_decomp`, tt_utils.py:159-201).
+
+    The table is viewed as a tensor with modes (p_t q_t); each step takes the rank-truncated SVD of the
+    current unfolding, keeps U as the core and carries diag(s)·V^T forward.  Runs where `matrix` lives.
+    Returns (cores, ranks) with cores float32 [1, p_t, R_t q_t R_{t+1}] and the ranks actually used.
+    """
+    T = len(tt_p_shapes)
+    want = _full_ranks(tt_ranks, T)
+    p = [int(x) for x in tt_p_shapes]
+    q = [int(x) for x in tt_q_shapes]
+    x = torch.as_tensor(matrix, dtype=torch.float32)
+    assert x.shape == (int(np.prod(p)), int(np.prod(q))), "matrix must be [prod(p), prod(q)]"
+    order = [i for t in range(T) for i in (t, T + t)]
+    x = x.reshape(p + q).permute(order)
+    ranks = [1] * (T + 1)
+    cores = []
+    for t in range(T - 1):
+        rows = ranks[t] * p[t] * q[t]
+        x = x.reshape(rows, -1)
+        ranks[t + 1] = 1 if want[t + 1] == 1 else min(want[t + 1], rows, x.shape[1])
+        if x.shape[1] > 4 * rows:
+            # wide unfolding: eigen-decompose the small Gram matrix instead of a full SVD
+            evals, u = torch.linalg.eigh((x @ x.t()).double())
+            u = u[:, -ranks[t + 1]:].flip(1).float()
+            x_next = u.t() @ x
+        else:
+            u, s, vh = torch.linalg.svd(x, full_matrices=False)
+            u = u[:, :ranks[t + 1]]
+            x_next = s[:ranks[t + 1], None] * vh[:ranks[t + 1]]
+        cores.append(_rows_from_core4(u.reshape(ranks[t], p[t], q[t], ranks[t + 1])))
+        x = x_next
+    cores.append(_rows_from_core4(x.reshape(ranks[T - 1], p[T - 1], q[T - 1], 1)))
+    return cores, ranks
+
+
+def prefix_locality(indices: torch.Tensor, tt_p_shapes):
+    """How well a batch of ids shares TT prefixes (what METIS reordering buys).
+
+    Returns a dict: ids, distinct ids, distinct prefixes (all index digits but the last), ids per
+    prefix, and the fraction of first-stage products a prefix-sharing kernel skips.  Runs on the
+    tensor's device.
+    """
+    ids = indices.reshape(-1).long()
+    n = int(ids.numel())
+    last = int(tt_p_shapes[-1])
+    prefixes = int(torch.unique(torch.div(ids, last, rounding_mode="floor")).numel()) if n else 0
+    distinct = int(torch.unique(ids).numel()) if n else 0
+    return {
+        "ids": n,
+        "distinct_ids": distinct,
+        "distinct_prefixes": prefixes,
+        "ids_per_prefix": (n / prefixes) if prefixes else 0.0,
+        "stage1_reuse": (1.0 - prefixes / n) if n else 0.0,
+    }

@@ -251,17 +251,29 @@ def hashtbl_find(key, hashtbl):
     return -1
 
 
-def update_cache_state(indices, hashtbl, cache_freq):
+def update_cache_state(indices, hashtbl, cache_freq, find_first=False):
     """Sequential hashtbl_insert<accumulate>(id, 1) over the ids
     [tt_embeddings_cuda.cu:1083-1095; hashtbl_cuda_utils.cuh:102-133].
     Mutates hashtbl / cache_freq in place; returns #failed inserts.
     (On the GPU the insertion order is undefined; the final table equals this
     one whenever no two distinct keys contend for a slot.)
+
+    ``find_first=False`` is the reference: the probe stops at the first empty slot, so once
+    ``cache_populate`` has evicted entries a key that sits *behind* such a hole is inserted a second
+    time in front of itself -- and ``hashtbl_find`` then returns the new slot, whose cache_state is
+    -1: the id silently drops out of the cache (which ids, depends on thread order on the GPU).
+    ``find_first=True`` is what the HIP path does: look for the key in all probe slots before
+    inserting.  The two are identical as long as nothing was evicted (the whole warm-up).
     """
     H = hashtbl.shape[0]
     failed = 0
     for key in np.asarray(indices, dtype=np.int64).tolist():
         s = murmur_slot(key, H)
+        if find_first:
+            t = hashtbl_find(key, hashtbl)
+            if t >= 0:
+                cache_freq[t] += 1
+                continue
         for _ in range(MAX_PROBES):
             if hashtbl[s] == UNUSED_KEY:
                 hashtbl[s] = key

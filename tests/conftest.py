@@ -15,7 +15,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 TINY_CASES = ["tt_tiny_T2", "tt_tiny_T3", "tt_tiny_T4", "tt_small_prodshape", "tt_small_arxivshape",
               "tt_small_papershape"]
-ROW_CASES = ["rows_arxiv", "rows_products", "rows_papers"]
+ROW_CASES = ["rows_arxiv", "rows_products", "rows_papers", "rows_products_b3"]
 
 
 def pytest_configure(config):

@@ -204,9 +204,42 @@ def suggested_shape_vectors():
     print("suggest_kat:", len(rows), "rows")
 
 
+def window_case(name, p, q, ranks, seed, n_emb, n_windows, width):
+    """SURVEY §8d cfg-B3 / §8f-1: ids of a METIS-reordered frontier = windows of consecutive ids
+    (seeds first).  Rows again come from the reference's tt_matrix_to_full on the sub-table of the
+    p-slices the windows touch."""
+    T = len(p)
+    R = orc.full_ranks(ranks, T)
+    cores = [c * np.float32(0.5) for c in seeded_cores(p, q, R, seed, scale=None)]
+    rng = np.random.default_rng(seed + 7)
+    L = orc.strides_L(p)
+    starts = rng.integers(0, n_emb - width, size=n_windows)
+    starts[0] = (starts[0] // p[-1]) * p[-1] + p[-1] - width // 2     # one window crosses an (i0,i1) boundary
+    starts[-1] = n_emb - width                                        # one ends at the last valid id
+    ids = (starts[:, None] + np.arange(width)[None, :]).reshape(-1).astype(np.int64)
+    digits = orc.split_index(ids, p)
+    sels = [np.unique(d) for d in digits]
+    sub_full = ref_full([len(s) for s in sels], q, R, [torch.tensor(cores[t][sels[t]]) for t in range(T)]).numpy()
+    pos = [np.searchsorted(sels[t], digits[t]) for t in range(T)]
+    sub_id = np.zeros_like(ids)
+    for t in range(T):
+        sub_id = sub_id * len(sels[t]) + pos[t]
+    rows = sub_full[sub_id]
+    o_rows = orc.tt_rows(ids, cores, p, q, R)
+    assert np.abs(o_rows - rows).max() <= 1e-4 * max(1.0, np.abs(rows).max()), name
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), p=np.array(p), q=np.array(q), R=np.array(R),
+                        seed=np.int64(seed), core_scale=np.float32(0.5), num_embeddings=np.int64(n_emb),
+                        indices=ids, rows=rows, cores_sha256=np.array(cores_sha256(cores)))
+    print(f"{name}: ids={ids.shape[0]} prefixes={np.unique(ids // p[-1]).shape[0]} max_id={ids.max()} "
+          f"|rows|max={np.abs(rows).max():.3f} oracle-vs-ref max diff={np.abs(o_rows - rows).max():.2e}")
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "suggest":
         suggested_shape_vectors()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "windows":
+        window_case("rows_products_b3", [125, 140, 140], [4, 5, 5], [16, 16], 22, 2449029, 6, 40)
         return
     torch.manual_seed(0)
     tiny_case("tt_tiny_T2", [6, 7], [4, 3], [5], seed=11)
@@ -219,6 +252,7 @@ def main():
     sampled_case("rows_arxiv", [56, 60, 51], [4, 4, 8], [8, 8], 21, 169343, [8, 8, 8])
     sampled_case("rows_products", [125, 140, 140], [4, 5, 5], [16, 16], 22, 2449029, [8, 8, 8])
     sampled_case("rows_papers", [500, 560, 400], [8, 4, 4], [32, 32], 23, 111059956, [6, 6, 6])
+    window_case("rows_products_b3", [125, 140, 140], [4, 5, 5], [16, 16], 22, 2449029, 6, 40)
     murmur_vectors()
     suggested_shape_vectors()
 

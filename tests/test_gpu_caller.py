@@ -1,0 +1,173 @@
+"""GPU: the caller contract either side of the layer.
+
+* `SAGE.forward` / `SAGE.inference` (gnn_model.py:193-253): `offsets = arange(N+1)`, frontier ids with the
+  seeds first, `inference` looks the whole table up in one call;
+* a 20-step training loss curve through the MI355X layer against the same model with the embedding done
+  on the CPU by autograd through the dense table;
+* `state_dict()` files interchange and a populated cache survives a save/load.
+"""
+import io
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available()
+    import FBTT.tt_embeddings_ops as m
+    return m
+
+
+P, Q, R = [20, 25, 20], [4, 5, 5], [16, 16]
+N_NODES, D = 10000, 100
+
+
+def test_inference_lookup_of_the_whole_table(ops):
+    torch.manual_seed(3)
+    emb = ops.TTEmbeddingBag(N_NODES, D, R, P, Q, sparse=True, use_cache=False, weight_dist="normal")
+    for c in emb.tt_cores:
+        c.data.mul_(30.0)
+    ids = torch.arange(N_NODES, device="cuda")
+    with torch.no_grad():
+        out = emb(ids, torch.arange(N_NODES + 1, device="cuda"))
+    full = emb.full_weight()[:N_NODES]
+    assert out.shape == (N_NODES, D)
+    assert (out - full).abs().max().item() < 1e-4
+
+
+def test_twenty_step_loss_curve_matches_cpu_table_autograd(ops):
+    import sage_epoch as harness
+    from FBTT.tt_embeddings_ops import tt_matrix_to_full
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(5)
+    indptr, indices = harness.build_graph(N_NODES, 10, 0.5, dev, gen)
+    labels = torch.randint(0, 7, (N_NODES,), device=dev, generator=gen)
+    lut = torch.full((N_NODES,), -1, dtype=torch.int64, device=dev)
+    lr_emb, steps, batch = 0.05, 20, 128
+    torch.manual_seed(11)
+    emb = ops.TTEmbeddingBag(N_NODES, D, R, P, Q, sparse=True, use_cache=False, weight_dist="normal",
+                             learning_rate=lr_emb)
+    for c in emb.tt_cores:
+        c.data.mul_(30.0)
+    layers = torch.nn.ModuleList([harness.MeanSAGE(D, 32), harness.MeanSAGE(32, 7)]).to(dev)
+    # the CPU replica: same weights, embedding rows by autograd through the dense table
+    cpu_cores = [c.detach().cpu().clone().requires_grad_(True) for c in emb.tt_cores]
+    cpu_layers = torch.nn.ModuleList([harness.MeanSAGE(D, 32), harness.MeanSAGE(32, 7)])
+    cpu_layers.load_state_dict({k: v.cpu() for k, v in layers.state_dict().items()})
+    opt = torch.optim.Adam(layers.parameters(), lr=0.01)         # tt_utils.py:23
+    cpu_opt = torch.optim.Adam(cpu_layers.parameters(), lr=0.01)
+    curve, cpu_curve = [], []
+    for s in range(steps):
+        seeds = torch.randint(0, N_NODES, (batch,), device=dev, generator=gen).unique()
+        input_nodes, blocks = harness.sample_blocks(indptr, indices, seeds, [5, 5], gen, lut)
+        assert torch.equal(input_nodes[: seeds.numel()], seeds)        # seeds first (gnn_model.py:211)
+        assert input_nodes.unique().numel() == input_nodes.numel()
+
+        h = emb(input_nodes, torch.arange(input_nodes.numel() + 1, device=dev))
+        x = h
+        for li, (layer, block) in enumerate(zip(layers, blocks)):
+            x = layer(x, block)
+            x = F.relu(x) if li == 0 else x
+        loss = F.cross_entropy(x, labels[seeds])
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        curve.append(loss.item())
+
+        table = tt_matrix_to_full(P, Q, [1] + R + [1], cpu_cores, [1, 0, 2, 3])
+        x = table[input_nodes.cpu()]
+        for li, (layer, block) in enumerate(zip(cpu_layers, blocks)):
+            x = layer(x, tuple(b.cpu() if torch.is_tensor(b) else b for b in block))
+            x = F.relu(x) if li == 0 else x
+        cpu_loss = F.cross_entropy(x, labels[seeds].cpu())
+        cpu_opt.zero_grad(set_to_none=True)
+        grads = torch.autograd.grad(cpu_loss, cpu_cores + list(cpu_layers.parameters()))
+        with torch.no_grad():
+            for c, g in zip(cpu_cores, grads[: len(cpu_cores)]):
+                c -= lr_emb * g                                     # the layer's fused SGD
+        for prm, g in zip(cpu_layers.parameters(), grads[len(cpu_cores):]):
+            prm.grad = g
+        cpu_opt.step()
+        cpu_curve.append(cpu_loss.item())
+    curve, cpu_curve = np.array(curve), np.array(cpu_curve)
+    assert np.isfinite(curve).all()
+    np.testing.assert_allclose(curve, cpu_curve, rtol=2e-3, atol=2e-3)
+    for c, ref in zip(emb.tt_cores, cpu_cores):
+        assert (c.detach().cpu() - ref.detach()).abs().max().item() < 2e-3 * ref.detach().abs().max().item()
+
+
+def test_state_dict_interchange_and_cache_survives_reload(ops):
+    torch.manual_seed(9)
+    rng = np.random.default_rng(9)
+    kw = dict(sparse=True, use_cache=True, cache_size=300, hashtbl_size=N_NODES, weight_dist="normal",
+              learning_rate=0.05)
+    emb = ops.TTEmbeddingBag(N_NODES, D, R, P, Q, **kw)
+    for c in emb.tt_cores:
+        c.data.mul_(30.0)
+    hot = rng.choice(N_NODES, size=250, replace=False)
+    batches = [np.concatenate([rng.choice(hot, size=1500), rng.integers(0, N_NODES, size=1500)]) for _ in range(6)]
+    for b in batches[:4]:
+        ids = torch.tensor(b).cuda()
+        o = emb(ids, torch.arange(ids.numel() + 1).cuda())
+        o.backward((torch.rand_like(o) - 0.5) * 0.01)
+    emb.cache_populate()
+    sd = emb.state_dict()
+    # key names / shapes / dtypes of the reference's module (tt_embeddings_ops.py:519-614)
+    want = {"L": torch.int64, "tt_cores.0": torch.float32, "tt_cores.1": torch.float32, "tt_cores.2": torch.float32,
+            "hashtbl": torch.int64, "cache_freq": torch.int64, "cache_state": torch.int32,
+            "cache_weight": torch.float32}
+    for k, dt in want.items():
+        assert k in sd and sd[k].dtype == dt, k
+    assert sd["tt_cores.1"].shape == (1, P[1], R[0] * Q[1] * R[1]) and sd["cache_weight"].shape == (300, D)
+    blob = io.BytesIO()
+    torch.save(sd, blob)
+    blob.seek(0)
+    emb2 = ops.TTEmbeddingBag(N_NODES, D, R, P, Q, **kw)
+    assert emb2.warmup
+    emb2.load_state_dict(torch.load(blob))
+    assert not emb2.warmup                      # a populated cache is live after the load
+    for it, b in enumerate(batches[4:]):        # both copies now train identically, cache and cores
+        ids = torch.tensor(b).cuda()
+        offs = torch.arange(ids.numel() + 1).cuda()
+        o1, o2 = emb(ids, offs), emb2(ids, offs)
+        assert torch.isfinite(o1).all()
+        bad = ((o1 - o2).abs().max(1).values > 1e-5).nonzero().flatten()
+        assert bad.numel() == 0, (it, bad.numel(), bad[:8].tolist(), ids[bad[:8]].tolist(),
+                                  (o1 - o2).abs().max().item())
+        g = (torch.rand_like(o1) - 0.5) * 0.01
+        o1.backward(g)
+        o2.backward(g)
+    sd1, sd2 = emb.state_dict(), emb2.state_dict()
+    for k in sd1:
+        a, b = sd1[k], sd2[k]
+        if a.dtype.is_floating_point and a.numel():
+            assert (a - b).abs().max().item() < 1e-4 * max(1.0, a.abs().max().item()), k
+        elif k in ("L", "cache_state"):
+            assert torch.equal(a, b), k
+    # ids first seen after the populate race for free slots (CAS order), so only the cached entries are
+    # pinned slot by slot; the tracked id sets still agree up to probe-limit insert failures.  No key
+    # sits in two slots (the reference's insert would duplicate cached ids into eviction holes).
+    tracked = sd1["hashtbl"][sd1["hashtbl"] >= 0]
+    assert tracked.unique().numel() == tracked.numel()
+    live = sd1["cache_state"] >= 0
+    assert torch.equal(sd1["hashtbl"][live], sd2["hashtbl"][live])
+    assert torch.equal(sd1["cache_freq"][live], sd2["cache_freq"][live])
+    k1 = set(sd1["hashtbl"][sd1["hashtbl"] >= 0].tolist())
+    k2 = set(sd2["hashtbl"][sd2["hashtbl"] >= 0].tolist())
+    assert len(k1 ^ k2) <= 0.01 * len(k1)
+    # a warm-up-phase checkpoint stays in warm-up
+    emb3 = ops.TTEmbeddingBag(N_NODES, D, R, P, Q, **kw)
+    emb4 = ops.TTEmbeddingBag(N_NODES, D, R, P, Q, **kw)
+    emb4.load_state_dict(emb3.state_dict())
+    assert emb4.warmup

@@ -281,6 +281,38 @@ def test_cache_lifecycle_keeps_forward_and_trains(ops, orc, sparse):
             np.testing.assert_allclose(c.grad[0].cpu().numpy(), g, rtol=1e-3, atol=1e-4 * np.abs(g).max())
 
 
+def test_lfu_update_after_populate_keeps_cached_ids(ops, orc):
+    """After cache_populate's evictions the update must find a displaced cached key instead of
+    inserting it again in front of itself (see oracle.update_cache_state, find_first=True)."""
+    import ttemb_native as nat
+    rng = np.random.default_rng(21)
+    H, C = 4096, 600
+    warm = rng.integers(0, 50000, size=6000)
+    warm = np.concatenate([warm, rng.choice(warm[:1500], size=6000)])        # some ids are hot
+    tbl, freq, state = np.full(H, -1, np.int64), np.zeros(H, np.int64), np.full(H, -1, np.int32)
+    orc.update_cache_state(warm, tbl, freq)
+    orc.cache_populate(tbl, freq, state, C)
+    d_tbl, d_freq = torch.tensor(tbl).cuda(), torch.tensor(freq).cuda()
+    cached = tbl[state >= 0]
+    # only cached ids + ids that cannot be inserted anywhere near them would be too easy: mix in new ids
+    later = np.concatenate([rng.choice(cached, size=5000), rng.integers(50000, 60000, size=300)])
+    nat.cache_update(torch.tensor(later).cuda(), d_tbl, d_freq)
+    o_tbl, o_freq = tbl.copy(), freq.copy()
+    orc.update_cache_state(later, o_tbl, o_freq, find_first=True)
+    g_tbl, g_freq = d_tbl.cpu().numpy(), d_freq.cpu().numpy()
+    live = state >= 0
+    assert np.array_equal(g_tbl[live], tbl[live])                   # cached entries stay where they were
+    assert np.array_equal(g_freq[live], o_freq[live])               # and all their hits were counted there
+    tracked = g_tbl[g_tbl >= 0]
+    assert np.unique(tracked).size == tracked.size                  # no key in two slots
+    is_tt, _ = orc.cache_lookup(cached, g_tbl, state)
+    assert not is_tt.any()                                          # every cached id still resolves to its row
+    # the reference's one-sweep insert loses some of them on the same input
+    r_tbl, r_freq = tbl.copy(), freq.copy()
+    orc.update_cache_state(later, r_tbl, r_freq)
+    assert orc.cache_lookup(cached, r_tbl, state)[0].any()
+
+
 def test_cache_rowwise_adagrad(ops, orc):
     import ttemb_native as nat
     rng = np.random.default_rng(8)

@@ -152,3 +152,75 @@ def test_no_cpu_fallback():
 def test_optimtype_values():
     assert str(OptimType.SGD) == "sgd" and OptimType("exact_row_wise_adagrad") is OptimType.EXACT_ROWWISE_ADAGRAD
     assert len(OptimType) == 9
+
+
+# ---- initialisers applied by the drivers (tt_utils.py:117-201) ---------------------------------
+
+def _full(cores, p, q, r):
+    from FBTT.tt_embeddings_ops import tt_matrix_to_full
+    return tt_matrix_to_full(p, q, [1] + list(r) + [1], [c for c in cores], [1, 0, 2, 3])
+
+
+@pytest.mark.parametrize("p,q,r", [([6, 5, 4], [2, 3, 2], [4, 3]), ([7, 6], [4, 2], [5]), ([3, 4, 3, 2], [2, 2, 2, 2], [3, 4, 2])])
+def test_tt_svd_recovers_a_tt_matrix(p, q, r):
+    import ttemb_init
+    g = torch.Generator().manual_seed(7)
+    T = len(p)
+    R = [1] + r + [1]
+    truth = [torch.randn(1, p[t], R[t] * q[t] * R[t + 1], generator=g) for t in range(T)]
+    table = _full(truth, p, q, r)
+    cores, ranks = ttemb_init.tt_svd_cores(table, r, p, q)
+    assert ranks == R
+    for t in range(T):
+        assert cores[t].shape == (1, p[t], R[t] * q[t] * R[t + 1]) and cores[t].dtype == torch.float32
+    again = _full(cores, p, q, r)
+    assert (again - table).abs().max().item() < 1e-4 * table.abs().max().item()
+    # the oracle reads the same cores the same way
+    ids = np.arange(int(np.prod(p)))
+    rows = orc.tt_rows(ids, [c.numpy()[0] for c in cores], p, q, R)
+    np.testing.assert_allclose(rows, table.numpy(), atol=1e-4 * float(table.abs().max()))
+
+
+def test_tt_svd_truncation_is_monotone_and_shim_matches():
+    import ttemb_init
+    import tt_utils
+    p, q = [8, 6, 5], [2, 2, 3]
+    table = torch.randn(240, 12, generator=torch.Generator().manual_seed(3))
+    errs = []
+    for rank in (1, 2, 4, 8, 64):
+        cores, ranks = ttemb_init.tt_svd_cores(table, [rank, rank], p, q)
+        errs.append((_full(cores, p, q, ranks[1:-1]) - table).norm().item())
+    assert all(a >= b - 1e-5 for a, b in zip(errs, errs[1:])) and errs[-1] < 1e-3
+    cores, ranks = tt_utils.tt_matrix_decomp(table.numpy(), [1, 4, 4, 1], p, q)   # reference call shape
+    assert ranks == [1, 4, 4, 1] and all(torch.is_tensor(c) and c.device.type == "cpu" for c in cores)
+    assert abs((_full(cores, p, q, [4, 4]) - table).norm().item() - errs[2]) < 1e-3
+
+
+def test_ortho_cores_are_orthonormal_frames():
+    import ttemb_init
+    import tt_utils
+    p, q, r = [12, 14, 48], [4, 5, 5], [8, 8]
+    R = [1] + r + [1]
+    cores = ttemb_init.ortho_cores(r, p, q, generator=torch.Generator().manual_seed(1))
+    for t, c in enumerate(cores):
+        assert c.shape == (1, p[t], R[t] * q[t] * R[t + 1])
+        core4 = c.reshape(p[t], R[t], q[t], R[t + 1]).permute(1, 2, 0, 3).reshape(R[t] * q[t], p[t] * R[t + 1])
+        gram = core4 @ core4.t()
+        assert (gram - torch.eye(gram.shape[0])).abs().max().item() < 1e-5
+    got = tt_utils.get_ortho([1, 8, 8, 1], p, q)
+    assert all(isinstance(c, np.ndarray) and c.dtype == np.float32 for c in got)
+    with pytest.raises(ValueError):
+        ttemb_init.ortho_cores([64, 64], [2, 2, 2], [4, 5, 5])
+
+
+def test_prefix_locality_metric():
+    import ttemb_init
+    p = [125, 140, 140]
+    g = torch.Generator().manual_seed(0)
+    uniform = torch.randperm(2449029, generator=g)[:40960]
+    starts = torch.randint(0, 2449029 - 200, (205,), generator=g)
+    windows = (starts[:, None] + torch.arange(200)[None, :]).reshape(-1)
+    u, w = ttemb_init.prefix_locality(uniform, p), ttemb_init.prefix_locality(windows, p)
+    assert u["ids"] == 40960 and w["ids"] == 41000
+    assert w["distinct_prefixes"] <= 3 * 205 and w["ids_per_prefix"] > 20 * u["ids_per_prefix"]
+    assert ttemb_init.prefix_locality(torch.empty(0, dtype=torch.long), p)["distinct_prefixes"] == 0

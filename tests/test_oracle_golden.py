@@ -111,3 +111,27 @@ def test_cache_lifecycle_oracle():
     assert ntt + (loc[ntt:] >= 0).sum() == idx.shape[0]
     assert sorted(pi.tolist()) == sorted(idx.tolist())
     assert (np.diff(pr[:ntt]) >= 0).all() and (np.diff(pr[ntt:]) <= 0).all()
+
+
+def test_update_after_eviction_reference_vs_find_first():
+    """hashtbl_insert probes and inserts in one sweep (hashtbl_cuda_utils.cuh:102-133): once
+    cache_populate has evicted the entry in front of a displaced cached key, the reference inserts that
+    key a second time and the lookup then lands on the copy with cache_state -1.  The HIP path looks for
+    the key first (oracle: find_first=True); before any eviction the two agree."""
+    H = 64
+    keys = [k for k in range(20000) if orc.murmur_slot(k, H) == 5][:3]
+    a, b, c = keys
+    for find_first in (False, True):
+        tbl, freq = np.full(H, -1, np.int64), np.zeros(H, np.int64)
+        state = np.full(H, -1, np.int32)
+        orc.update_cache_state([a, b, b, b, c, c], tbl, freq, find_first=find_first)
+        assert tbl[5] == a and tbl[6] == b and tbl[7] == c          # same table during warm-up
+        assert freq[5] == 1 and freq[6] == 3 and freq[7] == 2
+        orc.cache_populate(tbl, freq, state, 2)                      # keeps b and c, evicts a
+        assert tbl[5] == -1 and state[6] == 0 and state[7] == 1
+        orc.update_cache_state([c], tbl, freq, find_first=find_first)
+        is_tt, loc = orc.cache_lookup(np.array([c]), tbl, state)
+        if find_first:
+            assert tbl[5] == -1 and freq[7] == 3 and not is_tt[0] and loc[0] == 1
+        else:
+            assert tbl[5] == c and is_tt[0]                          # the cached id fell out of the cache
