@@ -95,10 +95,16 @@ static int64_t grad_scratch_bytes(const DevShape& s) {
   return b;
 }
 
-static bool use_fast3(const DevShape& s, int64_t nnz) {
+static bool use_fast3(const DevShape& s, int64_t nnz, int64_t B) {
   const int path = current_path();
   if (path == TTEMB_PATH_GENERIC || !fast3_supported(s)) return false;
+  if (B * s.D >= (int64_t(1) << 32)) return false;  // the fast kernels address output / gradient rows with 32-bit offsets
   return path == TTEMB_PATH_FAST3 || fast3_pays(s, nnz);
+}
+
+// a plan the fast path's backward will reuse as is (it holds the grouped ids and their rows)
+static bool plan_ready(const DevShape& s, int64_t nnz, int64_t B, const void* plan, int64_t plan_bytes) {
+  return plan != nullptr && use_fast3(s, nnz, B) && plan_bytes >= fast3_plan_bytes(s, nnz);
 }
 
 // rows whose bag length is not 1 must be zero before the lookups accumulate into them
@@ -205,7 +211,7 @@ static int check_lookup_args(const void* cores, const void* indices, int64_t nnz
 // rows of the ids: the caller's rowidx, or (rowidx == NULL) derived from offsets into the head
 // of the workspace; *ws / *ws_bytes are advanced past the part used
 static int resolve_rowidx(const int64_t** rowidx, const int64_t* offsets, int64_t nnz, int64_t B, char** ws,
-                          int64_t* ws_bytes, hipStream_t st) {
+                          int64_t* ws_bytes, hipStream_t st, bool rows_in_plan = false) {
   const int64_t need = align256(nnz * 8);
   char* base = *ws;
   if (base != nullptr && *ws_bytes >= need) {
@@ -216,6 +222,7 @@ static int resolve_rowidx(const int64_t** rowidx, const int64_t* offsets, int64_
   }
   if (*rowidx != nullptr || nnz == 0) return TTEMB_OK;
   if (offsets == nullptr) return fail(TTEMB_E_BADARG, "rowidx and offsets are both null");
+  if (rows_in_plan) return TTEMB_OK;  // a ready plan of the fast path already carries every id's row
   int rc = launch_rowidx(offsets, B, nnz, reinterpret_cast<int64_t*>(base), st);
   *rowidx = reinterpret_cast<const int64_t*>(base);
   return rc;
@@ -223,10 +230,10 @@ static int resolve_rowidx(const int64_t** rowidx, const int64_t* offsets, int64_
 
 // shared body of the three backward entry points: gradient of the live ids into `dst`
 static int backward_into(const DevShape& ds, const CorePtrs& cp, const int64_t* indices,
-                         const int64_t* rowidx, int64_t nnz, const int32_t* nnz_dev,
+                         const int64_t* rowidx, int64_t nnz, const int32_t* nnz_dev, int64_t B,
                          const float* d_output, const CorePtrsMut& dst, void* ws, int64_t ws_bytes,
                          const void* plan, int64_t plan_bytes, hipStream_t st) {
-  if (use_fast3(ds, nnz))
+  if (use_fast3(ds, nnz, B))
     return launch_backward_fast3(ds, cp, indices, rowidx, nnz, nnz_dev, d_output, dst, ws, ws_bytes, plan,
                                  plan_bytes, st);
   if (current_path() == TTEMB_PATH_FAST3) return fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
@@ -272,7 +279,7 @@ int64_t ttemb_workspace_bytes(const ttemb_shape_t* shape, int32_t op, int64_t nn
   DevShape ds;
   int rc = make_dev_shape(shape, &ds);
   if (rc) return rc;
-  const bool f3 = use_fast3(ds, op == TTEMB_OP_CACHE_POPULATE ? B : nnz);
+  const bool f3 = use_fast3(ds, op == TTEMB_OP_CACHE_POPULATE ? B : nnz, B);
   switch (op) {
     case TTEMB_OP_FORWARD:
       return align256(nnz * 8) + (f3 ? fast3_workspace_bytes(ds, op, nnz, B) : 0);
@@ -293,7 +300,7 @@ int64_t ttemb_plan_bytes(const ttemb_shape_t* shape, int64_t nnz) {
   int rc = make_dev_shape(shape, &ds);
   if (rc) return rc;
   if (nnz < 0) return fail(TTEMB_E_BADARG, "negative size");
-  return use_fast3(ds, nnz) ? fast3_plan_bytes(ds, nnz) : 0;
+  return use_fast3(ds, nnz, 0) ? fast3_plan_bytes(ds, nnz) : 0;
 }
 
 int ttemb_forward(const ttemb_shape_t* shape, const float* const* cores, const int64_t* indices,
@@ -324,7 +331,7 @@ int ttemb_forward(const ttemb_shape_t* shape, const float* const* cores, const i
   if (rc || nnz == 0) return rc;
   CorePtrs cp;
   for (int t = 0; t < TTEMB_MAX_CORES; ++t) cp.c[t] = t < ds.T ? cores[t] : nullptr;
-  if (use_fast3(ds, nnz))
+  if (use_fast3(ds, nnz, B))
     return launch_forward_fast3(ds, cp, indices, rowidx, offsets, nnz, nnz_dev, output, workspace, workspace_bytes,
                                 plan, plan_bytes, st);
   if (current_path() == TTEMB_PATH_FAST3) return fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
@@ -355,9 +362,9 @@ int ttemb_backward_dense(const ttemb_shape_t* shape, const float* const* cores,
   char* ws = reinterpret_cast<char*>(workspace);
   int64_t rest = workspace_bytes > skip ? workspace_bytes - skip : 0;
   ws = ws ? ws + skip : nullptr;
-  rc = resolve_rowidx(&rowidx, offsets, nnz, B, &ws, &rest, st);
+  rc = resolve_rowidx(&rowidx, offsets, nnz, B, &ws, &rest, st, plan_ready(ds, nnz, B, plan, plan_bytes));
   if (rc) return rc;
-  return backward_into(ds, cp, indices, rowidx, nnz, nnz_dev, d_output, dp, ws, rest, plan, plan_bytes, st);
+  return backward_into(ds, cp, indices, rowidx, nnz, nnz_dev, B, d_output, dp, ws, rest, plan, plan_bytes, st);
 }
 
 static int fused_backward(const ttemb_shape_t* shape, float* const* cores, float* const* opt_state,
@@ -390,9 +397,9 @@ static int fused_backward(const ttemb_shape_t* shape, float* const* cores, float
   }
   char* rest_ws = ws + off;
   int64_t rest = workspace_bytes - off;
-  rc = resolve_rowidx(&rowidx, offsets, nnz, B, &rest_ws, &rest, st);
+  rc = resolve_rowidx(&rowidx, offsets, nnz, B, &rest_ws, &rest, st, plan_ready(ds, nnz, B, plan, plan_bytes));
   if (rc) return rc;
-  rc = backward_into(ds, cp, indices, rowidx, nnz, nnz_dev, d_output, gp, rest_ws, rest, plan, plan_bytes, st);
+  rc = backward_into(ds, cp, indices, rowidx, nnz, nnz_dev, B, d_output, gp, rest_ws, rest, plan, plan_bytes, st);
   if (rc) return rc;
   Seg3 seg;
   memset(&seg, 0, sizeof(seg));

@@ -59,7 +59,12 @@ struct Cfg {
   static constexpr int B_FLOATS = kChunk * LDB;
   static constexpr int O_FLOATS = kChunk * LDO;
   // the output rows reuse the staged-G2 region (every G2 read precedes every row write)
-  static constexpr int PB_FLOATS = ((M2 * LDA + 3) / 4) * 4;  // backward reads only the M2 real rows of P
+  // backward chunk kernel: ds_read_b32 banks are (addr/4) mod 32 per 32-lane half (lane groups hi = {0,1} and
+  // {2,3}), so the stride between the two `hi` rows of an operand must be 16 mod 32 for a conflict-free read
+  static constexpr int LDPB = (R2 % 32 == 0) ? R2 + 16 : R2;                            // P rows, read as [4s+hi][lo]
+  static constexpr int LDBB = (Q2 % 2 == 1 && ROW2 % 32 == 16) ? ROW2 : ROW2 + 4;       // G2 rows, read as [hi][lo*q2+kk]
+  static constexpr int BB2_FLOATS = kChunk * LDBB;
+  static constexpr int PB_FLOATS = ((M2 * LDPB + 3) / 4) * 4;  // backward reads only the M2 real rows of P
   static constexpr int BO_FLOATS = B_FLOATS > O_FLOATS ? B_FLOATS : O_FLOATS;
   static constexpr int WAVE_FLOATS = P_FLOATS + BO_FLOATS;
   // backward: [P | staged G2 rows, later dP | staged d_output rows, later G1[i1]]
@@ -199,7 +204,7 @@ __global__ __launch_bounds__(64 * TTEMB_FWD_WAVES) void fast3_forward_kernel(
       const int b = f / F4G, c4 = f - b * F4G;
       const uint32_t row2 = __shfl(c.i2, b < kChunk ? b : 0, kWave);
       pre_g[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (f < kChunk * F4G) pre_g[it] = *reinterpret_cast<const float4*>(G2 + (size_t)row2 * C::ROW2 + 4 * c4);
+      if (f < kChunk * F4G) pre_g[it] = *reinterpret_cast<const float4*>(G2 + (row2 * (uint32_t)C::ROW2 + 4u * c4));
     }
   };
 
@@ -304,7 +309,7 @@ __global__ __launch_bounds__(64 * TTEMB_FWD_WAVES) void fast3_forward_kernel(
       const uint32_t v = __shfl(val, b < kChunk ? b : 0, kWave);
       if (f < kChunk * D4 && b < len) {
         const float4 x = *reinterpret_cast<const float4*>(obuf + b * C::LDO + 4 * c4);
-        float* dst = out + (size_t)(v & ~kMultiBit) * C::D + 4 * c4;
+        float* dst = out + ((v & ~kMultiBit) * (uint32_t)C::D + 4u * c4);  // B*D < 2^32: checked on the host
         if (v & kMultiBit) {
           atomicAdd(dst + 0, x.x);
           atomicAdd(dst + 1, x.y);
@@ -345,7 +350,7 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(
   const int hi = lane >> 4, lo = lane & 15;
   float* pbuf = smem;
   float* bbuf = pbuf + C::PB_FLOATS;  // staged G2 rows
-  float* dbuf = bbuf + C::B_FLOATS;   // staged d_output rows, later the chunk's E rows
+  float* dbuf = bbuf + C::BB2_FLOATS; // staged d_output rows
 
   // A wavefront owns the groups that START inside its 64-id window [begin, end): it skips a
   // leading group that began earlier and follows its last group past `end`, so every group is
@@ -376,7 +381,7 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(
     offA[mt] = hi * C::LDO + m * Q2;
   }
 #pragma unroll
-  for (int t = 0; t < C::RT2; ++t) offB[t] = hi * C::LDB + ((16 * t + lo) % R2) * Q2;
+  for (int t = 0; t < C::RT2; ++t) offB[t] = hi * C::LDBB + ((16 * t + lo) % R2) * Q2;
 #pragma unroll
   for (int nt = 0; nt < C::NT2; ++nt) {
     const int col = 16 * nt + lo;
@@ -446,7 +451,7 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(
       const int b = f / F4G, c4 = f - b * F4G;
       const uint32_t row2 = __shfl(c.i2, b < kChunk ? b : 0, kWave);
       pre_g[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (f < kChunk * F4G) pre_g[it] = *reinterpret_cast<const float4*>(G2 + (size_t)row2 * C::ROW2 + 4 * c4);
+      if (f < kChunk * F4G) pre_g[it] = *reinterpret_cast<const float4*>(G2 + (row2 * (uint32_t)C::ROW2 + 4u * c4));
     }
 #pragma unroll
     for (int it = 0; it < NLD; ++it) {
@@ -455,7 +460,11 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(
       const uint32_t v = __shfl(c.val, b < kChunk ? b : 0, kWave);
       pre_d[it] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (f < kChunk * F4D && b < c.len)
-        pre_d[it] = *reinterpret_cast<const float4*>(d_out + (size_t)(v & ~kMultiBit) * C::D + 4 * c4);
+#if defined(TTEMB_ABL) && (TTEMB_ABL & 2)
+        pre_d[it] = *reinterpret_cast<const float4*>(d_out + ((v & 1023u) * (uint32_t)C::D + 4u * c4));  // ablation: cache-resident rows
+#else
+        pre_d[it] = *reinterpret_cast<const float4*>(d_out + ((v & ~kMultiBit) * (uint32_t)C::D + 4u * c4));  // B*D < 2^32: checked on the host
+#endif
     }
   };
 
@@ -474,6 +483,7 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(
       const uint32_t i0 = cur_group - i1 * p0;
       const float* g0 = G0 + (size_t)i0 * C::ROW0;
       const float* g1 = G1 + (size_t)i1 * C::ROW1;
+#if !(defined(TTEMB_ABL) && (TTEMB_ABL & 16))
       f32x4 acc[C::NT1];
 #pragma unroll
       for (int nt = 0; nt < C::NT1; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -494,16 +504,17 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int a = 4 * hi + r;
-          if (a < Q0) pbuf[(a * Q1 + j) * C::LDA + c2] = acc[nt][r];
+          if (a < Q0) pbuf[(a * Q1 + j) * C::LDPB + c2] = acc[nt][r];
         }
       }
+#endif
     }
     // ---- the chunk's rows: registers -> LDS ----
 #pragma unroll
     for (int it = 0; it < NLG; ++it) {
       const int f = it * kWave + lane;
       const int b = f / F4G, c4 = f - b * F4G;
-      if (f < kChunk * F4G) *reinterpret_cast<float4*>(bbuf + b * C::LDB + 4 * c4) = pre_g[it];
+      if (f < kChunk * F4G) *reinterpret_cast<float4*>(bbuf + b * C::LDBB + 4 * c4) = pre_g[it];
     }
 #pragma unroll
     for (int it = 0; it < NLD; ++it) {
@@ -523,6 +534,7 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_sched_barrier(0);
 
+#if !(defined(TTEMB_ABL) && (TTEMB_ABL & 4))
     // ---- dP += dO (q0q1 x 16 q2) . G2s^T (16 q2 x r2) ----
 #pragma unroll
     for (int b4 = 0; b4 < kChunk / 4; ++b4)
@@ -533,7 +545,7 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(
         for (int mt = 0; mt < C::MT2; ++mt) av[mt] = dbuf[offA[mt] + b4 * 4 * C::LDO + kk];
 #pragma unroll
         for (int t = 0; t < C::RT2; ++t) {
-          bv[t] = bbuf[offB[t] + b4 * 4 * C::LDB + kk];
+          bv[t] = bbuf[offB[t] + b4 * 4 * C::LDBB + kk];
           if (16 * t + lo >= R2) bv[t] = 0.f;
         }
 #pragma unroll
@@ -544,18 +556,20 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(
         if (kk == Q2 - 1) __builtin_amdgcn_sched_barrier(0);  // keeps operand loads from piling up in registers
       }
 
+#endif
     // ---- E = P^T (r2 x q0q1) . dO (q0q1 x 16 q2) ----
     f32x4 e[C::RT2][C::NT2];
 #pragma unroll
     for (int t = 0; t < C::RT2; ++t)
 #pragma unroll
       for (int nt = 0; nt < C::NT2; ++nt) e[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#if !(defined(TTEMB_ABL) && (TTEMB_ABL & 8))
 #pragma unroll
     for (int s = 0; s < C::M2 / 4; ++s) {
       float av[C::RT2];
 #pragma unroll
       for (int t = 0; t < C::RT2; ++t) {
-        av[t] = pbuf[(4 * s + hi) * C::LDA + (16 * t + lo) % R2];
+        av[t] = pbuf[(4 * s + hi) * C::LDPB + (16 * t + lo) % R2];
         if (16 * t + lo >= R2) av[t] = 0.f;
       }
 #pragma unroll
@@ -567,34 +581,30 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();  // every dO read is done: the region now takes the E rows
-    // E accumulators (row c2 = 16 t + 4 hi + r, col 16 nt + lo) -> LDS [id][c2 * q2 + kk]
+#endif
+    // E leaves straight from the accumulators.  Lane (hi, lo) holds E[c2 = 16 t + 4 hi + r][col = 16 nt + lo]
+    // with col = id * q2 + kk, and the E table keeps an id's row as [kk][c2] (the reduce kernel sums rows
+    // element by element, the finalize kernel puts dG2 back into [c2][kk]): the chunk's rows are then one
+    // contiguous block indexed col * r2 + c2, and the 64 lanes of one (t, nt) write 16-byte pieces of it.
+    {
+      float* dst = plan.etab + (size_t)here * C::ROW2;
 #pragma unroll
-    for (int nt = 0; nt < C::NT2; ++nt) {
-      const int col = 16 * nt + lo;
-      const int b = col / Q2, kk = col % Q2;
+      for (int nt = 0; nt < C::NT2; ++nt) {
+        const int col = 16 * nt + lo;
 #pragma unroll
-      for (int t = 0; t < C::RT2; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int c2 = 16 * t + 4 * hi + r;
-          if (c2 < R2) dbuf[b * C::LDB + c2 * Q2 + kk] = e[t][nt][r];
+        for (int t = 0; t < C::RT2; ++t) {
+          const int c2 = 16 * t + 4 * hi;
+#if defined(TTEMB_ABL) && (TTEMB_ABL & 1)
+          if (col < len * Q2 && c2 < R2 && e[t][nt][0] == 123.456f)   // ablation: no E traffic
+#else
+          if (col < len * Q2 && c2 < R2)
+#endif
+            *reinterpret_cast<float4*>(dst + col * R2 + c2) = make_float4(e[t][nt][0], e[t][nt][1], e[t][nt][2], e[t][nt][3]);
         }
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-    for (int it = 0; it < NLG; ++it) {
-      const int f = it * kWave + lane;
-      const int b = f / F4G, c4 = f - b * F4G;
-      if (f < kChunk * F4G && b < len)  // the chunk's rows are consecutive in the table
-        *reinterpret_cast<float4*>(plan.etab + (size_t)(here + b) * C::ROW2 + 4 * c4) =
-            *reinterpret_cast<const float4*>(dbuf + b * C::LDB + 4 * c4);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_wave_barrier();  // every LDS read of this chunk is done before the next rows land
   }
   if (cur_group != 0xffffffffu) store_dp();
 }
@@ -828,7 +838,7 @@ __global__ __launch_bounds__(64) void fast3_group_epilogue_kernel(
 // rows split the terms, so every load instruction reads 128 contiguous bytes per row and many
 // are in flight; the 8 partial sums meet in LDS.  Every output is written exactly once.
 __global__ __launch_bounds__(256) void fast3_finalize_kernel(GroupPlan plan, int tiles, int p0, int p1,
-                                                             int g2_floats, int row0,
+                                                             int g2_floats, int row0, int q2, int r2,
                                                              float* __restrict__ dG0, float* __restrict__ dG2) {
   __shared__ float part[8][33];
   const int x = threadIdx.x & 31, y = threadIdx.x >> 5;
@@ -851,8 +861,14 @@ __global__ __launch_bounds__(256) void fast3_finalize_kernel(GroupPlan plan, int
     float tot = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) tot += part[k][x];
-    if (e < g2_floats) dG2[e] = tot;
-    else if (e < g2_floats + n0) dG0[e - g2_floats] = tot;
+    if (e < g2_floats) {  // the slabs hold rows as [kk][c2] (see fast3_bwd_chunk_kernel); dG2 rows are [c2][kk]
+      const int row2 = q2 * r2;
+      const int i2 = e / row2, w = e - i2 * row2;
+      const int kk = w / r2, c2 = w - kk * r2;
+      dG2[i2 * row2 + c2 * q2 + kk] = tot;
+    } else if (e < g2_floats + n0) {
+      dG0[e - g2_floats] = tot;
+    }
   }
 }
 
@@ -1027,7 +1043,7 @@ static int run_backward(const DevShape& s, const CorePtrs& cores, const GroupPla
                         const int32_t* nnz_dev, const float* d_output, const CorePtrsMut& d_cores,
                         hipStream_t st) {
   using C = Cfg<Q0, Q1, Q2, R1, R2>;
-  const size_t lds = (size_t)(C::PB_FLOATS + C::B_FLOATS + C::O_FLOATS) * sizeof(float);
+  const size_t lds = (size_t)(C::PB_FLOATS + C::BB2_FLOATS + C::O_FLOATS) * sizeof(float);
   const unsigned ranges = (unsigned)((nnz + kRange - 1) / kRange);
   profile_begin(1, st);
   profile_begin(2, st);
@@ -1050,7 +1066,7 @@ static int run_backward(const DevShape& s, const CorePtrs& cores, const GroupPla
     const int g2_floats = s.p[2] * C::ROW2;
     const int outs = g2_floats + s.p[0] * C::ROW0;
     hipLaunchKernelGGL(fast3_finalize_kernel, dim3((unsigned)((outs + 31) / 32)), dim3(256), 0, st, plan, tiles,
-                       s.p[0], s.p[1], g2_floats, (int)C::ROW0, d_cores.c[0], d_cores.c[2]);
+                       s.p[0], s.p[1], g2_floats, (int)C::ROW0, Q2, R2, d_cores.c[0], d_cores.c[2]);
   }
   profile_end(1, st);
   return check_hip(hipGetLastError(), "fast3_finalize_kernel");
