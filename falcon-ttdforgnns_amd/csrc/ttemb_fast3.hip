@@ -22,21 +22,15 @@
 #include <cstring>
 
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 
 namespace ttemb {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#ifndef TTEMB_FWD_VARIANT
-#define TTEMB_FWD_VARIANT 0
-#endif
-#ifndef TTEMB_FWD_WAVES
-#define TTEMB_FWD_WAVES 1   // wavefronts per forward workgroup (each is independent)
-#endif
 
 constexpr int kChunk = 16;        // ids per stage-2 GEMM (N = 16 * q2 columns)
-constexpr int kRange = 64;        // sorted ids walked by one wavefront
 constexpr uint32_t kMultiBit = 0x80000000u;
 
 template <int Q0, int Q1, int Q2, int R1, int R2>
@@ -64,6 +58,8 @@ struct Cfg {
   static constexpr int LDPB = (R2 % 32 == 0) ? R2 + 16 : R2;                            // P rows, read as [4s+hi][lo]
   static constexpr int LDBB = (Q2 % 2 == 1 && ROW2 % 32 == 16) ? ROW2 : ROW2 + 4;       // G2 rows, read as [hi][lo*q2+kk]
   static constexpr int BB2_FLOATS = kChunk * LDBB;
+  static constexpr int LDOB = ((D + 15) / 32) * 32 + 16;                                // d_output rows, read as [hi][m*q2+kk]
+  static constexpr int OB_FLOATS = kChunk * LDOB;
   static constexpr int PB_FLOATS = ((M2 * LDPB + 3) / 4) * 4;  // backward reads only the M2 real rows of P
   static constexpr int BO_FLOATS = B_FLOATS > O_FLOATS ? B_FLOATS : O_FLOATS;
   static constexpr int WAVE_FLOATS = P_FLOATS + BO_FLOATS;
@@ -83,25 +79,34 @@ struct Cfg {
 };
 
 // ---------------------------------------------------------------------------------
-// Grouping pass: a counting sort of the live ids by group' = i1 * p0 + i0 (three small
-// kernels; rocprim's radix/merge sort needs ~20 launches and > 100 us at these sizes).
+// Grouping pass: a counting sort of the live ids by group' = i1 * p0 + i0, cut into chunks
+// (three small kernels; rocprim's radix/merge sort needs ~20 launches and > 100 us at these sizes).
 //   key   = (i1 * p0 + i0) * p2 + i2   -- the id with its digits reordered: ids of one
 //           (i0, i1) group end up adjacent, and consecutive groups share i1;
 //   value = output row | kMultiBit when the bag holds several ids.
-// One returning atomic per id (its arrival rank inside the group) in the first kernel, a
-// rocPRIM exclusive scan of the group sizes, and an atomic-free scatter.  The order of ids inside a group is arrival order: every
-// consumer is insensitive to it except for fp32 summation order in the backward.
+// One returning atomic per id (its arrival rank inside the group) in the first kernel, ONE rocPRIM
+// exclusive scan that carries two running sums in a 64-bit word (ids before the group | chunks before
+// the group), and an atomic-free scatter.  The scatter also writes the *chunk table*: a chunk is <= 16
+// consecutive ids of one group, and its 16-byte descriptor {position, group, length | flags, first chunk
+// of the next group} is all the chain kernels need to walk the grouped ids -- they read descriptors with
+// scalar loads and never decode a key, compare neighbours or shuffle.  The order of ids inside a
+// group is arrival order: every consumer is insensitive to it except for fp32 summation order in
+// the backward.
 // ---------------------------------------------------------------------------------
 constexpr int kTile = 256;   // threads per workgroup in the grouping kernels
+constexpr uint32_t kFirstBit = 0x100u, kLastBit = 0x200u;   // flags next to a chunk's length
 
-struct GroupPlan {           // device pointers into the caller's workspace
+struct GroupPlan {           // device pointers into the caller's plan buffer / workspace
   uint32_t* keys_in;         // [nnz] ungrouped keys
   uint32_t* vals_in;
   uint32_t* rank_in;         // arrival rank of the id inside its group
-  uint32_t* keys;            // [nnz] grouped
-  uint32_t* vals;
+  uint32_t* i2s;             // [nnz] grouped: last index digit of the id
+  uint32_t* vals;            // [nnz] grouped: output row | kMultiBit
   uint32_t* counts;          // [G+1] ids per group (entry G stays 0)
-  uint32_t* gstart;          // [G+1] first grouped position of each group; [G] = live ids
+  uint64_t* gpre;            // [G+1] low word: first grouped position of the group; high word: its first chunk.
+                             //       entry G = (live ids, chunks)
+  uint4* ctab;               // [max_chunks] chunk descriptors
+  float* ptab;               // [G][M2*R2] prefix product P = G0[i0] . G1[i1] of every non-empty group
   float* etab;               // [nnz][ROW2] dG2 contribution rows, in grouped order
   float* dptab;              // [G][M2*R2] dP of every non-empty group
   float* g2part;             // [tiles][p2][ROW2] per-tile partial dG2
@@ -131,139 +136,194 @@ __global__ __launch_bounds__(kTile) void fast3_prep_kernel(
   plan.rank_in[n] = atomicAdd(&plan.counts[group], 1u);
 }
 
+// what the scan adds up per group: ids in the low word, chunks of <= kChunk ids in the high word
+struct PackCounts {
+  __host__ __device__ uint64_t operator()(uint32_t c) const {
+    return (uint64_t)c | ((uint64_t)((c + kChunk - 1) / kChunk) << 32);
+  }
+};
+
 __global__ __launch_bounds__(kTile) void fast3_scatter_kernel(int64_t nnz, const int32_t* __restrict__ nnz_dev,
                                                               uint32_t p2, GroupPlan plan) {
   const int64_t n = (int64_t)blockIdx.x * kTile + threadIdx.x;
   if (n >= live_count(nnz, nnz_dev)) return;
   const uint32_t key = plan.keys_in[n];
-  const uint32_t dst = plan.gstart[key / p2] + plan.rank_in[n];
-  plan.keys[dst] = key;
+  const uint32_t g = key / p2;
+  const uint32_t rank = plan.rank_in[n];
+  const uint64_t pre = plan.gpre[g];
+  const uint32_t dst = (uint32_t)pre + rank;
+  plan.i2s[dst] = key - g * p2;
   plan.vals[dst] = plan.vals_in[n];
+  if (rank % kChunk == 0) {  // this id opens a chunk of its group: it writes the descriptor
+    const uint32_t c = plan.counts[g];
+    const uint32_t chunks = (c + kChunk - 1) / kChunk, k = rank / kChunk;
+    const uint32_t first_chunk = (uint32_t)(pre >> 32);
+    const uint32_t len = c - rank < (uint32_t)kChunk ? c - rank : (uint32_t)kChunk;
+    plan.ctab[first_chunk + k] = make_uint4(dst, g, len | (k == 0 ? kFirstBit : 0u) | (k + 1 == chunks ? kLastBit : 0u),
+                                            first_chunk + chunks);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Prefix products: P[g] = G0[i0] . G1[i1]  (q0 x q1 r2, kept as a (q0 q1) x r2 matrix) for every
+// non-empty group, once per call, into a table the chain kernels read like any other operand.
+// (Computing P inside the chain kernels put ~24 dependent-latency core-row loads, 20 MFMAs and an
+// LDS round trip on the critical path of every group: 22 us of an 80 us forward.)  One wavefront
+// holds G1[i1] as MFMA B operands in registers and walks kPrefixGroups values of i0, 16/q0 groups
+// per MFMA tile (the tile's 16 rows are the q0 rows of those groups).
+// ---------------------------------------------------------------------------------
+constexpr int kPrefixGroups = 32;
+template <int Q0, int Q1, int Q2, int R1, int R2>
+__global__ __launch_bounds__(64) void fast3_prefix_kernel(const float* __restrict__ G0, const float* __restrict__ G1,
+                                                          uint32_t p0, GroupPlan plan) {
+  using C = Cfg<Q0, Q1, Q2, R1, R2>;
+  constexpr int GM = 16 / Q0;  // groups per MFMA tile
+  static_assert(16 % Q0 == 0, "q0 must divide the MFMA tile height");
+  const int lane = threadIdx.x, hi = lane >> 4, lo = lane & 15;
+  const uint32_t i1 = blockIdx.y;
+  const uint32_t i0_begin = blockIdx.x * kPrefixGroups;
+  const uint32_t i0_end = i0_begin + kPrefixGroups < p0 ? i0_begin + kPrefixGroups : p0;
+  // any work at all?  (one lane per i0 of the slice)
+  const uint32_t my = i0_begin + lane;
+  const bool mine = lane < kPrefixGroups && my < i0_end && plan.counts[i1 * p0 + my] != 0;
+  const unsigned long long live = __ballot(mine);
+  if (!live) return;
+  const float* g1 = G1 + (size_t)i1 * C::ROW1;
+  float bv[C::KS1][C::NT1];
+#pragma unroll
+  for (int s = 0; s < C::KS1; ++s)
+#pragma unroll
+    for (int nt = 0; nt < C::NT1; ++nt) bv[s][nt] = g1[(4 * s + hi) * C::N1 + 16 * nt + lo];
+  for (uint32_t base = 0; base < (uint32_t)kPrefixGroups; base += GM) {
+    if (!((live >> base) & ((1ull << GM) - 1))) continue;  // none of these groups holds an id
+    const uint32_t i0a = i0_begin + base + lo / Q0;         // A operand: row lo = (group lo / q0, core row lo % q0)
+    float av[C::KS1];
+#pragma unroll
+    for (int s = 0; s < C::KS1; ++s)
+      av[s] = i0a < i0_end ? G0[(size_t)i0a * C::ROW0 + (lo % Q0) * R1 + 4 * s + hi] : 0.f;
+    f32x4 acc[C::NT1];
+#pragma unroll
+    for (int nt = 0; nt < C::NT1; ++nt) {
+      acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < C::KS1; ++s) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s][nt], acc[nt], 0, 0, 0);
+    }
+    // accumulator row 4 hi + r = (group (4 hi + r) / q0, core row a = (4 hi + r) % q0), column n = 16 nt + lo = (j, c2)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * hi + r;
+      const uint32_t gi = base + row / Q0;
+      const int a = row % Q0;
+      if (!((live >> gi) & 1ull)) continue;
+      float* dst = plan.ptab + (size_t)(i1 * p0 + i0_begin + gi) * (C::M2 * R2);
+#pragma unroll
+      for (int nt = 0; nt < C::NT1; ++nt) {
+        const int n = 16 * nt + lo;
+        dst[(a * Q1 + n / R2) * R2 + n % R2] = acc[nt][r];
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------
 // forward
+//
+// One wavefront takes kCPW consecutive chunk descriptors.  Everything it needs for a chunk is known two
+// steps ahead, so the loop is a software pipeline with no data-dependent control flow: while chunk c is
+// multiplied, the G2 rows (and, when c+1 opens a group, the prefix product) of chunk c+1 are in flight
+// into registers and the (i2, row) pairs of chunk c+2 are being fetched.  Lanes are tied to ids four by
+// four (lane = 4 * id + piece): a lane loads the pieces j, j+4, ... of "its" id's rows and later stores
+// the same pieces of its output row, so no lane ever needs another lane's index.
 // ---------------------------------------------------------------------------------
+#ifndef TTEMB_CPW
+#define TTEMB_CPW 6
+#endif
+constexpr int kCPW = TTEMB_CPW;   // chunks per wavefront
+
 template <int Q0, int Q1, int Q2, int R1, int R2>
-__global__ __launch_bounds__(64 * TTEMB_FWD_WAVES) void fast3_forward_kernel(
-    const float* __restrict__ G0, const float* __restrict__ G1, const float* __restrict__ G2,
-    const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, int64_t nnz,
-    const int32_t* __restrict__ nnz_dev, uint32_t p0, uint32_t p2, float* __restrict__ out) {
+__global__ __launch_bounds__(64) void fast3_forward_kernel(const float* __restrict__ G2, GroupPlan plan, uint32_t G,
+                                                           float* __restrict__ out) {
   using C = Cfg<Q0, Q1, Q2, R1, R2>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x;
   const int hi = lane >> 4, lo = lane & 15;
-  float* pbuf = smem + wave * C::WAVE_FLOATS;
+  const int b_l = lane >> 2, j_l = lane & 3;   // this lane's id inside a chunk, and which pieces of its rows
+  float* pbuf = smem;
   float* bbuf = pbuf + C::P_FLOATS;
   float* obuf = bbuf;
 
-  const int64_t cnt = live_count(nnz, nnz_dev);
-  const int64_t begin = ((int64_t)blockIdx.x * TTEMB_FWD_WAVES + wave) * kRange;
-  if (begin >= cnt) return;
-  const int range = (int)(begin + kRange < cnt ? kRange : cnt - begin);
-  // the whole window's (group, i2, value) triples live in registers: one lane per grouped id
-  uint32_t grp_r = 0xffffffffu, i2_r = 0, val_r = 0;
-  if (lane < range) {
-    const uint32_t key = keys[begin + lane];
-    grp_r = key / p2;
-    i2_r = key - grp_r * p2;
-    val_r = vals[begin + lane];
-  }
+  const uint32_t nchunks = (uint32_t)(plan.gpre[G] >> 32);
+  const uint32_t c0 = blockIdx.x * kCPW;
+  if (c0 >= nchunks) return;
+  const uint32_t c1 = c0 + kCPW < nchunks ? c0 + kCPW : nchunks;
 
-  constexpr int F4G = C::ROW2 / 4, NLG = (kChunk * F4G + kWave - 1) / kWave;
-  constexpr int D4 = C::D / 4, NLO = (kChunk * D4 + kWave - 1) / kWave;
-  struct Chunk {
-    int len;
-    uint32_t group, i2, val;
+  constexpr int F4G = C::ROW2 / 4, NLG = (F4G + 3) / 4;     // float4 pieces of a G2 row / per lane
+  constexpr int D4 = C::D / 4, NLO = (D4 + 3) / 4;          // float4 pieces of an output row / per lane
+  constexpr int PF = C::M2 * R2, NLP = (PF + kWave - 1) / kWave;
+  const uint4 none = make_uint4(0u, 0u, 0u, 0u);
+
+  auto fetch_meta = [&](const uint4& d, uint32_t& i2, uint32_t& val) {
+    i2 = 0u;  // row 0 stands in for unused slots
+    val = 0u;
+    if (b_l < (int)(d.z & 0xffu)) {
+      i2 = plan.i2s[d.x + b_l];
+      val = plan.vals[d.x + b_l];
+    }
   };
-  // chunk = leading run (<= 16) of ids that share the group of the id at `at`
-  auto discover = [&](int at) {
-    Chunk c;
-    c.len = 0;
-    c.group = 0xffffffffu;
-    c.i2 = 0;
-    c.val = 0;
-    if (at >= range) return c;
-    const uint32_t g = __shfl(grp_r, (at + lo) & 63, kWave);
-    c.val = __shfl(val_r, (at + lo) & 63, kWave);
-    c.group = __shfl(grp_r, at, kWave);
-    const unsigned long long same = __ballot(hi == 0 && at + lo < range && g == c.group);
-    c.len = __builtin_ctzll(~same);
-    const uint32_t i2 = __shfl(i2_r, (at + lo) & 63, kWave);
-    c.i2 = lo < c.len ? i2 : 0u;  // row 0 stands in for unused slots
-    return c;
-  };
-  // the chunk's G2 rows are requested one chunk ahead (registers), so their L2 latency hides
-  // behind the previous chunk's MFMAs
   float4 pre_g[NLG];
-  auto request_rows = [&](const Chunk& c) {
+  float pre_p[NLP];
+  auto request = [&](const uint4& d, uint32_t i2, bool with_p) {
+    const float* row = G2 + i2 * (uint32_t)C::ROW2;
 #pragma unroll
-    for (int it = 0; it < NLG; ++it) {
-      const int f = it * kWave + lane;
-      const int b = f / F4G, c4 = f - b * F4G;
-      const uint32_t row2 = __shfl(c.i2, b < kChunk ? b : 0, kWave);
-      pre_g[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (f < kChunk * F4G) pre_g[it] = *reinterpret_cast<const float4*>(G2 + (row2 * (uint32_t)C::ROW2 + 4u * c4));
+    for (int k = 0; k < NLG; ++k) {
+      const int idx = j_l + 4 * k;
+      pre_g[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (F4G % 4 == 0 || idx < F4G) pre_g[k] = *reinterpret_cast<const float4*>(row + 4 * idx);
+    }
+    if (with_p) {
+      const float* p = plan.ptab + (size_t)d.y * PF;
+#pragma unroll
+      for (int it = 0; it < NLP; ++it) {
+        const int e = it * kWave + lane;
+        pre_p[it] = (PF % kWave == 0 || e < PF) ? p[e] : 0.f;
+      }
     }
   };
 
-  uint32_t cur_group = 0xffffffffu;
-  int pos = 0;
-  Chunk cur = discover(pos);
-  if (cur.len) request_rows(cur);
-  while (cur.len) {
-    // ---- stage 1 (once per group): P = G0[i0] . G1[i1] -> LDS ----
-    if (cur.group != cur_group) {
-      cur_group = cur.group;
-      const uint32_t i1 = cur_group / p0;
-      const uint32_t i0 = cur_group - i1 * p0;
-      const float* g0 = G0 + (size_t)i0 * C::ROW0;
-      const float* g1 = G1 + (size_t)i1 * C::ROW1;
-      f32x4 acc[C::NT1];
+  uint4 d_cur = plan.ctab[c0];
+  uint4 d_nxt = c0 + 1 < c1 ? plan.ctab[c0 + 1] : none;
+  uint32_t i2_cur, val_cur, i2_nxt = 0u, val_nxt = 0u;
+  fetch_meta(d_cur, i2_cur, val_cur);
+  request(d_cur, i2_cur, true);
+  if (c0 + 1 < c1) fetch_meta(d_nxt, i2_nxt, val_nxt);
+
+  for (uint32_t c = c0; c < c1; ++c) {
+    const int len = (int)(d_cur.z & 0xffu);
+    // ---- the prefix product of a new group -> LDS, as a (q0 q1) x r2 matrix ----
+    if (c == c0 || (d_cur.z & kFirstBit)) {
 #pragma unroll
-      for (int s = 0; s < C::KS1; ++s) {
-        const int k = 4 * s + hi;
-        const float a = lo < Q0 ? g0[lo * R1 + k] : 0.f;
-#pragma unroll
-        for (int nt = 0; nt < C::NT1; ++nt) {
-          const float b = g1[k * C::N1 + 16 * nt + lo];
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, s == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[nt], 0, 0, 0);
-        }
-      }
-      // accumulator (row 4*hi + r, col 16*nt + lo) -> P as a (q0 q1) x r2 matrix
-#pragma unroll
-      for (int nt = 0; nt < C::NT1; ++nt) {
-        const int n = 16 * nt + lo;
-        const int j = n / R2, c2 = n % R2;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int a = 4 * hi + r;
-          if (a < Q0) pbuf[(a * Q1 + j) * C::LDA + c2] = acc[nt][r];
-        }
+      for (int it = 0; it < NLP; ++it) {
+        const int e = it * kWave + lane;
+        if (PF % kWave == 0 || e < PF) pbuf[(e / R2) * C::LDA + e % R2] = pre_p[it];
       }
     }
     // ---- the chunk's G2 rows: registers -> LDS ----
 #pragma unroll
-    for (int it = 0; it < NLG; ++it) {
-      const int f = it * kWave + lane;
-      const int b = f / F4G, c4 = f - b * F4G;
-      if (f < kChunk * F4G) *reinterpret_cast<float4*>(bbuf + b * C::LDB + 4 * c4) = pre_g[it];
+    for (int k = 0; k < NLG; ++k) {
+      const int idx = j_l + 4 * k;
+      if (F4G % 4 == 0 || idx < F4G) *reinterpret_cast<float4*>(bbuf + b_l * C::LDB + 4 * idx) = pre_g[k];
     }
-#if TTEMB_FWD_VARIANT != 1
     __builtin_amdgcn_sched_barrier(0);
-#endif
-    const int len = cur.len;
-    const uint32_t val = cur.val;
-    pos += len;
-    cur = discover(pos);
-    if (cur.len) request_rows(cur);
+    // ---- next chunk's rows and the chunk after's indices go out now; they land while this one computes ----
+    const uint32_t val = val_cur;
+    const uint4 d_nn = c + 2 < c1 ? plan.ctab[c + 2] : none;
+    if (c + 1 < c1) request(d_nxt, i2_nxt, (d_nxt.z & kFirstBit) != 0u);
+    uint32_t i2_nn = 0u, val_nn = 0u;
+    if (c + 2 < c1) fetch_meta(d_nn, i2_nn, val_nn);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#if TTEMB_FWD_VARIANT != 1
     __builtin_amdgcn_sched_barrier(0);
-#endif
 
     // ---- stage 2: (q0 q1 x r2) . (r2 x 16 q2), one 16-row tile of P at a time ----
     float bv[C::KS2][C::NT2];
@@ -301,75 +361,74 @@ __global__ __launch_bounds__(64 * TTEMB_FWD_WAVES) void fast3_forward_kernel(
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ---- 16-byte global stores of whole rows ----
+    // ---- 16-byte global stores: four lanes per row ----
+    if (b_l < len) {
+      float* dst = out + (val & ~kMultiBit) * (uint32_t)C::D;  // B*D < 2^32: checked on the host
 #pragma unroll
-    for (int it = 0; it < NLO; ++it) {
-      const int f = it * kWave + lane;
-      const int b = f / D4, c4 = f - b * D4;
-      const uint32_t v = __shfl(val, b < kChunk ? b : 0, kWave);
-      if (f < kChunk * D4 && b < len) {
-        const float4 x = *reinterpret_cast<const float4*>(obuf + b * C::LDO + 4 * c4);
-        float* dst = out + ((v & ~kMultiBit) * (uint32_t)C::D + 4u * c4);  // B*D < 2^32: checked on the host
-        if (v & kMultiBit) {
-          atomicAdd(dst + 0, x.x);
-          atomicAdd(dst + 1, x.y);
-          atomicAdd(dst + 2, x.z);
-          atomicAdd(dst + 3, x.w);
-        } else {
-          *reinterpret_cast<float4*>(dst) = x;
+      for (int k = 0; k < NLO; ++k) {
+        const int idx = j_l + 4 * k;
+        if (D4 % 4 == 0 || idx < D4) {
+          const float4 x = *reinterpret_cast<const float4*>(obuf + b_l * C::LDO + 4 * idx);
+          if (val & kMultiBit) {
+            atomicAdd(dst + 4 * idx + 0, x.x);
+            atomicAdd(dst + 4 * idx + 1, x.y);
+            atomicAdd(dst + 4 * idx + 2, x.z);
+            atomicAdd(dst + 4 * idx + 3, x.w);
+          } else {
+            *reinterpret_cast<float4*>(dst + 4 * idx) = x;
+          }
         }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    d_cur = d_nxt;
+    d_nxt = d_nn;
+    val_cur = val_nxt;
+    i2_nxt = i2_nn;
+    val_nxt = val_nn;
   }
 }
 
 // ---------------------------------------------------------------------------------
-// backward, atomics-free formulation (three kernels)
+// backward, atomics-free formulation (four kernels)
 //
-//  A. chunk kernel (stateless, one wavefront per 64 sorted ids): per chunk
-//        dP  += dO . G2s^T                        (q0q1 x r2, per group-run)
+//  A. chunk kernel: per chunk
+//        dP  += dO . G2s^T                        (q0q1 x r2, accumulated over the chunks of a group)
 //        E    = P^T . dO   -> one (r2 q2)-float row per id, stored at the id's grouped position
-//     and per group-run the dP partial sum is stored in its own slot.  Plain stores only.
-//  B. dG2[i2] = sum of the E rows whose id has that i2: each wave of a workgroup owns a slice of
-//     the i2 range and accumulates its rows into an LDS copy with plain read-modify-writes.
-//  C. group epilogue: per non-empty group (ranks are (i1, i0)-ordered) dP = sum of its parts,
+//     and per group dP is stored in its own slot.  Plain stores only.
+//  B. dG2[i2] = sum of the E rows whose id has that i2 (tile-local bucket sums, per-tile slabs).
+//  C. group epilogue: per non-empty group (groups are (i1, i0)-ordered)
 //        dG1[i1] += G0[i0]^T . dP  (registers while i1 repeats),  dG0[i0] += dP . G1[i1]^T.
+//  D. finalize: dG2 = sum of slabs, dG0 = sum of per-group parts.
 // LDS float atomics cost ~160 LDS cycles per wave-instruction on gfx950 (measured), global
 // ones ~1.3 TB/s chip-wide; a store pass + per-destination sum pass is several times cheaper.
 // ---------------------------------------------------------------------------------
 template <int Q0, int Q1, int Q2, int R1, int R2>
-__global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(
-    const float* __restrict__ G0, const float* __restrict__ G1, const float* __restrict__ G2,
-    int64_t nnz, const int32_t* __restrict__ nnz_dev, uint32_t p0, uint32_t p2,
-    const float* __restrict__ d_out, GroupPlan plan) {
+__global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(const float* __restrict__ G2, uint32_t G,
+                                                             const float* __restrict__ d_out, GroupPlan plan) {
   using C = Cfg<Q0, Q1, Q2, R1, R2>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x;
   const int hi = lane >> 4, lo = lane & 15;
+  const int b_l = lane >> 2, j_l = lane & 3;   // this lane's id inside a chunk, and which pieces of its rows
   float* pbuf = smem;
-  float* bbuf = pbuf + C::PB_FLOATS;  // staged G2 rows
-  float* dbuf = bbuf + C::BB2_FLOATS; // staged d_output rows
+  float* bbuf = pbuf + C::PB_FLOATS;   // staged G2 rows
+  float* dbuf = bbuf + C::BB2_FLOATS;  // staged d_output rows
 
-  // A wavefront owns the groups that START inside its 64-id window [begin, end): it skips a
-  // leading group that began earlier and follows its last group past `end`, so every group is
-  // handled by exactly one wavefront and its dP needs no partial sums.
-  const int64_t cnt = live_count(nnz, nnz_dev);
-  const int64_t begin = (int64_t)blockIdx.x * kRange;
-  if (begin >= cnt) return;
-  const int64_t end = begin + kRange < cnt ? begin + kRange : cnt;
-  int64_t pos = begin;
-  if (begin > 0) {
-    const uint32_t prev = plan.keys[begin - 1] / p2;
-    while (pos < end) {  // wave-uniform scan, 64 keys at a time
-      const uint32_t k = pos + lane < cnt ? plan.keys[pos + lane] : 0xffffffffu;
-      const unsigned long long cont = __ballot(pos + lane < cnt && k / p2 == prev);
-      const int run = __builtin_ctzll(~cont);
-      pos += run;
-      if (run < kWave) break;
-    }
-    if (pos >= end) return;  // the window holds nothing but the tail of an earlier group
+  // A wavefront owns the groups whose FIRST chunk lies in its kCPW descriptors: it skips the tail of a
+  // group that began earlier and follows its last group to the end, so every group is handled by exactly
+  // one wavefront and its dP needs no partial sums.
+  const uint32_t nchunks = (uint32_t)(plan.gpre[G] >> 32);
+  const uint32_t c0 = blockIdx.x * kCPW;
+  if (c0 >= nchunks) return;
+  const uint32_t c1 = c0 + kCPW < nchunks ? c0 + kCPW : nchunks;
+  uint32_t c = c0;
+  uint4 d_cur = plan.ctab[c];
+  if (!(d_cur.z & kFirstBit)) {
+    c = d_cur.w;  // first chunk of the next group
+    if (c >= c1) return;
+    d_cur = plan.ctab[c];
   }
 
   // ---- lane-constant LDS offsets of the MFMA operands ----
@@ -378,22 +437,60 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(
 #pragma unroll
   for (int mt = 0; mt < C::MT2; ++mt) {
     const int m = 16 * mt + lo < C::M2 ? 16 * mt + lo : C::M2 - 1;  // rows past M2 are discarded
-    offA[mt] = hi * C::LDO + m * Q2;
+    offA[mt] = hi * C::LDOB + m * Q2;
   }
 #pragma unroll
   for (int t = 0; t < C::RT2; ++t) offB[t] = hi * C::LDBB + ((16 * t + lo) % R2) * Q2;
 #pragma unroll
   for (int nt = 0; nt < C::NT2; ++nt) {
     const int col = 16 * nt + lo;
-    offE[nt] = (col / Q2) * C::LDO + col % Q2 + hi * Q2;
+    offE[nt] = (col / Q2) * C::LDOB + col % Q2 + hi * Q2;
   }
-  constexpr int F4G = C::ROW2 / 4, NLG = (kChunk * F4G + kWave - 1) / kWave;  // G2-row float4 loads per lane
-  constexpr int F4D = C::D / 4, NLD = (kChunk * F4D + kWave - 1) / kWave;     // d_output-row float4 loads per lane
+  constexpr int F4G = C::ROW2 / 4, NLG = (F4G + 3) / 4;   // float4 pieces of a G2 row / per lane (4 lanes per id)
+  constexpr int F4D = C::D / 4, NLD = (F4D + 3) / 4;      // float4 pieces of a d_output row / per lane
+  constexpr int PF4 = C::M2 * R2 / 4, NLP = (PF4 + kWave - 1) / kWave;
+  const uint4 none = make_uint4(0u, 0u, 0u, 0u);
+
+  auto fetch_meta = [&](const uint4& d, uint32_t& i2, uint32_t& val) {
+    i2 = 0u;
+    val = 0xffffffffu;  // no row: the staged gradient row is zero
+    if (b_l < (int)(d.z & 0xffu)) {
+      i2 = plan.i2s[d.x + b_l];
+      val = plan.vals[d.x + b_l] & ~kMultiBit;
+    }
+  };
+  // the chunk's G2 rows, d_output rows and (for a group's first chunk) P travel through registers: they are
+  // requested one chunk ahead so that their HBM / L2 latency hides behind the previous chunk's MFMAs
+  float4 pre_g[NLG], pre_d[NLD], pre_p[NLP];
+  auto request = [&](const uint4& d, uint32_t i2, uint32_t val) {
+    const float* row = G2 + i2 * (uint32_t)C::ROW2;
+#pragma unroll
+    for (int k = 0; k < NLG; ++k) {
+      const int idx = j_l + 4 * k;
+      pre_g[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (F4G % 4 == 0 || idx < F4G) pre_g[k] = *reinterpret_cast<const float4*>(row + 4 * idx);
+    }
+    const float* grow = d_out + val * (uint32_t)C::D;  // B*D < 2^32: checked on the host
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int idx = j_l + 4 * k;
+      pre_d[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((F4D % 4 == 0 || idx < F4D) && val != 0xffffffffu) pre_d[k] = *reinterpret_cast<const float4*>(grow + 4 * idx);
+    }
+    if (d.z & kFirstBit) {
+      const float* p = plan.ptab + (size_t)d.y * (C::M2 * R2);
+#pragma unroll
+      for (int it = 0; it < NLP; ++it) {
+        const int e = it * kWave + lane;
+        pre_p[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (PF4 % kWave == 0 || e < PF4) pre_p[it] = *reinterpret_cast<const float4*>(p + 4 * e);
+      }
+    }
+  };
 
   f32x4 dp[C::MT2][C::RT2];
-  uint32_t cur_group = 0xffffffffu;
-  auto store_dp = [&]() {
-    float* dst = plan.dptab + (size_t)cur_group * (C::M2 * R2);
+  auto store_dp = [&](uint32_t group) {
+    float* dst = plan.dptab + (size_t)group * (C::M2 * R2);
 #pragma unroll
     for (int mt = 0; mt < C::MT2; ++mt)
 #pragma unroll
@@ -406,135 +503,56 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(
         }
   };
 
-  // ---- chunk discovery over a sliding 64-id register window ----
-  int64_t win = -kWave;
-  uint32_t grp_r = 0xffffffffu, i2_r = 0, val_r = 0;
-  struct Chunk {
-    int len;            // ids in the chunk, 0 = nothing left for this wavefront
-    uint32_t group, i2, val;
-  };
-  auto discover = [&](int64_t at, uint32_t open_group) {
-    Chunk c;
-    c.len = 0;
-    c.group = 0xffffffffu;
-    c.i2 = 0;
-    c.val = 0;
-    if (at >= cnt) return c;
-    if (at + kChunk > win + kWave) {  // slide the window; (group, i2) are decoded once per id here
-      win = at;
-      grp_r = 0xffffffffu;
-      if (win + lane < cnt) {
-        const uint32_t key = plan.keys[win + lane];
-        grp_r = key / p2;
-        i2_r = key - grp_r * p2;
-        val_r = plan.vals[win + lane];
-      }
-    }
-    const int off = (int)(at - win);
-    const uint32_t g = __shfl(grp_r, (off + lo) & 63, kWave);
-    c.val = __shfl(val_r, (off + lo) & 63, kWave);
-    c.group = __shfl(grp_r, off, kWave);
-    if (at >= end && c.group != open_group) return c;  // past the window: only the open group continues
-    const unsigned long long same = __ballot(hi == 0 && at + lo < cnt && g == c.group);
-    c.len = __builtin_ctzll(~same);
-    const uint32_t i2 = __shfl(i2_r, (off + lo) & 63, kWave);
-    c.i2 = lo < c.len ? i2 : 0u;
-    return c;
-  };
-  // the chunk's G2 rows and d_output rows travel through registers: they are requested one
-  // chunk ahead so that their HBM / L2 latency hides behind the previous chunk's MFMAs
-  float4 pre_g[NLG], pre_d[NLD];
-  auto request_rows = [&](const Chunk& c) {
-#pragma unroll
-    for (int it = 0; it < NLG; ++it) {
-      const int f = it * kWave + lane;
-      const int b = f / F4G, c4 = f - b * F4G;
-      const uint32_t row2 = __shfl(c.i2, b < kChunk ? b : 0, kWave);
-      pre_g[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (f < kChunk * F4G) pre_g[it] = *reinterpret_cast<const float4*>(G2 + (row2 * (uint32_t)C::ROW2 + 4u * c4));
-    }
-#pragma unroll
-    for (int it = 0; it < NLD; ++it) {
-      const int f = it * kWave + lane;
-      const int b = f / F4D, c4 = f - b * F4D;
-      const uint32_t v = __shfl(c.val, b < kChunk ? b : 0, kWave);
-      pre_d[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (f < kChunk * F4D && b < c.len)
-#if defined(TTEMB_ABL) && (TTEMB_ABL & 2)
-        pre_d[it] = *reinterpret_cast<const float4*>(d_out + ((v & 1023u) * (uint32_t)C::D + 4u * c4));  // ablation: cache-resident rows
-#else
-        pre_d[it] = *reinterpret_cast<const float4*>(d_out + ((v & ~kMultiBit) * (uint32_t)C::D + 4u * c4));  // B*D < 2^32: checked on the host
-#endif
-    }
-  };
+  // which chunk follows `cc` for this wavefront: the next one, unless `cc` closed a group at or past the range end
+  auto has_next = [&](uint32_t cc, const uint4& d) { return cc + 1 < nchunks && !((d.z & kLastBit) && cc + 1 >= c1); };
 
-  Chunk cur = discover(pos, cur_group);
-  if (cur.len) request_rows(cur);
-  while (cur.len) {
-    // ---- group change: close the previous group, form P = G0[i0] . G1[i1] ----
-    if (cur.group != cur_group) {
-      if (cur_group != 0xffffffffu) store_dp();
-      cur_group = cur.group;
+  bool more1 = has_next(c, d_cur);
+  uint4 d_nxt = more1 ? plan.ctab[c + 1] : none;
+  uint32_t i2_cur, val_cur, i2_nxt = 0u, val_nxt = 0xffffffffu;
+  fetch_meta(d_cur, i2_cur, val_cur);
+  request(d_cur, i2_cur, val_cur);
+  if (more1) fetch_meta(d_nxt, i2_nxt, val_nxt);
+
+  for (;;) {
+    const int len = (int)(d_cur.z & 0xffu);
+    const uint32_t here = d_cur.x;
+    // ---- group change: P of the new group -> LDS, dP starts from zero ----
+    if (d_cur.z & kFirstBit) {
 #pragma unroll
       for (int mt = 0; mt < C::MT2; ++mt)
 #pragma unroll
         for (int t = 0; t < C::RT2; ++t) dp[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      const uint32_t i1 = cur_group / p0;
-      const uint32_t i0 = cur_group - i1 * p0;
-      const float* g0 = G0 + (size_t)i0 * C::ROW0;
-      const float* g1 = G1 + (size_t)i1 * C::ROW1;
-#if !(defined(TTEMB_ABL) && (TTEMB_ABL & 16))
-      f32x4 acc[C::NT1];
 #pragma unroll
-      for (int nt = 0; nt < C::NT1; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < C::KS1; ++s) {
-        const int k = 4 * s + hi;
-        const float a = lo < Q0 ? g0[lo * R1 + k] : 0.f;
-#pragma unroll
-        for (int nt = 0; nt < C::NT1; ++nt) {
-          const float b = g1[k * C::N1 + 16 * nt + lo];
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[nt], 0, 0, 0);
-        }
+      for (int it = 0; it < NLP; ++it) {
+        const int e = it * kWave + lane;  // float4 number e of the (q0 q1) x r2 matrix
+        if (PF4 % kWave == 0 || e < PF4)
+          *reinterpret_cast<float4*>(pbuf + (4 * e / R2) * C::LDPB + (4 * e) % R2) = pre_p[it];
       }
-#pragma unroll
-      for (int nt = 0; nt < C::NT1; ++nt) {
-        const int n = 16 * nt + lo;
-        const int j = n / R2, c2 = n % R2;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int a = 4 * hi + r;
-          if (a < Q0) pbuf[(a * Q1 + j) * C::LDPB + c2] = acc[nt][r];
-        }
-      }
-#endif
     }
     // ---- the chunk's rows: registers -> LDS ----
 #pragma unroll
-    for (int it = 0; it < NLG; ++it) {
-      const int f = it * kWave + lane;
-      const int b = f / F4G, c4 = f - b * F4G;
-      if (f < kChunk * F4G) *reinterpret_cast<float4*>(bbuf + b * C::LDBB + 4 * c4) = pre_g[it];
+    for (int k = 0; k < NLG; ++k) {
+      const int idx = j_l + 4 * k;
+      if (F4G % 4 == 0 || idx < F4G) *reinterpret_cast<float4*>(bbuf + b_l * C::LDBB + 4 * idx) = pre_g[k];
     }
 #pragma unroll
-    for (int it = 0; it < NLD; ++it) {
-      const int f = it * kWave + lane;
-      const int b = f / F4D, c4 = f - b * F4D;
-      if (f < kChunk * F4D) *reinterpret_cast<float4*>(dbuf + b * C::LDO + 4 * c4) = pre_d[it];
+    for (int k = 0; k < NLD; ++k) {
+      const int idx = j_l + 4 * k;
+      if (F4D % 4 == 0 || idx < F4D) *reinterpret_cast<float4*>(dbuf + b_l * C::LDOB + 4 * idx) = pre_d[k];
     }
     __builtin_amdgcn_sched_barrier(0);  // the row registers are free again only after the stores above
-    // ---- request the next chunk's rows now; they land while this chunk computes ----
-    const int64_t here = pos;
-    const int len = cur.len;
-    pos += len;
-    cur = discover(pos, cur_group);
-    if (cur.len) request_rows(cur);
+    // ---- request the next chunk's rows and the chunk after's indices now; they land while this chunk computes ----
+    const uint4 d_done = d_cur;
+    const bool more2 = more1 && has_next(c + 1, d_nxt);
+    const uint4 d_nn = more2 ? plan.ctab[c + 2] : none;
+    if (more1) request(d_nxt, i2_nxt, val_nxt);
+    uint32_t i2_nn = 0u, val_nn = 0xffffffffu;
+    if (more2) fetch_meta(d_nn, i2_nn, val_nn);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_sched_barrier(0);
 
-#if !(defined(TTEMB_ABL) && (TTEMB_ABL & 4))
     // ---- dP += dO (q0q1 x 16 q2) . G2s^T (16 q2 x r2) ----
 #pragma unroll
     for (int b4 = 0; b4 < kChunk / 4; ++b4)
@@ -542,7 +560,7 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(
       for (int kk = 0; kk < Q2; ++kk) {
         float av[C::MT2], bv[C::RT2];
 #pragma unroll
-        for (int mt = 0; mt < C::MT2; ++mt) av[mt] = dbuf[offA[mt] + b4 * 4 * C::LDO + kk];
+        for (int mt = 0; mt < C::MT2; ++mt) av[mt] = dbuf[offA[mt] + b4 * 4 * C::LDOB + kk];
 #pragma unroll
         for (int t = 0; t < C::RT2; ++t) {
           bv[t] = bbuf[offB[t] + b4 * 4 * C::LDBB + kk];
@@ -556,14 +574,12 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(
         if (kk == Q2 - 1) __builtin_amdgcn_sched_barrier(0);  // keeps operand loads from piling up in registers
       }
 
-#endif
     // ---- E = P^T (r2 x q0q1) . dO (q0q1 x 16 q2) ----
     f32x4 e[C::RT2][C::NT2];
 #pragma unroll
     for (int t = 0; t < C::RT2; ++t)
 #pragma unroll
       for (int nt = 0; nt < C::NT2; ++nt) e[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#if !(defined(TTEMB_ABL) && (TTEMB_ABL & 8))
 #pragma unroll
     for (int s = 0; s < C::M2 / 4; ++s) {
       float av[C::RT2];
@@ -581,7 +597,6 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-#endif
     // E leaves straight from the accumulators.  Lane (hi, lo) holds E[c2 = 16 t + 4 hi + r][col = 16 nt + lo]
     // with col = id * q2 + kk, and the E table keeps an id's row as [kk][c2] (the reduce kernel sums rows
     // element by element, the finalize kernel puts dG2 back into [c2][kk]): the chunk's rows are then one
@@ -594,19 +609,22 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(
 #pragma unroll
         for (int t = 0; t < C::RT2; ++t) {
           const int c2 = 16 * t + 4 * hi;
-#if defined(TTEMB_ABL) && (TTEMB_ABL & 1)
-          if (col < len * Q2 && c2 < R2 && e[t][nt][0] == 123.456f)   // ablation: no E traffic
-#else
           if (col < len * Q2 && c2 < R2)
-#endif
             *reinterpret_cast<float4*>(dst + col * R2 + c2) = make_float4(e[t][nt][0], e[t][nt][1], e[t][nt][2], e[t][nt][3]);
         }
       }
     }
+    if (d_done.z & kLastBit) store_dp(d_done.y);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();  // every LDS read of this chunk is done before the next rows land
+    if (!more1) break;
+    ++c;
+    d_cur = d_nxt;
+    d_nxt = d_nn;
+    more1 = more2;
+    i2_nxt = i2_nn;
+    val_nxt = val_nn;
   }
-  if (cur_group != 0xffffffffu) store_dp();
 }
 
 // B. dG2 reduce.  A workgroup takes kRowsB consecutive E rows, buckets them by i2 inside LDS
@@ -623,7 +641,7 @@ __global__ __launch_bounds__(NWB * 64) void fast3_dg2_reduce_kernel(GroupPlan pl
   constexpr int F4 = ROW2 / 4;      // float4 per row
   constexpr int SUB = kWave / F4;   // rows handled per load instruction
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const uint32_t total = plan.gstart[G];
+  const uint32_t total = (uint32_t)plan.gpre[G];
   const uint32_t s0 = blockIdx.x * kRowsB;
   const uint32_t n_rows = s0 >= total ? 0u : (s0 + kRowsB < total ? kRowsB : total - s0);
   float* slab = plan.g2part + (size_t)blockIdx.x * p2 * ROW2;  // this tile's partial dG2, every row written
@@ -636,8 +654,7 @@ __global__ __launch_bounds__(NWB * 64) void fast3_dg2_reduce_kernel(GroupPlan pl
     const uint32_t r = k * NWB * 64 + tid;
     my_i2[k] = 0xffffffffu;
     if (r < n_rows) {
-      const uint32_t key = plan.keys[s0 + r];
-      my_i2[k] = key - (key / p2) * p2;
+      my_i2[k] = plan.i2s[s0 + r];
       my_rank[k] = atomicAdd(&bstart[my_i2[k] + 1], 1u);
     }
   }
@@ -906,21 +923,32 @@ constexpr int kRowsB = TTEMB_ROWS_B;  // E rows per workgroup of the dG2 reduce
 constexpr int NWB = 16;
 static int64_t reduce_tiles(int64_t nnz) { return (nnz + kRowsB - 1) / kRowsB; }
 
-// The grouping that forward and backward share ("plan"): grouped keys / values and the group
-// sizes / starts.  It lives in a caller buffer when one is given, else in the workspace.
+// The grouping that forward and backward share ("plan"): grouped (i2, row) pairs, group sizes / starts and
+// the chunk table.  It lives in a caller buffer when one is given, else in the workspace.
+static int64_t max_chunks(const DevShape& s, int64_t nnz) {
+  const int64_t G = num_groups(s);
+  return nnz / kChunk + (nnz < G ? nnz : G) + 1;
+}
+
 int64_t fast3_plan_bytes(const DevShape& s, int64_t nnz) {
-  return 2 * align256(nnz * 4) + 2 * align256((num_groups(s) + 1) * 4);
+  const int64_t G = num_groups(s);
+  return 2 * align256(nnz * 4) + align256((G + 1) * 4) + align256((G + 1) * 8) + align256(max_chunks(s, nnz) * 16);
 }
 
 static void carve_plan_part(const DevShape& s, int64_t nnz, char* base, GroupPlan* pl) {
   const int64_t G = num_groups(s);
-  pl->keys = (uint32_t*)base;
-  pl->vals = (uint32_t*)(base + align256(nnz * 4));
-  pl->counts = (uint32_t*)(base + 2 * align256(nnz * 4));
-  pl->gstart = (uint32_t*)(base + 2 * align256(nnz * 4) + align256((G + 1) * 4));
+  pl->i2s = (uint32_t*)base;
+  base += align256(nnz * 4);
+  pl->vals = (uint32_t*)base;
+  base += align256(nnz * 4);
+  pl->counts = (uint32_t*)base;
+  base += align256((G + 1) * 4);
+  pl->gpre = (uint64_t*)base;
+  base += align256((G + 1) * 8);
+  pl->ctab = (uint4*)base;
 }
 
-// workspace layout: [plan part unless external] [grouping scratch] [backward tables]
+// workspace layout: [plan part unless external] [prefix products] [grouping scratch] [backward tables]
 static int64_t carve_workspace(const DevShape& s, int64_t nnz, bool bwd, bool plan_inside, bool need_grouping,
                                char* base, GroupPlan* pl, char** scan_tmp) {
   const int64_t G = num_groups(s);
@@ -933,6 +961,10 @@ static int64_t carve_workspace(const DevShape& s, int64_t nnz, bool bwd, bool pl
   if (plan_inside) {
     char* p = take(fast3_plan_bytes(s, nnz));
     if (pl && p) carve_plan_part(s, nnz, p, pl);
+  }
+  {
+    float* pt = (float*)take(G * (int64_t)s.q[0] * s.q[1] * s.R[2] * 4);
+    if (pl) pl->ptab = pt;
   }
   if (need_grouping) {
     uint32_t* a = (uint32_t*)take(nnz * 4);
@@ -966,13 +998,14 @@ int64_t fast3_workspace_bytes(const DevShape& s, int32_t op, int64_t nnz, int64_
   return carve_workspace(s, nnz, op == TTEMB_OP_BACKWARD, true, true, nullptr, nullptr, nullptr) + 256;
 }
 
-// fill plan->{keys, vals, counts, gstart} from the ids
+// fill plan->{i2s, vals, counts, gpre, ctab} from the ids
 static int group_ids(const DevShape& s, const int64_t* indices, const int64_t* rowidx, const int64_t* offsets,
                      int64_t nnz, const int32_t* nnz_dev, GroupPlan* plan, char* scan_tmp, hipStream_t st) {
   const int64_t G = num_groups(s);
   size_t tmp_bytes = 0;
-  uint32_t* nul = nullptr;
-  hipError_t e = rocprim::exclusive_scan(nullptr, tmp_bytes, nul, nul, 0u, (size_t)(G + 1), rocprim::plus<uint32_t>(), st, false);
+  auto packed = rocprim::make_transform_iterator(plan->counts, PackCounts());
+  hipError_t e = rocprim::exclusive_scan(nullptr, tmp_bytes, packed, plan->gpre, (uint64_t)0, (size_t)(G + 1),
+                                         rocprim::plus<uint64_t>(), st, false);
   if (e != hipSuccess) return check_hip(e, "exclusive_scan(size)");
   if ((int64_t)tmp_bytes > scan_temp_bytes(G)) return fail(TTEMB_E_WORKSPACE, "scan scratch bound too small");
   const uint32_t sentinel = (uint32_t)((unsigned long long)s.L[0] * s.p[0]);
@@ -983,9 +1016,9 @@ static int group_ids(const DevShape& s, const int64_t* indices, const int64_t* r
                      (uint32_t)s.p[0], (uint32_t)s.p[1], (uint32_t)s.p[2], *plan);
   rc = check_hip(hipGetLastError(), "fast3_prep_kernel");
   if (rc) return rc;
-  // gstart[g] = first grouped position of group g; gstart[G] = number of live ids
-  e = rocprim::exclusive_scan(scan_tmp, tmp_bytes, plan->counts, plan->gstart, 0u, (size_t)(G + 1),
-                              rocprim::plus<uint32_t>(), st, false);
+  // gpre[g] = (first grouped position, first chunk) of group g; gpre[G] = (live ids, chunks)
+  e = rocprim::exclusive_scan(scan_tmp, tmp_bytes, packed, plan->gpre, (uint64_t)0, (size_t)(G + 1),
+                              rocprim::plus<uint64_t>(), st, false);
   if (e != hipSuccess) return check_hip(e, "exclusive_scan");
   hipLaunchKernelGGL(fast3_scatter_kernel, dim3(tiles), dim3(kTile), 0, st, nnz, nnz_dev, (uint32_t)s.p[2], *plan);
   return check_hip(hipGetLastError(), "fast3_scatter_kernel");
@@ -1008,16 +1041,28 @@ static int prepare(const DevShape& s, bool bwd, const int64_t* indices, const in
   return group_ids(s, indices, rowidx, offsets, nnz, nnz_dev, plan, scan_tmp, st);
 }
 
+// P of every non-empty group from the cores as they are now (forward and backward each do this: the backward
+// differentiates the chain at the current cores, like the reference's recompute)
 template <int Q0, int Q1, int Q2, int R1, int R2>
-static int run_forward(const DevShape& s, const CorePtrs& cores, const GroupPlan& ids, int64_t nnz,
-                       const int32_t* nnz_dev, float* output, hipStream_t st) {
+static int run_prefix(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, hipStream_t st) {
+  hipLaunchKernelGGL((fast3_prefix_kernel<Q0, Q1, Q2, R1, R2>),
+                     dim3((unsigned)((s.p[0] + kPrefixGroups - 1) / kPrefixGroups), (unsigned)s.p[1]), dim3(64), 0, st,
+                     cores.c[0], cores.c[1], (uint32_t)s.p[0], plan);
+  return check_hip(hipGetLastError(), "fast3_prefix_kernel");
+}
+
+static unsigned chunk_waves(const DevShape& s, int64_t nnz) { return (unsigned)((max_chunks(s, nnz) + kCPW - 1) / kCPW); }
+
+template <int Q0, int Q1, int Q2, int R1, int R2>
+static int run_forward(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int64_t nnz, float* output,
+                       hipStream_t st) {
   using C = Cfg<Q0, Q1, Q2, R1, R2>;
-  const size_t lds = TTEMB_FWD_WAVES * C::WAVE_FLOATS * sizeof(float);
-  const unsigned blocks = (unsigned)((nnz + kRange * TTEMB_FWD_WAVES - 1) / (kRange * TTEMB_FWD_WAVES));
+  int rc = run_prefix<Q0, Q1, Q2, R1, R2>(s, cores, plan, st);
+  if (rc) return rc;
+  const size_t lds = C::WAVE_FLOATS * sizeof(float);
   profile_begin(0, st);
-  hipLaunchKernelGGL((fast3_forward_kernel<Q0, Q1, Q2, R1, R2>), dim3(blocks), dim3(64 * TTEMB_FWD_WAVES), lds, st, cores.c[0],
-                     cores.c[1], cores.c[2], ids.keys, ids.vals, nnz, nnz_dev, (uint32_t)s.p[0],
-                     (uint32_t)s.p[2], output);
+  hipLaunchKernelGGL((fast3_forward_kernel<Q0, Q1, Q2, R1, R2>), dim3(chunk_waves(s, nnz)), dim3(64), lds, st, cores.c[2],
+                     plan, (uint32_t)num_groups(s), output);
   profile_end(0, st);
   return check_hip(hipGetLastError(), "fast3_forward_kernel");
 }
@@ -1027,37 +1072,37 @@ int launch_forward_fast3(const DevShape& s, const CorePtrs& cores, const int64_t
                          float* output, void* ws, int64_t ws_bytes, void* plan_buf, int64_t plan_bytes,
                          hipStream_t st) {
   if (nnz <= 0) return TTEMB_OK;
-  GroupPlan ids;
-  int rc = prepare(s, false, indices, rowidx, offsets, nnz, nnz_dev, ws, ws_bytes, plan_buf, plan_bytes, false, &ids, st);
+  GroupPlan plan;
+  int rc = prepare(s, false, indices, rowidx, offsets, nnz, nnz_dev, ws, ws_bytes, plan_buf, plan_bytes, false, &plan, st);
   if (rc) return rc;
   switch (classify(s)) {
-    case kProducts: return run_forward<4, 5, 5, 16, 16>(s, cores, ids, nnz, nnz_dev, output, st);
-    case kArxiv: return run_forward<4, 4, 8, 8, 8>(s, cores, ids, nnz, nnz_dev, output, st);
-    case kPapers: return run_forward<8, 4, 4, 32, 32>(s, cores, ids, nnz, nnz_dev, output, st);
+    case kProducts: return run_forward<4, 5, 5, 16, 16>(s, cores, plan, nnz, output, st);
+    case kArxiv: return run_forward<4, 4, 8, 8, 8>(s, cores, plan, nnz, output, st);
+    case kPapers: return run_forward<8, 4, 4, 32, 32>(s, cores, plan, nnz, output, st);
     default: return fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
   }
 }
 
 template <int Q0, int Q1, int Q2, int R1, int R2>
 static int run_backward(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int64_t nnz,
-                        const int32_t* nnz_dev, const float* d_output, const CorePtrsMut& d_cores,
-                        hipStream_t st) {
+                        const float* d_output, const CorePtrsMut& d_cores, hipStream_t st) {
   using C = Cfg<Q0, Q1, Q2, R1, R2>;
-  const size_t lds = (size_t)(C::PB_FLOATS + C::BB2_FLOATS + C::O_FLOATS) * sizeof(float);
-  const unsigned ranges = (unsigned)((nnz + kRange - 1) / kRange);
+  const int64_t G = num_groups(s);
   profile_begin(1, st);
+  int rc = run_prefix<Q0, Q1, Q2, R1, R2>(s, cores, plan, st);
+  if (rc) return rc;
+  const size_t lds = (size_t)(C::PB_FLOATS + C::BB2_FLOATS + C::OB_FLOATS) * sizeof(float);
   profile_begin(2, st);
-  hipLaunchKernelGGL((fast3_bwd_chunk_kernel<Q0, Q1, Q2, R1, R2>), dim3(ranges), dim3(64), lds, st, cores.c[0],
-                     cores.c[1], cores.c[2], nnz, nnz_dev, (uint32_t)s.p[0], (uint32_t)s.p[2], d_output, plan);
+  hipLaunchKernelGGL((fast3_bwd_chunk_kernel<Q0, Q1, Q2, R1, R2>), dim3(chunk_waves(s, nnz)), dim3(64), lds, st, cores.c[2],
+                     (uint32_t)G, d_output, plan);
   profile_end(2, st);
-  int rc = check_hip(hipGetLastError(), "fast3_bwd_chunk_kernel");
+  rc = check_hip(hipGetLastError(), "fast3_bwd_chunk_kernel");
   if (rc) return rc;
   const int tiles = (int)reduce_tiles(nnz);
   hipLaunchKernelGGL((fast3_dg2_reduce_kernel<C::ROW2, kRowsB, NWB>), dim3((unsigned)tiles), dim3(NWB * 64),
-                     (size_t)(2 * s.p[2] + 1) * 4 + kRowsB * 2, st, plan, (int)num_groups(s), (uint32_t)s.p[2]);
+                     (size_t)(2 * s.p[2] + 1) * 4 + kRowsB * 2, st, plan, (int)G, (uint32_t)s.p[2]);
   rc = check_hip(hipGetLastError(), "fast3_dg2_reduce_kernel");
   if (rc) return rc;
-  const int64_t G = num_groups(s);
   hipLaunchKernelGGL((fast3_group_epilogue_kernel<Q0, Q1, Q2, R1, R2>), dim3((unsigned)((G + kGroupsC - 1) / kGroupsC)),
                      dim3(64), 0, st, cores.c[0], cores.c[1], (uint32_t)s.p[0], (uint32_t)G, plan, d_cores.c[1]);
   rc = check_hip(hipGetLastError(), "fast3_group_epilogue_kernel");
@@ -1088,9 +1133,9 @@ int launch_backward_fast3(const DevShape& s, const CorePtrs& cores, const int64_
                    plan_buf != nullptr, &plan, st);
   if (rc) return rc;
   switch (classify(s)) {
-    case kProducts: return run_backward<4, 5, 5, 16, 16>(s, cores, plan, nnz, nnz_dev, d_output, d_cores, st);
-    case kArxiv: return run_backward<4, 4, 8, 8, 8>(s, cores, plan, nnz, nnz_dev, d_output, d_cores, st);
-    case kPapers: return run_backward<8, 4, 4, 32, 32>(s, cores, plan, nnz, nnz_dev, d_output, d_cores, st);
+    case kProducts: return run_backward<4, 5, 5, 16, 16>(s, cores, plan, nnz, d_output, d_cores, st);
+    case kArxiv: return run_backward<4, 4, 8, 8, 8>(s, cores, plan, nnz, d_output, d_cores, st);
+    case kPapers: return run_backward<8, 4, 4, 32, 32>(s, cores, plan, nnz, d_output, d_cores, st);
     default: return fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
   }
 }
