@@ -109,22 +109,29 @@ def main():
     result = None
     if rank == 0:
         # roofline leg: kernels bracketed by HIP events on the stream they are launched on.
-        # slot 0 = forward chain kernel (all 13 440 nominal flops of a lookup), slot 2 = backward chunk
-        # kernel (P recompute + dP + dG2 rows: F0 + 2 F1 = 16 640 nominal flops), slot 1 = all backward
-        # chain kernels (37 120 nominal flops; dG1/dG0 run once per (i0,i1) group in the epilogue kernel)
+        # slot 0 = forward chain kernel, slot 2 = backward chunk kernel, slot 1 = all backward chain kernels,
+        # slot 3 = grouping pass (counting sort + chunk table + prefix-product kernel).  Nominal work per
+        # lookup: forward F0 + F1 = 13 440 flop, backward 3 F0 + 2 F1 = 37 120 flop, 408 B each
+        # way (8 B id + one D-float row).  The chunk kernel's own share is the two per-id GEMMs of the backward
+        # (dP and the dG2 rows: 2 F1 = 6 400 flop) over 408 algorithmic bytes = 15.7 flop/B, under the
+        # fp32-MFMA ridge (157.3 TF / 8 TB/s = 19.7): it is priced against HBM.
         nat.profile_enable(True)
-        fwd_ms, bwd_ms, chunk_ms = [], [], []
+        fwd_ms, bwd_ms, chunk_ms, group_ms = [], [], [], []
         for i in range(10):
             step(i)
             fwd_ms.append(nat.profile_read(0))
             bwd_ms.append(nat.profile_read(1))
             chunk_ms.append(nat.profile_read(2))
+            group_ms.append(nat.profile_read(3))
         nat.profile_enable(False)
         fwd, bwd, chunk = float(np.mean(fwd_ms)), float(np.mean(bwd_ms)), float(np.mean(chunk_ms))
-        chunk_flops = F0 + 2 * F1
-        dom_name, dom_ms, dom_flops = ("fast3_bwd_chunk_kernel", chunk, chunk_flops) if chunk >= fwd else \
-                                      ("fast3_forward_kernel", fwd, FWD_FLOPS)
-        achieved = N * dom_flops / (dom_ms * 1e-3) / 1e12
+        group = float(np.mean(group_ms))
+        row_bytes = 8 + 4 * D
+        if chunk >= fwd:
+            dom_name, dom_ms, dom_flops = "fast3_bwd_chunk_kernel", chunk, 2 * F1
+        else:
+            dom_name, dom_ms, dom_flops = "fast3_forward_kernel", fwd, F1
+        achieved = N * row_bytes / (dom_ms * 1e-3) / 1e9
         # HBM bytes per launch of that kernel from the committed PMC passes (profiles/r01_traffic.json;
         # FETCH_SIZE/WRITE_SIZE cannot be read from inside the process), valid for the default workload
         traffic = None
@@ -134,18 +141,23 @@ def main():
                     traffic = json.load(fh)["kernels"][dom_name]["hbm_bytes"]
         except (OSError, KeyError, ValueError):
             traffic = None
-        roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 3),
-                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                    "kernel_ms": round(dom_ms, 4), "flops_per_lookup": dom_flops,
+        tf = lambda flops, ms: N * flops / (ms * 1e-3) / 1e12
+        roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1),
+                    "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": traffic,
+                    "kernel_ms": round(dom_ms, 4), "algorithmic_bytes_per_lookup": row_bytes,
+                    "kernel_flops_per_lookup": dom_flops,
+                    "kernel_mfma_frac": round(tf(dom_flops, dom_ms) / PEAK_F32_MFMA_TFLOPS, 4),
+                    "traffic_gbs": None if traffic is None else round(traffic / (dom_ms * 1e-3) / 1e9, 1),
                     "fwd_kernel_ms": round(fwd, 4), "bwd_chunk_kernel_ms": round(chunk, 4),
-                    "bwd_chain_ms": round(bwd, 4),
-                    "fwd_achieved_tflops": round(N * FWD_FLOPS / (fwd * 1e-3) / 1e12, 3),
-                    "fwd_frac": round(N * FWD_FLOPS / (fwd * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                    "bwd_chain_achieved_tflops": round(N * BWD_FLOPS / (bwd * 1e-3) / 1e12, 3),
-                    "bwd_chain_frac": round(N * BWD_FLOPS / (bwd * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                    "fwd_row_store_gbs": round(N * (8 + 4 * D) / (fwd * 1e-3) / 1e9, 1),
-                    "peak_hbm_gbs": PEAK_HBM_GBS}
+                    "bwd_chain_ms": round(bwd, 4), "grouping_ms": round(group, 4),
+                    # chain level, nominal flops (executed flops are lower: P is formed once per group)
+                    "fwd_chain_nominal_tflops": round(tf(FWD_FLOPS, fwd + group), 3),
+                    "fwd_chain_mfma_frac": round(tf(FWD_FLOPS, fwd + group) / PEAK_F32_MFMA_TFLOPS, 4),
+                    "bwd_chain_nominal_tflops": round(tf(BWD_FLOPS, bwd), 3),
+                    "bwd_chain_mfma_frac": round(tf(BWD_FLOPS, bwd) / PEAK_F32_MFMA_TFLOPS, 4),
+                    "fwd_row_store_gbs": round(N * row_bytes / (fwd * 1e-3) / 1e9, 1),
+                    "peak_f32_mfma_tflops": PEAK_F32_MFMA_TFLOPS}
         # latency regime of the metric's "batch 2048": 2048 unique ids per step (sparse batch -> generic
         # wave-per-id kernels), same fwd + bwd + SGD step through the class
         small = None

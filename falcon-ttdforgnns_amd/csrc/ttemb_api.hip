@@ -31,8 +31,8 @@ int check_hip(hipError_t e, const char* what) {
 int current_path() { return g_path.load(); }
 
 static std::atomic<bool> g_prof_on{false};
-static hipEvent_t g_prof_ev[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
-static std::atomic<bool> g_prof_valid[3] = {{false}, {false}, {false}};
+static hipEvent_t g_prof_ev[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+static std::atomic<bool> g_prof_valid[4] = {{false}, {false}, {false}, {false}};
 
 void profile_begin(int which, hipStream_t st) {
   if (!g_prof_on) return;
@@ -98,13 +98,8 @@ static int64_t grad_scratch_bytes(const DevShape& s) {
 static bool use_fast3(const DevShape& s, int64_t nnz, int64_t B) {
   const int path = current_path();
   if (path == TTEMB_PATH_GENERIC || !fast3_supported(s)) return false;
-  if (B * s.D >= (int64_t(1) << 32)) return false;  // the fast kernels address output / gradient rows with 32-bit offsets
+  if (!fast3_fits(s, nnz, B)) return false;  // the fast kernels address their tables with 32-bit byte offsets
   return path == TTEMB_PATH_FAST3 || fast3_pays(s, nnz);
-}
-
-// a plan the fast path's backward will reuse as is (it holds the grouped ids and their rows)
-static bool plan_ready(const DevShape& s, int64_t nnz, int64_t B, const void* plan, int64_t plan_bytes) {
-  return plan != nullptr && use_fast3(s, nnz, B) && plan_bytes >= fast3_plan_bytes(s, nnz);
 }
 
 // rows whose bag length is not 1 must be zero before the lookups accumulate into them
@@ -222,7 +217,7 @@ static int resolve_rowidx(const int64_t** rowidx, const int64_t* offsets, int64_
   }
   if (*rowidx != nullptr || nnz == 0) return TTEMB_OK;
   if (offsets == nullptr) return fail(TTEMB_E_BADARG, "rowidx and offsets are both null");
-  if (rows_in_plan) return TTEMB_OK;  // a ready plan of the fast path already carries every id's row
+  if (rows_in_plan) return TTEMB_OK;  // the fast path derives rows from `offsets` while it groups the ids
   int rc = launch_rowidx(offsets, B, nnz, reinterpret_cast<int64_t*>(base), st);
   *rowidx = reinterpret_cast<const int64_t*>(base);
   return rc;
@@ -230,11 +225,11 @@ static int resolve_rowidx(const int64_t** rowidx, const int64_t* offsets, int64_
 
 // shared body of the three backward entry points: gradient of the live ids into `dst`
 static int backward_into(const DevShape& ds, const CorePtrs& cp, const int64_t* indices,
-                         const int64_t* rowidx, int64_t nnz, const int32_t* nnz_dev, int64_t B,
+                         const int64_t* rowidx, const int64_t* offsets, int64_t nnz, const int32_t* nnz_dev, int64_t B,
                          const float* d_output, const CorePtrsMut& dst, void* ws, int64_t ws_bytes,
                          const void* plan, int64_t plan_bytes, hipStream_t st) {
   if (use_fast3(ds, nnz, B))
-    return launch_backward_fast3(ds, cp, indices, rowidx, nnz, nnz_dev, d_output, dst, ws, ws_bytes, plan,
+    return launch_backward_fast3(ds, cp, indices, rowidx, offsets, nnz, nnz_dev, B, d_output, dst, ws, ws_bytes, plan,
                                  plan_bytes, st);
   if (current_path() == TTEMB_PATH_FAST3) return fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
   for (int t = 0; t < ds.T; ++t) {
@@ -266,7 +261,7 @@ int ttemb_profile_enable(int32_t on) {
 }
 
 int ttemb_profile_read(int32_t which, float* ms_host) {
-  if (which < 0 || which > 2 || ms_host == nullptr) return fail(TTEMB_E_BADARG, "bad profile slot");
+  if (which < 0 || which > 3 || ms_host == nullptr) return fail(TTEMB_E_BADARG, "bad profile slot");
   if (!g_prof_valid[which]) return fail(TTEMB_E_BADARG, "no profiled launch recorded for slot %d", which);
   int rc = check_hip(hipEventSynchronize(g_prof_ev[which][1]), "hipEventSynchronize");
   if (rc) return rc;
@@ -316,24 +311,28 @@ int ttemb_forward(const ttemb_shape_t* shape, const float* const* cores, const i
   if (output == nullptr) return fail(TTEMB_E_BADARG, "output is null");
   if (B >= 0x7fffffffll) return fail(TTEMB_E_BADARG, "B exceeds int32 range");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  CorePtrs cp;
+  for (int t = 0; t < TTEMB_MAX_CORES; ++t) cp.c[t] = t < ds.T ? cores[t] : nullptr;
+  const bool f3 = nnz > 0 && use_fast3(ds, nnz, B);
+  if (rowidx == nullptr && offsets == nullptr && nnz > 0) return fail(TTEMB_E_BADARG, "rowidx and offsets are both null");
   char* ws = reinterpret_cast<char*>(workspace);
-  rc = resolve_rowidx(&rowidx, offsets, nnz, B, &ws, &workspace_bytes, st);
+  // the row-index slot at the head of the workspace is part of the layout on both paths; the fast path derives
+  // rows (and clears the rows of bags that do not hold exactly one id) inside its grouping pass
+  rc = resolve_rowidx(&rowidx, offsets, nnz, B, &ws, &workspace_bytes, st, f3);
   if (rc) return rc;
   workspace = ws;
-  if (offsets != nullptr) {
+  if (offsets == nullptr) {
+    rc = check_hip(hipMemsetAsync(output, 0, (size_t)B * ds.D * 4, st), "memset output");
+  } else if (!f3) {
     const int threads = 256;
     hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)((B + threads - 1) / threads)), dim3(threads), 0,
                        st, offsets, B, ds.D, output);
     rc = check_hip(hipGetLastError(), "zero_rows_kernel");
-  } else {
-    rc = check_hip(hipMemsetAsync(output, 0, (size_t)B * ds.D * 4, st), "memset output");
   }
   if (rc || nnz == 0) return rc;
-  CorePtrs cp;
-  for (int t = 0; t < TTEMB_MAX_CORES; ++t) cp.c[t] = t < ds.T ? cores[t] : nullptr;
-  if (use_fast3(ds, nnz, B))
-    return launch_forward_fast3(ds, cp, indices, rowidx, offsets, nnz, nnz_dev, output, workspace, workspace_bytes,
-                                plan, plan_bytes, st);
+  if (f3)
+    return launch_forward_fast3(ds, cp, indices, rowidx, offsets, nnz, nnz_dev, B, output, offsets != nullptr, workspace,
+                                workspace_bytes, plan, plan_bytes, st);
   if (current_path() == TTEMB_PATH_FAST3) return fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
   return launch_forward_generic(ds, cp, indices, rowidx, offsets, nnz, nnz_dev, output, st);
 }
@@ -362,9 +361,9 @@ int ttemb_backward_dense(const ttemb_shape_t* shape, const float* const* cores,
   char* ws = reinterpret_cast<char*>(workspace);
   int64_t rest = workspace_bytes > skip ? workspace_bytes - skip : 0;
   ws = ws ? ws + skip : nullptr;
-  rc = resolve_rowidx(&rowidx, offsets, nnz, B, &ws, &rest, st, plan_ready(ds, nnz, B, plan, plan_bytes));
+  rc = resolve_rowidx(&rowidx, offsets, nnz, B, &ws, &rest, st, use_fast3(ds, nnz, B));
   if (rc) return rc;
-  return backward_into(ds, cp, indices, rowidx, nnz, nnz_dev, B, d_output, dp, ws, rest, plan, plan_bytes, st);
+  return backward_into(ds, cp, indices, rowidx, offsets, nnz, nnz_dev, B, d_output, dp, ws, rest, plan, plan_bytes, st);
 }
 
 static int fused_backward(const ttemb_shape_t* shape, float* const* cores, float* const* opt_state,
@@ -397,9 +396,9 @@ static int fused_backward(const ttemb_shape_t* shape, float* const* cores, float
   }
   char* rest_ws = ws + off;
   int64_t rest = workspace_bytes - off;
-  rc = resolve_rowidx(&rowidx, offsets, nnz, B, &rest_ws, &rest, st, plan_ready(ds, nnz, B, plan, plan_bytes));
+  rc = resolve_rowidx(&rowidx, offsets, nnz, B, &rest_ws, &rest, st, use_fast3(ds, nnz, B));
   if (rc) return rc;
-  rc = backward_into(ds, cp, indices, rowidx, nnz, nnz_dev, B, d_output, gp, rest_ws, rest, plan, plan_bytes, st);
+  rc = backward_into(ds, cp, indices, rowidx, offsets, nnz, nnz_dev, B, d_output, gp, rest_ws, rest, plan, plan_bytes, st);
   if (rc) return rc;
   Seg3 seg;
   memset(&seg, 0, sizeof(seg));

@@ -53,16 +53,19 @@ int launch_backward_generic(const DevShape& s, const CorePtrs& cores, const int6
 
 // fast 3-core path (ttemb_fast3.hip)
 bool fast3_supported(const DevShape& s);
-bool fast3_pays(const DevShape& s, int64_t nnz);  // enough ids per group for the grouped path to win
+bool fast3_pays(const DevShape& s, int64_t nnz);
+bool fast3_fits(const DevShape& s, int64_t nnz, int64_t B);  // enough ids per group for the grouped path to win
 int64_t fast3_workspace_bytes(const DevShape& s, int32_t op, int64_t nnz, int64_t B);
 int64_t fast3_plan_bytes(const DevShape& s, int64_t nnz);
+// rowidx may be null when offsets is given (rows are derived while grouping); zero_rows: clear the output rows
+// of bags that do not hold exactly one id (needs offsets)
 int launch_forward_fast3(const DevShape& s, const CorePtrs& cores, const int64_t* indices,
                          const int64_t* rowidx, const int64_t* offsets, int64_t nnz,
-                         const int32_t* nnz_dev, float* output, void* ws, int64_t ws_bytes, void* plan,
-                         int64_t plan_bytes, hipStream_t st);
+                         const int32_t* nnz_dev, int64_t B, float* output, bool zero_rows, void* ws,
+                         int64_t ws_bytes, void* plan, int64_t plan_bytes, hipStream_t st);
 int launch_backward_fast3(const DevShape& s, const CorePtrs& cores, const int64_t* indices,
-                          const int64_t* rowidx, int64_t nnz, const int32_t* nnz_dev,
-                          const float* d_output, const CorePtrsMut& d_cores, void* ws,
+                          const int64_t* rowidx, const int64_t* offsets, int64_t nnz, const int32_t* nnz_dev,
+                          int64_t B, const float* d_output, const CorePtrsMut& d_cores, void* ws,
                           int64_t ws_bytes, const void* plan, int64_t plan_bytes, hipStream_t st);
 
 // ---------------------------------------------------------------------------------

@@ -58,7 +58,11 @@ struct Cfg {
   static constexpr int LDPB = (R2 % 32 == 0) ? R2 + 16 : R2;                            // P rows, read as [4s+hi][lo]
   static constexpr int LDBB = (Q2 % 2 == 1 && ROW2 % 32 == 16) ? ROW2 : ROW2 + 4;       // G2 rows, read as [hi][lo*q2+kk]
   static constexpr int BB2_FLOATS = kChunk * LDBB;
-  static constexpr int LDOB = ((D + 15) / 32) * 32 + 16;                                // d_output rows, read as [hi][m*q2+kk]
+#ifdef TTEMB_LDOB_PLAIN
+  static constexpr int LDOB = D + 4;
+#else
+  static constexpr int LDOB = ((D + 15) / 32) * 32 + 16;
+#endif                                // d_output rows, read as [hi][m*q2+kk]
   static constexpr int OB_FLOATS = kChunk * LDOB;
   static constexpr int PB_FLOATS = ((M2 * LDPB + 3) / 4) * 4;  // backward reads only the M2 real rows of P
   static constexpr int BO_FLOATS = B_FLOATS > O_FLOATS ? B_FLOATS : O_FLOATS;
@@ -111,19 +115,38 @@ struct GroupPlan {           // device pointers into the caller's plan buffer / 
   float* dptab;              // [G][M2*R2] dP of every non-empty group
   float* g2part;             // [tiles][p2][ROW2] per-tile partial dG2
   float* g0part;             // [G][ROW0] per-group contribution to dG0
+  float* g1part;             // [slices][p1][ROW1] per-slice partial dG1
 };
 
 __global__ __launch_bounds__(kTile) void fast3_prep_kernel(
     const int64_t* __restrict__ indices, const int64_t* __restrict__ rowidx,
     const int64_t* __restrict__ offsets, int64_t nnz,
-    const int32_t* __restrict__ nnz_dev, uint32_t sentinel, uint32_t p0, uint32_t p1, uint32_t p2,
-    GroupPlan plan) {
+    const int32_t* __restrict__ nnz_dev, int64_t B, int D, float* __restrict__ zero_out, uint32_t sentinel,
+    uint32_t p0, uint32_t p1, uint32_t p2, GroupPlan plan) {
   const int64_t n = (int64_t)blockIdx.x * kTile + threadIdx.x;
+  // rows whose bag does not hold exactly one id are zeroed here: the forward stores one-id bags and
+  // accumulates into the others (zero_out is null in the backward and when the caller cleared the output)
+  if (zero_out != nullptr && n < B && offsets[n + 1] - offsets[n] != 1) {
+    float4* o = reinterpret_cast<float4*>(zero_out + n * D);
+    for (int c = 0; c * 4 < D; ++c) o[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   const int64_t cnt = live_count(nnz, nnz_dev);
   if (n >= cnt) return;
   int64_t id = indices[n];
   id = id < 0 ? 0 : (id >= (int64_t)sentinel ? (int64_t)sentinel - 1 : id);
-  const int64_t row = rowidx[n];
+  int64_t row;
+  if (rowidx != nullptr) {
+    row = rowidx[n];
+  } else if (n < B && offsets[n] <= n && n < offsets[n + 1]) {
+    row = n;  // the usual case (every bag holds one id) costs two coalesced reads
+  } else {    // bag of position n: the last b with offsets[b] <= n  (tt_embeddings_cuda.cu:1349-1365)
+    int64_t lo = 0, hi = B;  // invariant: offsets[lo] <= n < offsets[hi]
+    while (hi - lo > 1) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (offsets[mid] <= n) lo = mid; else hi = mid;
+    }
+    row = lo;
+  }
   const bool multi = !bag_is_single(rowidx, offsets, n, cnt, row);
   const uint32_t u = (uint32_t)id;
   const uint32_t i0 = u / (p1 * p2);
@@ -172,7 +195,10 @@ __global__ __launch_bounds__(kTile) void fast3_scatter_kernel(int64_t nnz, const
 // holds G1[i1] as MFMA B operands in registers and walks kPrefixGroups values of i0, 16/q0 groups
 // per MFMA tile (the tile's 16 rows are the q0 rows of those groups).
 // ---------------------------------------------------------------------------------
-constexpr int kPrefixGroups = 32;
+#ifndef TTEMB_PREFIX_GROUPS
+#define TTEMB_PREFIX_GROUPS 8
+#endif
+constexpr int kPrefixGroups = TTEMB_PREFIX_GROUPS;   // values of i0 per wavefront
 template <int Q0, int Q1, int Q2, int R1, int R2>
 __global__ __launch_bounds__(64) void fast3_prefix_kernel(const float* __restrict__ G0, const float* __restrict__ G1,
                                                           uint32_t p0, GroupPlan plan) {
@@ -226,23 +252,72 @@ __global__ __launch_bounds__(64) void fast3_prefix_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------
+// Addressing helpers of the chain kernels.  Every global access of their inner loops goes through a buffer
+// descriptor with a per-lane 32-bit byte offset: an offset past the buffer (kOob) makes a load return zeros and
+// a store vanish, so ragged chunks need no branch around a memory instruction -- the instruction stream per
+// chunk is fixed, and the compiler can count outstanding operations exactly (a skipped instruction would force
+// every later wait to vmcnt(0), i.e. to drain the prefetch that was just issued).
+// ---------------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr uint32_t kOob = 0xffffffffu;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load4(rsrc_t r, uint32_t voff) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ u32x4 buf_load4u(rsrc_t r, uint32_t voff) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0);
+}
+__device__ __forceinline__ uint32_t buf_load1u(rsrc_t r, uint32_t voff) {
+  return __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, 0, 0);
+}
+__device__ __forceinline__ void buf_store4(rsrc_t r, uint32_t voff, const float4& x) {
+  u32x4 v;
+  v.x = __float_as_uint(x.x);
+  v.y = __float_as_uint(x.y);
+  v.z = __float_as_uint(x.z);
+  v.w = __float_as_uint(x.w);
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, 0, 0);
+}
+__device__ __forceinline__ void buf_store1(rsrc_t r, uint32_t voff, float x) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), r, (int)voff, 0, 0);
+}
+
+// Chunk descriptors are read through the constant address space with a wave-uniform index: scalar loads
+// (s_load_dwordx4), which are counted by lgkmcnt, not vmcnt, and so never sit in the queue of the row loads.
+typedef const __attribute__((address_space(4))) uint32_t* desc_ptr;
+__device__ __forceinline__ uint4 load_desc(desc_ptr tab, uint32_t c, uint32_t nchunks) {
+  const uint32_t at = 4u * (c < nchunks ? c : nchunks - 1);
+  const uint32_t keep = c < nchunks ? 0xffffffffu : 0u;   // past the table: an empty chunk
+  return make_uint4(tab[at] & keep, tab[at + 1] & keep, tab[at + 2] & keep, tab[at + 3] & keep);
+}
+
+// ---------------------------------------------------------------------------------
 // forward
 //
-// One wavefront takes kCPW consecutive chunk descriptors.  Everything it needs for a chunk is known two
+// One wavefront takes kCPWF consecutive chunk descriptors.  Everything it needs for a chunk is known two
 // steps ahead, so the loop is a software pipeline with no data-dependent control flow: while chunk c is
-// multiplied, the G2 rows (and, when c+1 opens a group, the prefix product) of chunk c+1 are in flight
-// into registers and the (i2, row) pairs of chunk c+2 are being fetched.  Lanes are tied to ids four by
-// four (lane = 4 * id + piece): a lane loads the pieces j, j+4, ... of "its" id's rows and later stores
-// the same pieces of its output row, so no lane ever needs another lane's index.
+// multiplied, the G2 rows and the prefix product of chunk c+1 are in flight into registers and the (i2, row)
+// pairs of chunk c+2 are being fetched.  Lanes are tied to ids four by four (lane = 4 * id + piece): a lane
+// loads the pieces j, j+4, ... of "its" id's rows and later stores the same pieces of its output row, so no
+// lane ever needs another lane's index.
 // ---------------------------------------------------------------------------------
-#ifndef TTEMB_CPW
-#define TTEMB_CPW 6
+#ifndef TTEMB_CPW_FWD
+#define TTEMB_CPW_FWD 3
 #endif
-constexpr int kCPW = TTEMB_CPW;   // chunks per wavefront
+#ifndef TTEMB_CPW_BWD
+#define TTEMB_CPW_BWD 2
+#endif
+constexpr int kCPWF = TTEMB_CPW_FWD, kCPWB = TTEMB_CPW_BWD;   // chunk descriptors per wavefront
 
 template <int Q0, int Q1, int Q2, int R1, int R2>
 __global__ __launch_bounds__(64) void fast3_forward_kernel(const float* __restrict__ G2, GroupPlan plan, uint32_t G,
-                                                           float* __restrict__ out) {
+                                                           uint32_t p2, uint32_t nnz, float* __restrict__ out,
+                                                           uint32_t out_bytes) {
   using C = Cfg<Q0, Q1, Q2, R1, R2>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x;
@@ -253,58 +328,56 @@ __global__ __launch_bounds__(64) void fast3_forward_kernel(const float* __restri
   float* obuf = bbuf;
 
   const uint32_t nchunks = (uint32_t)(plan.gpre[G] >> 32);
-  const uint32_t c0 = blockIdx.x * kCPW;
+  const uint32_t c0 = blockIdx.x * kCPWF;
   if (c0 >= nchunks) return;
-  const uint32_t c1 = c0 + kCPW < nchunks ? c0 + kCPW : nchunks;
+  const uint32_t c1 = c0 + kCPWF < nchunks ? c0 + kCPWF : nchunks;
 
   constexpr int F4G = C::ROW2 / 4, NLG = (F4G + 3) / 4;     // float4 pieces of a G2 row / per lane
   constexpr int D4 = C::D / 4, NLO = (D4 + 3) / 4;          // float4 pieces of an output row / per lane
-  constexpr int PF = C::M2 * R2, NLP = (PF + kWave - 1) / kWave;
-  const uint4 none = make_uint4(0u, 0u, 0u, 0u);
+  constexpr int PF = C::M2 * R2, PF4 = PF / 4, NLP = (PF4 + kWave - 1) / kWave;
+  const desc_ptr ctab = (desc_ptr)plan.ctab;
+  const rsrc_t r_i2 = make_rsrc(plan.i2s, nnz * 4u), r_val = make_rsrc(plan.vals, nnz * 4u);
+  const rsrc_t r_g2 = make_rsrc(G2, p2 * (uint32_t)C::ROW2 * 4u);
+  const rsrc_t r_p = make_rsrc(plan.ptab, G * (uint32_t)PF * 4u);
+  const rsrc_t r_out = make_rsrc(out, out_bytes);
 
   auto fetch_meta = [&](const uint4& d, uint32_t& i2, uint32_t& val) {
-    i2 = 0u;  // row 0 stands in for unused slots
-    val = 0u;
-    if (b_l < (int)(d.z & 0xffu)) {
-      i2 = plan.i2s[d.x + b_l];
-      val = plan.vals[d.x + b_l];
-    }
+    const uint32_t voff = b_l < (int)(d.z & 0xffu) ? (d.x + (uint32_t)b_l) * 4u : kOob;
+    i2 = buf_load1u(r_i2, voff);   // unused slots read 0: row 0 stands in
+    val = buf_load1u(r_val, voff);
   };
-  float4 pre_g[NLG];
-  float pre_p[NLP];
-  auto request = [&](const uint4& d, uint32_t i2, bool with_p) {
-    const float* row = G2 + i2 * (uint32_t)C::ROW2;
+  float4 pre_g[NLG], pre_p[NLP];
+  auto request = [&](const uint4& d, uint32_t i2, bool with_p) {   // with_p is wave-uniform: only offsets change
+    const uint32_t row = i2 * (uint32_t)(C::ROW2 * 4) + 16u * j_l;
 #pragma unroll
-    for (int k = 0; k < NLG; ++k) {
-      const int idx = j_l + 4 * k;
-      pre_g[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (F4G % 4 == 0 || idx < F4G) pre_g[k] = *reinterpret_cast<const float4*>(row + 4 * idx);
-    }
-    if (with_p) {
-      const float* p = plan.ptab + (size_t)d.y * PF;
+    for (int k = 0; k < NLG; ++k)
+      pre_g[k] = buf_load4(r_g2, (F4G % 4 == 0 || j_l + 4 * k < F4G) ? row + 64u * k : kOob);
 #pragma unroll
-      for (int it = 0; it < NLP; ++it) {
-        const int e = it * kWave + lane;
-        pre_p[it] = (PF % kWave == 0 || e < PF) ? p[e] : 0.f;
-      }
+    for (int it = 0; it < NLP; ++it) {
+      const int e = it * kWave + lane;
+      pre_p[it] = buf_load4(r_p, (with_p && (PF4 % kWave == 0 || e < PF4)) ? d.y * (uint32_t)(PF * 4) + 16u * e : kOob);
     }
   };
 
-  uint4 d_cur = plan.ctab[c0];
-  uint4 d_nxt = c0 + 1 < c1 ? plan.ctab[c0 + 1] : none;
-  uint32_t i2_cur, val_cur, i2_nxt = 0u, val_nxt = 0u;
+  uint4 d_cur = load_desc(ctab, c0, c1);
+  uint4 d_nxt = load_desc(ctab, c0 + 1, c1);   // past c1: an empty chunk
+  uint32_t i2_cur, val_cur, i2_nxt, val_nxt;
   fetch_meta(d_cur, i2_cur, val_cur);
   request(d_cur, i2_cur, true);
-  if (c0 + 1 < c1) fetch_meta(d_nxt, i2_nxt, val_nxt);
+  fetch_meta(d_nxt, i2_nxt, val_nxt);
 
   for (uint32_t c = c0; c < c1; ++c) {
     const int len = (int)(d_cur.z & 0xffu);
-    // ---- the prefix product of a new group -> LDS, as a (q0 q1) x r2 matrix ----
-    if (c == c0 || (d_cur.z & kFirstBit)) {
+    // ---- the prefix product of a new group -> LDS, as a (q0 q1) x r2 matrix (P rows are padded: b32 writes) ----
 #pragma unroll
-      for (int it = 0; it < NLP; ++it) {
-        const int e = it * kWave + lane;
-        if (PF % kWave == 0 || e < PF) pbuf[(e / R2) * C::LDA + e % R2] = pre_p[it];
+    for (int it = 0; it < NLP; ++it) {
+      const int e = it * kWave + lane;
+      if ((c == c0 || (d_cur.z & kFirstBit)) && (PF4 % kWave == 0 || e < PF4)) {
+        float* dst = pbuf + (4 * e / R2) * C::LDA + (4 * e) % R2;
+        dst[0] = pre_p[it].x;
+        dst[1] = pre_p[it].y;
+        dst[2] = pre_p[it].z;
+        dst[3] = pre_p[it].w;
       }
     }
     // ---- the chunk's G2 rows: registers -> LDS ----
@@ -316,10 +389,10 @@ __global__ __launch_bounds__(64) void fast3_forward_kernel(const float* __restri
     __builtin_amdgcn_sched_barrier(0);
     // ---- next chunk's rows and the chunk after's indices go out now; they land while this one computes ----
     const uint32_t val = val_cur;
-    const uint4 d_nn = c + 2 < c1 ? plan.ctab[c + 2] : none;
-    if (c + 1 < c1) request(d_nxt, i2_nxt, (d_nxt.z & kFirstBit) != 0u);
-    uint32_t i2_nn = 0u, val_nn = 0u;
-    if (c + 2 < c1) fetch_meta(d_nn, i2_nn, val_nn);
+    const uint4 d_nn = load_desc(ctab, c + 2, c1);
+    request(d_nxt, i2_nxt, (d_nxt.z & kFirstBit) != 0u);
+    uint32_t i2_nn, val_nn;
+    fetch_meta(d_nn, i2_nn, val_nn);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -346,36 +419,48 @@ __global__ __launch_bounds__(64) void fast3_forward_kernel(const float* __restri
         for (int nt = 0; nt < C::NT2; ++nt)
           acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[s][nt], s == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[nt], 0, 0, 0);
       }
-      // rows -> LDS, id-major
+      // rows -> LDS, id-major.  q0 q1 is a multiple of 4, so a lane's four rows 16 mt + 4 hi + r are in or out together
+      if (16 * mt + 4 * hi + 3 < C::M2) {
 #pragma unroll
-      for (int nt = 0; nt < C::NT2; ++nt) {
-        const int n = 16 * nt + lo;
-        const int b = n / Q2, kk = n % Q2;
+        for (int nt = 0; nt < C::NT2; ++nt) {
+          const int n = 16 * nt + lo;
+          const int b = n / Q2, kk = n % Q2;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = 16 * mt + 4 * hi + r;
-          if (m < C::M2) obuf[b * C::LDO + m * Q2 + kk] = acc[nt][r];
+          for (int r = 0; r < 4; ++r) obuf[b * C::LDO + (16 * mt + 4 * hi + r) * Q2 + kk] = acc[nt][r];
         }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ---- 16-byte global stores: four lanes per row ----
-    if (b_l < len) {
-      float* dst = out + (val & ~kMultiBit) * (uint32_t)C::D;  // B*D < 2^32: checked on the host
+    // ---- 16-byte global stores: four lanes per row; all LDS reads first ----
+    {
+      const bool row_ok = b_l < len;
+      const uint32_t row_off = (val & ~kMultiBit) * (uint32_t)(C::D * 4) + 16u * j_l;  // B*D*4 < 2^32: checked on the host
+      float4 x[NLO];
 #pragma unroll
       for (int k = 0; k < NLO; ++k) {
-        const int idx = j_l + 4 * k;
-        if (D4 % 4 == 0 || idx < D4) {
-          const float4 x = *reinterpret_cast<const float4*>(obuf + b_l * C::LDO + 4 * idx);
-          if (val & kMultiBit) {
-            atomicAdd(dst + 4 * idx + 0, x.x);
-            atomicAdd(dst + 4 * idx + 1, x.y);
-            atomicAdd(dst + 4 * idx + 2, x.z);
-            atomicAdd(dst + 4 * idx + 3, x.w);
-          } else {
-            *reinterpret_cast<float4*>(dst + 4 * idx) = x;
+        const int idx = j_l + 4 * k < D4 ? j_l + 4 * k : D4 - 1;
+        x[k] = *reinterpret_cast<const float4*>(obuf + b_l * C::LDO + 4 * idx);
+      }
+      if (__ballot(row_ok && (val & kMultiBit)) == 0ull) {  // the usual case: every bag of the chunk holds one id
+#pragma unroll
+        for (int k = 0; k < NLO; ++k)
+          buf_store4(r_out, (row_ok && (D4 % 4 == 0 || j_l + 4 * k < D4)) ? row_off + 64u * k : kOob, x[k]);
+      } else {
+        float* dst = out + (val & ~kMultiBit) * (uint32_t)C::D;
+#pragma unroll
+        for (int k = 0; k < NLO; ++k) {
+          const int idx = j_l + 4 * k;
+          if (row_ok && (D4 % 4 == 0 || idx < D4)) {
+            if (val & kMultiBit) {
+              atomicAdd(dst + 4 * idx + 0, x[k].x);
+              atomicAdd(dst + 4 * idx + 1, x[k].y);
+              atomicAdd(dst + 4 * idx + 2, x[k].z);
+              atomicAdd(dst + 4 * idx + 3, x[k].w);
+            } else {
+              *reinterpret_cast<float4*>(dst + 4 * idx) = x[k];
+            }
           }
         }
       }
@@ -399,14 +484,15 @@ __global__ __launch_bounds__(64) void fast3_forward_kernel(const float* __restri
 //     and per group dP is stored in its own slot.  Plain stores only.
 //  B. dG2[i2] = sum of the E rows whose id has that i2 (tile-local bucket sums, per-tile slabs).
 //  C. group epilogue: per non-empty group (groups are (i1, i0)-ordered)
-//        dG1[i1] += G0[i0]^T . dP  (registers while i1 repeats),  dG0[i0] += dP . G1[i1]^T.
-//  D. finalize: dG2 = sum of slabs, dG0 = sum of per-group parts.
+//        dG1[i1] += G0[i0]^T . dP  (registers over a slice of i0, per-slice slabs),  dG0[i0] += dP . G1[i1]^T.
+//  D. finalize: dG2 / dG1 = sum of slabs, dG0 = sum of per-group parts.
 // LDS float atomics cost ~160 LDS cycles per wave-instruction on gfx950 (measured), global
 // ones ~1.3 TB/s chip-wide; a store pass + per-destination sum pass is several times cheaper.
 // ---------------------------------------------------------------------------------
 template <int Q0, int Q1, int Q2, int R1, int R2>
-__global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(const float* __restrict__ G2, uint32_t G,
-                                                             const float* __restrict__ d_out, GroupPlan plan) {
+__global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(const float* __restrict__ G2, uint32_t G, uint32_t p2,
+                                                             uint32_t nnz, const float* __restrict__ d_out,
+                                                             uint32_t dout_bytes, GroupPlan plan) {
   using C = Cfg<Q0, Q1, Q2, R1, R2>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x;
@@ -416,20 +502,32 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(const float* __rest
   float* bbuf = pbuf + C::PB_FLOATS;   // staged G2 rows
   float* dbuf = bbuf + C::BB2_FLOATS;  // staged d_output rows
 
-  // A wavefront owns the groups whose FIRST chunk lies in its kCPW descriptors: it skips the tail of a
+  // A wavefront owns the groups whose FIRST chunk lies in its kCPWB descriptors: it skips the tail of a
   // group that began earlier and follows its last group to the end, so every group is handled by exactly
   // one wavefront and its dP needs no partial sums.
   const uint32_t nchunks = (uint32_t)(plan.gpre[G] >> 32);
-  const uint32_t c0 = blockIdx.x * kCPW;
+  const uint32_t c0 = blockIdx.x * kCPWB;
   if (c0 >= nchunks) return;
-  const uint32_t c1 = c0 + kCPW < nchunks ? c0 + kCPW : nchunks;
+  const uint32_t c1 = c0 + kCPWB < nchunks ? c0 + kCPWB : nchunks;
   uint32_t c = c0;
-  uint4 d_cur = plan.ctab[c];
-  if (!(d_cur.z & kFirstBit)) {
-    c = d_cur.w;  // first chunk of the next group
-    if (c >= c1) return;
-    d_cur = plan.ctab[c];
+  {
+    const uint4 d = plan.ctab[c0];
+    if (!(d.z & kFirstBit)) {
+      c = d.w;  // first chunk of the next group
+      if (c >= c1) return;
+    }
   }
+
+  constexpr int F4G = C::ROW2 / 4, NLG = (F4G + 3) / 4;   // float4 pieces of a G2 row / per lane (4 lanes per id)
+  constexpr int F4D = C::D / 4, NLD = (F4D + 3) / 4;      // float4 pieces of a d_output row / per lane
+  constexpr int PF = C::M2 * R2, PF4 = PF / 4, NLP = (PF4 + kWave - 1) / kWave;
+  const desc_ptr ctab = (desc_ptr)plan.ctab;
+  const rsrc_t r_i2 = make_rsrc(plan.i2s, nnz * 4u), r_val = make_rsrc(plan.vals, nnz * 4u);
+  const rsrc_t r_g2 = make_rsrc(G2, p2 * (uint32_t)C::ROW2 * 4u);
+  const rsrc_t r_p = make_rsrc(plan.ptab, G * (uint32_t)PF * 4u);
+  const rsrc_t r_do = make_rsrc(d_out, dout_bytes);
+  const rsrc_t r_e = make_rsrc(plan.etab, nnz * (uint32_t)C::ROW2 * 4u);
+  const rsrc_t r_dp = make_rsrc(plan.dptab, G * (uint32_t)PF * 4u);
 
   // ---- lane-constant LDS offsets of the MFMA operands ----
   // dP step (b4, kk): lane group `hi` contributes id b = 4 b4 + hi, column kk of that id
@@ -446,82 +544,45 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(const float* __rest
     const int col = 16 * nt + lo;
     offE[nt] = (col / Q2) * C::LDOB + col % Q2 + hi * Q2;
   }
-  constexpr int F4G = C::ROW2 / 4, NLG = (F4G + 3) / 4;   // float4 pieces of a G2 row / per lane (4 lanes per id)
-  constexpr int F4D = C::D / 4, NLD = (F4D + 3) / 4;      // float4 pieces of a d_output row / per lane
-  constexpr int PF4 = C::M2 * R2 / 4, NLP = (PF4 + kWave - 1) / kWave;
-  const uint4 none = make_uint4(0u, 0u, 0u, 0u);
 
+  // Pipeline of one wavefront (k = the chunk being multiplied):
+  //     multiply chunk k out of LDS | rows of k+1: registers -> LDS | offsets of k+2 from its (i2, row) pairs |
+  //     store E / dP of k | load rows of k+2 | load the (i2, row) pairs of k+3
+  // Stores are issued only after everything the next steps wait for has been consumed, so no wait ever sits
+  // behind a store; rows travel through registers and are in flight during one whole multiply.
+  struct Offs {
+    uint32_t row, grow, prow;   // byte offsets of this lane's pieces: G2 row, d_output row (kOob = no id), P
+  };
   auto fetch_meta = [&](const uint4& d, uint32_t& i2, uint32_t& val) {
-    i2 = 0u;
-    val = 0xffffffffu;  // no row: the staged gradient row is zero
-    if (b_l < (int)(d.z & 0xffu)) {
-      i2 = plan.i2s[d.x + b_l];
-      val = plan.vals[d.x + b_l] & ~kMultiBit;
-    }
+    const uint32_t voff = b_l < (int)(d.z & 0xffu) ? (d.x + (uint32_t)b_l) * 4u : kOob;
+    i2 = buf_load1u(r_i2, voff);   // unused slots read 0: G2 row 0 stands in (its gradient row is zero)
+    val = buf_load1u(r_val, voff);
   };
-  // the chunk's G2 rows, d_output rows and (for a group's first chunk) P travel through registers: they are
-  // requested one chunk ahead so that their HBM / L2 latency hides behind the previous chunk's MFMAs
+  auto offsets = [&](const uint4& d, uint32_t i2, uint32_t val) {
+    Offs o;
+    o.row = i2 * (uint32_t)(C::ROW2 * 4) + 16u * j_l;
+#if defined(TTEMB_ABL) && (TTEMB_ABL & 2)
+    o.grow = b_l < (int)(d.z & 0xffu) ? (val & 1023u) * (uint32_t)(C::D * 4) + 16u * j_l : kOob;  // ablation: cache-resident rows
+#else
+    o.grow = b_l < (int)(d.z & 0xffu) ? (val & ~kMultiBit) * (uint32_t)(C::D * 4) + 16u * j_l : kOob;  // B*D*4 < 2^32 (host)
+#endif
+    o.prow = (d.z & kFirstBit) ? d.y * (uint32_t)(PF * 4) + 16u * lane : kOob;
+    return o;
+  };
   float4 pre_g[NLG], pre_d[NLD], pre_p[NLP];
-  auto request = [&](const uint4& d, uint32_t i2, uint32_t val) {
-    const float* row = G2 + i2 * (uint32_t)C::ROW2;
+  auto request = [&](const Offs& o) {
 #pragma unroll
-    for (int k = 0; k < NLG; ++k) {
-      const int idx = j_l + 4 * k;
-      pre_g[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (F4G % 4 == 0 || idx < F4G) pre_g[k] = *reinterpret_cast<const float4*>(row + 4 * idx);
-    }
-    const float* grow = d_out + val * (uint32_t)C::D;  // B*D < 2^32: checked on the host
+    for (int k = 0; k < NLG; ++k)
+      pre_g[k] = buf_load4(r_g2, (F4G % 4 == 0 || j_l + 4 * k < F4G) ? o.row + 64u * k : kOob);
 #pragma unroll
-    for (int k = 0; k < NLD; ++k) {
-      const int idx = j_l + 4 * k;
-      pre_d[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if ((F4D % 4 == 0 || idx < F4D) && val != 0xffffffffu) pre_d[k] = *reinterpret_cast<const float4*>(grow + 4 * idx);
-    }
-    if (d.z & kFirstBit) {
-      const float* p = plan.ptab + (size_t)d.y * (C::M2 * R2);
+    for (int k = 0; k < NLD; ++k)
+      pre_d[k] = buf_load4(r_do, (o.grow != kOob && (F4D % 4 == 0 || j_l + 4 * k < F4D)) ? o.grow + 64u * k : kOob);
 #pragma unroll
-      for (int it = 0; it < NLP; ++it) {
-        const int e = it * kWave + lane;
-        pre_p[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (PF4 % kWave == 0 || e < PF4) pre_p[it] = *reinterpret_cast<const float4*>(p + 4 * e);
-      }
-    }
+    for (int it = 0; it < NLP; ++it)
+      pre_p[it] = buf_load4(r_p, (o.prow != kOob && (PF4 % kWave == 0 || it * kWave + lane < PF4)) ? o.prow + 1024u * it : kOob);
   };
-
-  f32x4 dp[C::MT2][C::RT2];
-  auto store_dp = [&](uint32_t group) {
-    float* dst = plan.dptab + (size_t)group * (C::M2 * R2);
-#pragma unroll
-    for (int mt = 0; mt < C::MT2; ++mt)
-#pragma unroll
-      for (int t = 0; t < C::RT2; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = 16 * mt + 4 * hi + r;
-          const int c2 = 16 * t + lo;
-          if (m < C::M2 && c2 < R2) dst[m * R2 + c2] = dp[mt][t][r];
-        }
-  };
-
-  // which chunk follows `cc` for this wavefront: the next one, unless `cc` closed a group at or past the range end
-  auto has_next = [&](uint32_t cc, const uint4& d) { return cc + 1 < nchunks && !((d.z & kLastBit) && cc + 1 >= c1); };
-
-  bool more1 = has_next(c, d_cur);
-  uint4 d_nxt = more1 ? plan.ctab[c + 1] : none;
-  uint32_t i2_cur, val_cur, i2_nxt = 0u, val_nxt = 0xffffffffu;
-  fetch_meta(d_cur, i2_cur, val_cur);
-  request(d_cur, i2_cur, val_cur);
-  if (more1) fetch_meta(d_nxt, i2_nxt, val_nxt);
-
-  for (;;) {
-    const int len = (int)(d_cur.z & 0xffu);
-    const uint32_t here = d_cur.x;
-    // ---- group change: P of the new group -> LDS, dP starts from zero ----
-    if (d_cur.z & kFirstBit) {
-#pragma unroll
-      for (int mt = 0; mt < C::MT2; ++mt)
-#pragma unroll
-        for (int t = 0; t < C::RT2; ++t) dp[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  auto stage = [&](bool with_p) {   // registers -> LDS
+    if (with_p) {
 #pragma unroll
       for (int it = 0; it < NLP; ++it) {
         const int e = it * kWave + lane;  // float4 number e of the (q0 q1) x r2 matrix
@@ -529,7 +590,6 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(const float* __rest
           *reinterpret_cast<float4*>(pbuf + (4 * e / R2) * C::LDPB + (4 * e) % R2) = pre_p[it];
       }
     }
-    // ---- the chunk's rows: registers -> LDS ----
 #pragma unroll
     for (int k = 0; k < NLG; ++k) {
       const int idx = j_l + 4 * k;
@@ -540,18 +600,44 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(const float* __rest
       const int idx = j_l + 4 * k;
       if (F4D % 4 == 0 || idx < F4D) *reinterpret_cast<float4*>(dbuf + b_l * C::LDOB + 4 * idx) = pre_d[k];
     }
-    __builtin_amdgcn_sched_barrier(0);  // the row registers are free again only after the stores above
-    // ---- request the next chunk's rows and the chunk after's indices now; they land while this chunk computes ----
-    const uint4 d_done = d_cur;
-    const bool more2 = more1 && has_next(c + 1, d_nxt);
-    const uint4 d_nn = more2 ? plan.ctab[c + 2] : none;
-    if (more1) request(d_nxt, i2_nxt, val_nxt);
-    uint32_t i2_nn = 0u, val_nn = 0xffffffffu;
-    if (more2) fetch_meta(d_nn, i2_nn, val_nn);
+  };
+
+  f32x4 dp[C::MT2][C::RT2];
+  // which chunk follows `cc` for this wavefront: the next one, unless `cc` closed a group at or past the range end
+  auto has_next = [&](uint32_t cc, const uint4& d) { return cc + 1 < nchunks && !((d.z & kLastBit) && cc + 1 >= c1); };
+  const uint4 none = make_uint4(0u, 0u, 0u, 0u);
+
+  // ---- prologue: chunk 0 into LDS, rows of chunk 1 and the pairs of chunk 2 in flight ----
+  uint4 d_cur = load_desc(ctab, c, nchunks);
+  bool more1 = has_next(c, d_cur);
+  uint4 d_nxt = load_desc(ctab, c + 1, nchunks);
+  if (!more1) d_nxt = none;
+  bool more2 = more1 && has_next(c + 1, d_nxt);
+  uint4 d_nn = load_desc(ctab, c + 2, nchunks);
+  if (!more2) d_nn = none;
+  uint32_t i2_a, val_a, i2_b, val_b;
+  fetch_meta(d_cur, i2_a, val_a);
+  fetch_meta(d_nxt, i2_b, val_b);
+  request(offsets(d_cur, i2_a, val_a));
+  stage(true);
+  __builtin_amdgcn_sched_barrier(0);
+  request(offsets(d_nxt, i2_b, val_b));
+  uint32_t i2_nn, val_nn;
+  fetch_meta(d_nn, i2_nn, val_nn);
+
+  for (;;) {
+    const int len = (int)(d_cur.z & 0xffu);
+    const uint32_t here = d_cur.x;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_sched_barrier(0);
+    if (d_cur.z & kFirstBit) {
+#pragma unroll
+      for (int mt = 0; mt < C::MT2; ++mt)
+#pragma unroll
+        for (int t = 0; t < C::RT2; ++t) dp[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 
     // ---- dP += dO (q0q1 x 16 q2) . G2s^T (16 q2 x r2) ----
 #pragma unroll
@@ -597,33 +683,59 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(const float* __rest
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    // E leaves straight from the accumulators.  Lane (hi, lo) holds E[c2 = 16 t + 4 hi + r][col = 16 nt + lo]
-    // with col = id * q2 + kk, and the E table keeps an id's row as [kk][c2] (the reduce kernel sums rows
-    // element by element, the finalize kernel puts dG2 back into [c2][kk]): the chunk's rows are then one
-    // contiguous block indexed col * r2 + c2, and the 64 lanes of one (t, nt) write 16-byte pieces of it.
-    {
-      float* dst = plan.etab + (size_t)here * C::ROW2;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // every LDS read of this chunk is done: the next chunk's rows may land
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- rows of the next chunk: registers -> LDS; then the offsets of the chunk after (consumes its pairs) ----
+    stage((d_nxt.z & kFirstBit) != 0u);
+    const Offs o_nn = offsets(d_nn, i2_nn, val_nn);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- this chunk's results leave now: no load is waited for behind these stores ----
+    // Lane (hi, lo) holds E[c2 = 16 t + 4 hi + r][col = 16 nt + lo] with col = id * q2 + kk, and the E table keeps
+    // an id's row as [kk][c2] (the reduce kernel sums rows element by element, the finalize kernel puts dG2 back
+    // into [c2][kk]): the chunk's rows are one contiguous block indexed col * r2 + c2, written in 16-byte pieces.
 #pragma unroll
-      for (int nt = 0; nt < C::NT2; ++nt) {
-        const int col = 16 * nt + lo;
+    for (int nt = 0; nt < C::NT2; ++nt) {
+      const int col = 16 * nt + lo;
 #pragma unroll
-        for (int t = 0; t < C::RT2; ++t) {
-          const int c2 = 16 * t + 4 * hi;
-          if (col < len * Q2 && c2 < R2)
-            *reinterpret_cast<float4*>(dst + col * R2 + c2) = make_float4(e[t][nt][0], e[t][nt][1], e[t][nt][2], e[t][nt][3]);
-        }
+      for (int t = 0; t < C::RT2; ++t) {
+        const int c2 = 16 * t + 4 * hi;
+        const uint32_t off = (here * (uint32_t)C::ROW2 + (uint32_t)(col * R2 + c2)) * 4u;
+#if defined(TTEMB_ABL) && (TTEMB_ABL & 1)
+        buf_store4(r_e, kOob, make_float4(   // ablation: no E traffic
+#else
+        buf_store4(r_e, (col < len * Q2 && c2 < R2) ? off : kOob, make_float4(
+#endif
+            e[t][nt][0], e[t][nt][1], e[t][nt][2], e[t][nt][3]));
       }
     }
-    if (d_done.z & kLastBit) store_dp(d_done.y);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();  // every LDS read of this chunk is done before the next rows land
+    {  // dP of a finished group (for the other chunks the stores fall off the end of the buffer)
+      const bool closing = (d_cur.z & kLastBit) != 0u;
+      const uint32_t base = d_cur.y * (uint32_t)(PF * 4);
+#pragma unroll
+      for (int mt = 0; mt < C::MT2; ++mt)
+#pragma unroll
+        for (int t = 0; t < C::RT2; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = 16 * mt + 4 * hi + r;
+            const int c2 = 16 * t + lo;
+            buf_store1(r_dp, (closing && m < C::M2 && c2 < R2) ? base + (uint32_t)(m * R2 + c2) * 4u : kOob, dp[mt][t][r]);
+          }
+    }
     if (!more1) break;
+    // ---- loads of the chunk after next, pairs of the one after that ----
+    request(o_nn);
     ++c;
     d_cur = d_nxt;
     d_nxt = d_nn;
     more1 = more2;
-    i2_nxt = i2_nn;
-    val_nxt = val_nn;
+    more2 = more1 && has_next(c + 1, d_nxt);
+    d_nn = load_desc(ctab, c + 2, nchunks);
+    if (!more2) d_nn = none;
+    fetch_meta(d_nn, i2_nn, val_nn);
   }
 }
 
@@ -715,110 +827,131 @@ __global__ __launch_bounds__(NWB * 64) void fast3_dg2_reduce_kernel(GroupPlan pl
   }
 }
 
-// C. group epilogue: one wavefront per kGroupsC consecutive groups (empty ones are skipped)
-#ifndef TTEMB_GROUPS_C
-#define TTEMB_GROUPS_C 8
+// C. group epilogue: one wavefront per (i1, slice of `gpw` consecutive i0) -- groups are numbered i1 * p0 + i0.
+//    dG1[i1] += G0[i0]^T . dP accumulates in MFMA registers over the slice and leaves as the slice's own slab
+//    (plain stores; the first version flushed with float atomics: 2.8 M of them per launch bounded the kernel),
+//    the dG0 contribution dP . G1[i1]^T is stored per group.  The finalize kernel adds slabs and contributions.
+//    The loop body is the same instruction stream for every group: an empty group's dP load falls off its buffer
+//    (zeros), so it multiplies zeros and stores a zero contribution -- no branch around a memory instruction, the
+//    next group's operands are requested before this group's MFMAs and its stores are issued after them.
+#ifndef TTEMB_EPI_SLICES
+#define TTEMB_EPI_SLICES 16
 #endif
-constexpr int kGroupsC = TTEMB_GROUPS_C;
+constexpr int kEpiSlices = TTEMB_EPI_SLICES;   // target number of i0 slices (dG1 slabs)
 template <int Q0, int Q1, int Q2, int R1, int R2>
 __global__ __launch_bounds__(64) void fast3_group_epilogue_kernel(
-    const float* __restrict__ G0, const float* __restrict__ G1, uint32_t p0, uint32_t G, GroupPlan plan,
-    float* __restrict__ dG1) {
+    const float* __restrict__ G0, const float* __restrict__ G1, uint32_t p0, uint32_t p1, uint32_t gpw, GroupPlan plan) {
   using C = Cfg<Q0, Q1, Q2, R1, R2>;
   __shared__ __attribute__((aligned(16))) float dpbuf[C::P_FLOATS];
   __shared__ __attribute__((aligned(16))) float g1buf[R1 * C::LDG];
   const int lane = threadIdx.x;
   const int hi = lane >> 4, lo = lane & 15;
-  const uint32_t g_begin = blockIdx.x * kGroupsC;
-  const uint32_t g_end = g_begin + kGroupsC < G ? g_begin + kGroupsC : G;
+  const uint32_t i1 = blockIdx.y;
+  const uint32_t i0_begin = blockIdx.x * gpw;
+  const uint32_t i0_end = i0_begin + gpw < p0 ? i0_begin + gpw : p0;
+  const uint32_t g_begin = i1 * p0 + i0_begin;
+  const uint32_t G = p0 * p1;
+  constexpr int PF = C::M2 * R2;
+  constexpr int PER = (PF + kWave - 1) / kWave;
+  constexpr int KS0 = (Q0 + 3) / 4;
+  constexpr int KS3 = C::N1 / 4;
+  const rsrc_t r_dp = make_rsrc(plan.dptab, G * (uint32_t)PF * 4u);
+  const rsrc_t r_g0 = make_rsrc(G0, p0 * (uint32_t)C::ROW0 * 4u);
+  const rsrc_t r_part = make_rsrc(plan.g0part, G * (uint32_t)C::ROW0 * 4u);
 
   f32x4 g1acc[C::RT1][C::NT1];
 #pragma unroll
   for (int t = 0; t < C::RT1; ++t)
 #pragma unroll
     for (int nt = 0; nt < C::NT1; ++nt) g1acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  uint32_t cur_i1 = 0xffffffffu;
-  auto flush_g1 = [&]() {
-    float* dst = dG1 + (size_t)cur_i1 * C::ROW1;
-#pragma unroll
-    for (int t = 0; t < C::RT1; ++t)
-#pragma unroll
-      for (int nt = 0; nt < C::NT1; ++nt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int c = 16 * t + 4 * hi + r;
-          if (c < R1) atomicAdd(dst + c * C::N1 + 16 * nt + lo, g1acc[t][nt][r]);
-        }
-        g1acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      }
-  };
 
-  // which of this wave's groups are non-empty (one lane per group), then walk them with the next
-  // group's dP and G0 operand already requested while the current one is being multiplied
-  const uint32_t cnt_l = (lane < kGroupsC && g_begin + lane < g_end) ? plan.counts[g_begin + lane] : 0u;
-  unsigned long long live = __ballot(cnt_l != 0);
-  if (!live) return;
-  constexpr int PER = (C::M2 * R2 + kWave - 1) / kWave;
-  constexpr int KS0 = (Q0 + 3) / 4;
+  // which of this wave's groups hold ids (one lane per group; gpw <= 64)
+  const uint32_t cnt_l = (i0_begin + lane < i0_end) ? plan.counts[g_begin + lane] : 0u;
+  const unsigned long long live = __ballot(cnt_l != 0);
   float nxt[PER], nxt_g0[KS0][C::RT1];
-  auto request = [&](uint32_t g) {
-    const float* src = plan.dptab + (size_t)g * (C::M2 * R2);
+  auto request = [&](uint32_t k) {   // operands of the slice's k-th group; an empty or missing group reads zeros
+    const bool on = k < gpw && ((live >> k) & 1ull);
+    const uint32_t base = (g_begin + k) * (uint32_t)(PF * 4);
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int e = i * kWave + lane;
-      nxt[i] = e < C::M2 * R2 ? src[e] : 0.f;
+      nxt[i] = __uint_as_float(buf_load1u(r_dp, (on && (PF % kWave == 0 || e < PF)) ? base + 4u * e : kOob));
     }
-    const uint32_t i1n = g / p0;
-    const float* g0 = G0 + (size_t)(g - i1n * p0) * C::ROW0;
+    const uint32_t g0off = (i0_begin + k) * (uint32_t)(C::ROW0 * 4);
 #pragma unroll
     for (int s = 0; s < KS0; ++s)
 #pragma unroll
       for (int t = 0; t < C::RT1; ++t) {
         const int a = 4 * s + hi;
-        nxt_g0[s][t] = (a < Q0 && 16 * t + lo < R1) ? g0[a * R1 + 16 * t + lo] : 0.f;
+        nxt_g0[s][t] = __uint_as_float(
+            buf_load1u(r_g0, (on && a < Q0 && 16 * t + lo < R1) ? g0off + 4u * (a * R1 + 16 * t + lo) : kOob));
       }
   };
-  request(g_begin + __builtin_ctzll(live));
-  while (live) {
-    const uint32_t g = g_begin + __builtin_ctzll(live);
-    live &= live - 1;
-    const uint32_t i1 = g / p0;
+  request(0);
+  {
+    // G1[i1] -> LDS (also for a slice without ids: 0 x stale LDS could be NaN): all loads first -- a load / wait /
+    // store per piece would serialise ~20 L2 round trips
+    const float* g1 = G1 + (size_t)i1 * C::ROW1;
+    constexpr int NG1 = (C::ROW1 + kWave - 1) / kWave;
+    float g1v[NG1];
+#pragma unroll
+    for (int it = 0; it < NG1; ++it) {
+      const int e = it * kWave + lane;
+      g1v[it] = (C::ROW1 % kWave == 0 || e < C::ROW1) ? g1[e] : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < NG1; ++it) {
+      const int e = it * kWave + lane;
+      if (C::ROW1 % kWave == 0 || e < C::ROW1) g1buf[(e / C::N1) * C::LDG + e % C::N1] = g1v[it];
+    }
+  }
+  const uint32_t n_here = i0_end - i0_begin;
+  for (uint32_t k = 0; k < n_here; ++k) {
     // dP of the group -> LDS matrix [m2][c2]
     float g0v[KS0][C::RT1];
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int e = i * kWave + lane;
-      if (e < C::M2 * R2) dpbuf[(e / R2) * C::LDA + e % R2] = nxt[i];
+      if (PF % kWave == 0 || e < PF) dpbuf[(e / R2) * C::LDA + e % R2] = nxt[i];
     }
 #pragma unroll
     for (int s = 0; s < KS0; ++s)
 #pragma unroll
       for (int t = 0; t < C::RT1; ++t) g0v[s][t] = nxt_g0[s][t];
-    if (live) request(g_begin + __builtin_ctzll(live));
-    if (i1 != cur_i1) {
-      if (cur_i1 != 0xffffffffu) flush_g1();
-      cur_i1 = i1;
-      const float* g1 = G1 + (size_t)i1 * C::ROW1;
-#pragma unroll
-      for (int it = 0; it < (C::ROW1 + kWave - 1) / kWave; ++it) {
-        const int e = it * kWave + lane;
-        if (e < C::ROW1) g1buf[(e / C::N1) * C::LDG + e % C::N1] = g1[e];
-      }
-    }
-    __syncthreads();
-    // dG1[i1] += G0[i0]^T (r1 x q0) . dP (q0 x q1 r2)
+    __builtin_amdgcn_sched_barrier(0);
+    request(k + 1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // one wavefront per workgroup: LDS hand-over only (a __syncthreads would also drain the prefetch)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // operands of both products are read from LDS first, then the MFMAs run back to back
+    float b1[KS0][C::NT1];
 #pragma unroll
     for (int s = 0; s < KS0; ++s) {
       const int a = 4 * s + hi;
 #pragma unroll
       for (int nt = 0; nt < C::NT1; ++nt) {
         const int n = 16 * nt + lo;
-        const float bv = a < Q0 ? dpbuf[(a * Q1 + n / R2) * C::LDA + n % R2] : 0.f;
-#pragma unroll
-        for (int t = 0; t < C::RT1; ++t)
-          g1acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(g0v[s][t], bv, g1acc[t][nt], 0, 0, 0);
+        b1[s][nt] = a < Q0 ? dpbuf[(a * Q1 + n / R2) * C::LDA + n % R2] : 0.f;
       }
     }
+    float a3[KS3], b3[KS3][C::RT1];
+#pragma unroll
+    for (int s = 0; s < KS3; ++s) {
+      const int n = 4 * s + hi;
+      a3[s] = lo < Q0 ? dpbuf[(lo * Q1 + n / R2) * C::LDA + n % R2] : 0.f;
+#pragma unroll
+      for (int t = 0; t < C::RT1; ++t) b3[s][t] = 16 * t + lo < R1 ? g1buf[(16 * t + lo) * C::LDG + n] : 0.f;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // every LDS read of this group is done before the next dP lands
+    // dG1[i1] += G0[i0]^T (r1 x q0) . dP (q0 x q1 r2)
+#pragma unroll
+    for (int s = 0; s < KS0; ++s)
+#pragma unroll
+      for (int nt = 0; nt < C::NT1; ++nt)
+#pragma unroll
+        for (int t = 0; t < C::RT1; ++t)
+          g1acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(g0v[s][t], b1[s][nt], g1acc[t][nt], 0, 0, 0);
     // dG0[i0] += dP (q0 x q1 r2) . G1[i1]^T (q1 r2 x r1); four interleaved accumulation chains
     f32x4 g0part[4][C::RT1];
 #pragma unroll
@@ -826,51 +959,79 @@ __global__ __launch_bounds__(64) void fast3_group_epilogue_kernel(
 #pragma unroll
       for (int t = 0; t < C::RT1; ++t) g0part[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < C::N1 / 4; ++s) {
-      const int n = 4 * s + hi;
-      const float av = lo < Q0 ? dpbuf[(lo * Q1 + n / R2) * C::LDA + n % R2] : 0.f;
+    for (int s = 0; s < KS3; ++s)
 #pragma unroll
-      for (int t = 0; t < C::RT1; ++t) {
-        const float bv = 16 * t + lo < R1 ? g1buf[(16 * t + lo) * C::LDG + n] : 0.f;
-        g0part[s & 3][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, g0part[s & 3][t], 0, 0, 0);
-      }
-    }
-    float* dst0 = plan.g0part + (size_t)g * C::ROW0;  // summed over i1 by fast3_finalize_kernel
+      for (int t = 0; t < C::RT1; ++t)
+        g0part[s & 3][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[s], b3[s][t], g0part[s & 3][t], 0, 0, 0);
+    // the group's contribution to dG0 (zeros for an empty group): summed over i1 by fast3_finalize_kernel
+    const uint32_t dst0 = (g_begin + k) * (uint32_t)(C::ROW0 * 4);
 #pragma unroll
     for (int t = 0; t < C::RT1; ++t) {
       const f32x4 sum = (g0part[0][t] + g0part[1][t]) + (g0part[2][t] + g0part[3][t]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int a = 4 * hi + r;
-        if (a < Q0 && 16 * t + lo < R1) dst0[a * R1 + 16 * t + lo] = sum[r];
+        buf_store1(r_part, (a < Q0 && 16 * t + lo < R1) ? dst0 + 4u * (a * R1 + 16 * t + lo) : kOob, sum[r]);
       }
     }
-    __syncthreads();
   }
-  if (cur_i1 != 0xffffffffu) flush_g1();
+  // this slice's dG1[i1] slab: every element is written (zeros when the slice holds no id)
+  float* dst = plan.g1part + ((size_t)blockIdx.x * p1 + i1) * C::ROW1;
+#pragma unroll
+  for (int t = 0; t < C::RT1; ++t)
+#pragma unroll
+    for (int nt = 0; nt < C::NT1; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = 16 * t + 4 * hi + r;
+        if (c < R1) dst[c * C::N1 + 16 * nt + lo] = g1acc[t][nt][r];
+      }
 }
 
-// D. finalize: dG2 = sum of the per-tile slabs; dG0[i0] = sum over i1 of the per-group
-// contributions of the non-empty groups.  A workgroup owns 32 consecutive outputs; its 8 lane
+// D. finalize: dG2 = sum of the per-tile slabs; dG0[i0] = sum over i1 of the per-group contributions of the
+// non-empty groups; dG1 = sum of the per-slice slabs.  A workgroup owns 32 consecutive outputs; its 8 lane
 // rows split the terms, so every load instruction reads 128 contiguous bytes per row and many
 // are in flight; the 8 partial sums meet in LDS.  Every output is written exactly once.
-__global__ __launch_bounds__(256) void fast3_finalize_kernel(GroupPlan plan, int tiles, int p0, int p1,
-                                                             int g2_floats, int row0, int q2, int r2,
-                                                             float* __restrict__ dG0, float* __restrict__ dG2) {
+__global__ __launch_bounds__(256) void fast3_finalize_kernel(GroupPlan plan, int tiles, int slices, int p0, int p1,
+                                                             int g2_floats, int row0, int g1_floats, int q2, int r2,
+                                                             float* __restrict__ dG0, float* __restrict__ dG1,
+                                                             float* __restrict__ dG2) {
   __shared__ float part[8][33];
   const int x = threadIdx.x & 31, y = threadIdx.x >> 5;
   const int e = blockIdx.x * 32 + x;
   const int n0 = p0 * row0;
   float s = 0.f;
+  // U independent partial sums per thread keep that many loads in flight (a single running sum issues them one by one)
+  constexpr int U = 4;
   if (e < g2_floats) {
-    for (int t = y; t < tiles; t += 8) s += plan.g2part[(size_t)t * g2_floats + e];
+    float a[U] = {0.f, 0.f, 0.f, 0.f};
+    for (int t = y; t < tiles; t += 8 * U) {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (t + 8 * u < tiles) a[u] += plan.g2part[(size_t)(t + 8 * u) * g2_floats + e];
+    }
+    s = (a[0] + a[1]) + (a[2] + a[3]);
   } else if (e < g2_floats + n0) {
     const int o = e - g2_floats;
     const int i0 = o / row0, c = o - i0 * row0;
-    for (int i1 = y; i1 < p1; i1 += 8) {
-      const int g = i1 * p0 + i0;
-      if (plan.counts[g]) s += plan.g0part[(size_t)g * row0 + c];
+    float a[U] = {0.f, 0.f, 0.f, 0.f};
+    for (int i1 = y; i1 < p1; i1 += 8 * U) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int g = (i1 + 8 * u) * p0 + i0;
+        if (i1 + 8 * u < p1) a[u] += plan.g0part[(size_t)g * row0 + c];   // empty groups hold zeros
+      }
     }
+    s = (a[0] + a[1]) + (a[2] + a[3]);
+  } else if (e < g2_floats + n0 + g1_floats) {
+    const int o = e - g2_floats - n0;
+    float a[U] = {0.f, 0.f, 0.f, 0.f};
+    for (int t = y; t < slices; t += 8 * U) {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (t + 8 * u < slices) a[u] += plan.g1part[(size_t)(t + 8 * u) * g1_floats + o];
+    }
+    s = (a[0] + a[1]) + (a[2] + a[3]);
   }
   part[y][x] = s;
   __syncthreads();
@@ -885,6 +1046,8 @@ __global__ __launch_bounds__(256) void fast3_finalize_kernel(GroupPlan plan, int
       dG2[i2 * row2 + c2 * q2 + kk] = tot;
     } else if (e < g2_floats + n0) {
       dG0[e - g2_floats] = tot;
+    } else if (e < g2_floats + n0 + g1_floats) {
+      dG1[e - g2_floats - n0] = tot;
     }
   }
 }
@@ -916,15 +1079,30 @@ static int64_t scan_temp_bytes(int64_t G) { return 64 * 1024 + (G + 1) / 8; }
 
 bool fast3_pays(const DevShape& s, int64_t nnz) { return nnz >= 2 * num_groups(s); }
 
+// the chain kernels address every table through 32-bit byte offsets (buffer descriptors): 4 GiB each
+bool fast3_fits(const DevShape& s, int64_t nnz, int64_t B) {
+  const int64_t lim = int64_t(1) << 32;
+  return B * s.D * 4 < lim && nnz * (int64_t)s.row_len[2] * 4 < lim &&
+         num_groups(s) * (int64_t)s.q[0] * s.q[1] * s.R[2] * 4 < lim && s.p[2] < 65536;
+}
+
 #ifndef TTEMB_ROWS_B
 #define TTEMB_ROWS_B 2048
 #endif
 constexpr int kRowsB = TTEMB_ROWS_B;  // E rows per workgroup of the dG2 reduce
 constexpr int NWB = 16;
 static int64_t reduce_tiles(int64_t nnz) { return (nnz + kRowsB - 1) / kRowsB; }
+// the epilogue cuts the i0 range of every i1 into ~kEpiSlices slices of `gpw` groups (one wavefront each)
+static int epi_groups_per_wave(const DevShape& s) {
+  int gpw = (s.p[0] + kEpiSlices - 1) / kEpiSlices;
+  return gpw < 1 ? 1 : (gpw > 64 ? 64 : gpw);
+}
+static int epi_slices(const DevShape& s) { const int g = epi_groups_per_wave(s); return (s.p[0] + g - 1) / g; }
 
-// The grouping that forward and backward share ("plan"): grouped (i2, row) pairs, group sizes / starts and
-// the chunk table.  It lives in a caller buffer when one is given, else in the workspace.
+// What forward and backward share ("plan"): grouped (i2, row) pairs, group sizes / starts, the chunk table and
+// the prefix products.  It lives in a caller buffer when one is given, else in the workspace.  A backward that
+// is handed the forward's plan differentiates the chain at the prefix products the forward used (what autograd's
+// saved tensors mean); one that builds its own plan forms them from the cores as they are then.
 static int64_t max_chunks(const DevShape& s, int64_t nnz) {
   const int64_t G = num_groups(s);
   return nnz / kChunk + (nnz < G ? nnz : G) + 1;
@@ -932,7 +1110,8 @@ static int64_t max_chunks(const DevShape& s, int64_t nnz) {
 
 int64_t fast3_plan_bytes(const DevShape& s, int64_t nnz) {
   const int64_t G = num_groups(s);
-  return 2 * align256(nnz * 4) + align256((G + 1) * 4) + align256((G + 1) * 8) + align256(max_chunks(s, nnz) * 16);
+  return 2 * align256(nnz * 4) + align256((G + 1) * 4) + align256((G + 1) * 8) + align256(max_chunks(s, nnz) * 16) +
+         align256(G * (int64_t)s.q[0] * s.q[1] * s.R[2] * 4);
 }
 
 static void carve_plan_part(const DevShape& s, int64_t nnz, char* base, GroupPlan* pl) {
@@ -946,9 +1125,11 @@ static void carve_plan_part(const DevShape& s, int64_t nnz, char* base, GroupPla
   pl->gpre = (uint64_t*)base;
   base += align256((G + 1) * 8);
   pl->ctab = (uint4*)base;
+  base += align256(max_chunks(s, nnz) * 16);
+  pl->ptab = (float*)base;
 }
 
-// workspace layout: [plan part unless external] [prefix products] [grouping scratch] [backward tables]
+// workspace layout: [plan part unless external] [grouping scratch] [backward tables]
 static int64_t carve_workspace(const DevShape& s, int64_t nnz, bool bwd, bool plan_inside, bool need_grouping,
                                char* base, GroupPlan* pl, char** scan_tmp) {
   const int64_t G = num_groups(s);
@@ -961,10 +1142,6 @@ static int64_t carve_workspace(const DevShape& s, int64_t nnz, bool bwd, bool pl
   if (plan_inside) {
     char* p = take(fast3_plan_bytes(s, nnz));
     if (pl && p) carve_plan_part(s, nnz, p, pl);
-  }
-  {
-    float* pt = (float*)take(G * (int64_t)s.q[0] * s.q[1] * s.R[2] * 4);
-    if (pl) pl->ptab = pt;
   }
   if (need_grouping) {
     uint32_t* a = (uint32_t*)take(nnz * 4);
@@ -983,7 +1160,9 @@ static int64_t carve_workspace(const DevShape& s, int64_t nnz, bool bwd, bool pl
     float* d = (float*)take(G * (int64_t)s.q[0] * s.q[1] * s.R[2] * 4);
     float* g2 = (float*)take(reduce_tiles(nnz) * (int64_t)s.p[2] * s.row_len[2] * 4);
     float* g0 = (float*)take(G * (int64_t)s.row_len[0] * 4);
+    float* g1 = (float*)take((int64_t)epi_slices(s) * s.p[1] * s.row_len[1] * 4);
     if (pl) {
+      pl->g1part = g1;
       pl->etab = e;
       pl->dptab = d;
       pl->g2part = g2;
@@ -999,8 +1178,11 @@ int64_t fast3_workspace_bytes(const DevShape& s, int32_t op, int64_t nnz, int64_
 }
 
 // fill plan->{i2s, vals, counts, gpre, ctab} from the ids
-static int group_ids(const DevShape& s, const int64_t* indices, const int64_t* rowidx, const int64_t* offsets,
-                     int64_t nnz, const int32_t* nnz_dev, GroupPlan* plan, char* scan_tmp, hipStream_t st) {
+static int run_prefix(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, hipStream_t st);
+
+static int group_ids(const DevShape& s, const CorePtrs& cores, const int64_t* indices, const int64_t* rowidx,
+                     const int64_t* offsets, int64_t nnz, const int32_t* nnz_dev, int64_t B, float* zero_out,
+                     GroupPlan* plan, char* scan_tmp, hipStream_t st) {
   const int64_t G = num_groups(s);
   size_t tmp_bytes = 0;
   auto packed = rocprim::make_transform_iterator(plan->counts, PackCounts());
@@ -1012,8 +1194,10 @@ static int group_ids(const DevShape& s, const int64_t* indices, const int64_t* r
   int rc = check_hip(hipMemsetAsync(plan->counts, 0, (size_t)(G + 1) * 4, st), "memset counts");
   if (rc) return rc;
   const unsigned tiles = (unsigned)((nnz + kTile - 1) / kTile);
-  hipLaunchKernelGGL(fast3_prep_kernel, dim3(tiles), dim3(kTile), 0, st, indices, rowidx, offsets, nnz, nnz_dev, sentinel,
-                     (uint32_t)s.p[0], (uint32_t)s.p[1], (uint32_t)s.p[2], *plan);
+  const int64_t prep_threads = zero_out != nullptr && B > nnz ? B : nnz;
+  hipLaunchKernelGGL(fast3_prep_kernel, dim3((unsigned)((prep_threads + kTile - 1) / kTile)), dim3(kTile), 0, st, indices,
+                     rowidx, offsets, nnz, nnz_dev, B, s.D, zero_out, sentinel, (uint32_t)s.p[0], (uint32_t)s.p[1],
+                     (uint32_t)s.p[2], *plan);
   rc = check_hip(hipGetLastError(), "fast3_prep_kernel");
   if (rc) return rc;
   // gpre[g] = (first grouped position, first chunk) of group g; gpre[G] = (live ids, chunks)
@@ -1021,13 +1205,15 @@ static int group_ids(const DevShape& s, const int64_t* indices, const int64_t* r
                               rocprim::plus<uint64_t>(), st, false);
   if (e != hipSuccess) return check_hip(e, "exclusive_scan");
   hipLaunchKernelGGL(fast3_scatter_kernel, dim3(tiles), dim3(kTile), 0, st, nnz, nnz_dev, (uint32_t)s.p[2], *plan);
-  return check_hip(hipGetLastError(), "fast3_scatter_kernel");
+  rc = check_hip(hipGetLastError(), "fast3_scatter_kernel");
+  if (rc) return rc;
+  return run_prefix(s, cores, *plan, st);  // only `counts` is needed: could overlap the scan, but it is 5 us
 }
 
 // resolve where the plan lives, carve the workspace, group the ids unless a ready plan was passed
-static int prepare(const DevShape& s, bool bwd, const int64_t* indices, const int64_t* rowidx,
-                   const int64_t* offsets, int64_t nnz, const int32_t* nnz_dev, void* ws, int64_t ws_bytes, void* plan_buf, int64_t plan_bytes,
-                   bool plan_ready, GroupPlan* plan, hipStream_t st) {
+static int prepare(const DevShape& s, const CorePtrs& cores, bool bwd, const int64_t* indices, const int64_t* rowidx,
+                   const int64_t* offsets, int64_t nnz, const int32_t* nnz_dev, int64_t B, float* zero_out, void* ws,
+                   int64_t ws_bytes, void* plan_buf, int64_t plan_bytes, bool plan_ready, GroupPlan* plan, hipStream_t st) {
   memset(plan, 0, sizeof(*plan));
   const bool external = plan_buf != nullptr && plan_bytes >= fast3_plan_bytes(s, nnz);
   const bool reuse = external && plan_ready;
@@ -1038,63 +1224,74 @@ static int prepare(const DevShape& s, bool bwd, const int64_t* indices, const in
     return fail(TTEMB_E_WORKSPACE, "fast path needs %lld workspace bytes, got %lld", (long long)need, (long long)ws_bytes);
   if (external) carve_plan_part(s, nnz, reinterpret_cast<char*>(plan_buf), plan);
   if (reuse) return TTEMB_OK;
-  return group_ids(s, indices, rowidx, offsets, nnz, nnz_dev, plan, scan_tmp, st);
+  profile_begin(3, st);
+  const int rc = group_ids(s, cores, indices, rowidx, offsets, nnz, nnz_dev, B, zero_out, plan, scan_tmp, st);
+  profile_end(3, st);
+  return rc;
 }
 
-// P of every non-empty group from the cores as they are now (forward and backward each do this: the backward
-// differentiates the chain at the current cores, like the reference's recompute)
+// P of every non-empty group from the cores as they are now
 template <int Q0, int Q1, int Q2, int R1, int R2>
-static int run_prefix(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, hipStream_t st) {
+static int run_prefix_t(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, hipStream_t st) {
   hipLaunchKernelGGL((fast3_prefix_kernel<Q0, Q1, Q2, R1, R2>),
                      dim3((unsigned)((s.p[0] + kPrefixGroups - 1) / kPrefixGroups), (unsigned)s.p[1]), dim3(64), 0, st,
                      cores.c[0], cores.c[1], (uint32_t)s.p[0], plan);
   return check_hip(hipGetLastError(), "fast3_prefix_kernel");
 }
 
-static unsigned chunk_waves(const DevShape& s, int64_t nnz) { return (unsigned)((max_chunks(s, nnz) + kCPW - 1) / kCPW); }
+static int run_prefix(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, hipStream_t st) {
+  switch (classify(s)) {
+    case kProducts: return run_prefix_t<4, 5, 5, 16, 16>(s, cores, plan, st);
+    case kArxiv: return run_prefix_t<4, 4, 8, 8, 8>(s, cores, plan, st);
+    case kPapers: return run_prefix_t<8, 4, 4, 32, 32>(s, cores, plan, st);
+    default: return fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
+  }
+}
+
+static unsigned chunk_waves(const DevShape& s, int64_t nnz, int per_wave) {
+  return (unsigned)((max_chunks(s, nnz) + per_wave - 1) / per_wave);
+}
 
 template <int Q0, int Q1, int Q2, int R1, int R2>
-static int run_forward(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int64_t nnz, float* output,
-                       hipStream_t st) {
+static int run_forward(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int64_t nnz, int64_t B,
+                       float* output, hipStream_t st) {
   using C = Cfg<Q0, Q1, Q2, R1, R2>;
-  int rc = run_prefix<Q0, Q1, Q2, R1, R2>(s, cores, plan, st);
-  if (rc) return rc;
   const size_t lds = C::WAVE_FLOATS * sizeof(float);
   profile_begin(0, st);
-  hipLaunchKernelGGL((fast3_forward_kernel<Q0, Q1, Q2, R1, R2>), dim3(chunk_waves(s, nnz)), dim3(64), lds, st, cores.c[2],
-                     plan, (uint32_t)num_groups(s), output);
+  hipLaunchKernelGGL((fast3_forward_kernel<Q0, Q1, Q2, R1, R2>), dim3(chunk_waves(s, nnz, kCPWF)), dim3(64), lds, st, cores.c[2],
+                     plan, (uint32_t)num_groups(s), (uint32_t)s.p[2], (uint32_t)nnz, output, (uint32_t)(B * s.D * 4));
   profile_end(0, st);
   return check_hip(hipGetLastError(), "fast3_forward_kernel");
 }
 
 int launch_forward_fast3(const DevShape& s, const CorePtrs& cores, const int64_t* indices,
                          const int64_t* rowidx, const int64_t* offsets, int64_t nnz, const int32_t* nnz_dev,
-                         float* output, void* ws, int64_t ws_bytes, void* plan_buf, int64_t plan_bytes,
-                         hipStream_t st) {
+                         int64_t B, float* output, bool zero_rows, void* ws, int64_t ws_bytes, void* plan_buf,
+                         int64_t plan_bytes, hipStream_t st) {
   if (nnz <= 0) return TTEMB_OK;
   GroupPlan plan;
-  int rc = prepare(s, false, indices, rowidx, offsets, nnz, nnz_dev, ws, ws_bytes, plan_buf, plan_bytes, false, &plan, st);
+  int rc = prepare(s, cores, false, indices, rowidx, offsets, nnz, nnz_dev, B, zero_rows ? output : nullptr, ws, ws_bytes,
+                   plan_buf, plan_bytes, false, &plan, st);
   if (rc) return rc;
   switch (classify(s)) {
-    case kProducts: return run_forward<4, 5, 5, 16, 16>(s, cores, plan, nnz, output, st);
-    case kArxiv: return run_forward<4, 4, 8, 8, 8>(s, cores, plan, nnz, output, st);
-    case kPapers: return run_forward<8, 4, 4, 32, 32>(s, cores, plan, nnz, output, st);
+    case kProducts: return run_forward<4, 5, 5, 16, 16>(s, cores, plan, nnz, B, output, st);
+    case kArxiv: return run_forward<4, 4, 8, 8, 8>(s, cores, plan, nnz, B, output, st);
+    case kPapers: return run_forward<8, 4, 4, 32, 32>(s, cores, plan, nnz, B, output, st);
     default: return fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
   }
 }
 
 template <int Q0, int Q1, int Q2, int R1, int R2>
-static int run_backward(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int64_t nnz,
+static int run_backward(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int64_t nnz, int64_t B,
                         const float* d_output, const CorePtrsMut& d_cores, hipStream_t st) {
   using C = Cfg<Q0, Q1, Q2, R1, R2>;
   const int64_t G = num_groups(s);
   profile_begin(1, st);
-  int rc = run_prefix<Q0, Q1, Q2, R1, R2>(s, cores, plan, st);
-  if (rc) return rc;
+  int rc;
   const size_t lds = (size_t)(C::PB_FLOATS + C::BB2_FLOATS + C::OB_FLOATS) * sizeof(float);
   profile_begin(2, st);
-  hipLaunchKernelGGL((fast3_bwd_chunk_kernel<Q0, Q1, Q2, R1, R2>), dim3(chunk_waves(s, nnz)), dim3(64), lds, st, cores.c[2],
-                     (uint32_t)G, d_output, plan);
+  hipLaunchKernelGGL((fast3_bwd_chunk_kernel<Q0, Q1, Q2, R1, R2>), dim3(chunk_waves(s, nnz, kCPWB)), dim3(64), lds, st, cores.c[2],
+                     (uint32_t)G, (uint32_t)s.p[2], (uint32_t)nnz, d_output, (uint32_t)(B * s.D * 4), plan);
   profile_end(2, st);
   rc = check_hip(hipGetLastError(), "fast3_bwd_chunk_kernel");
   if (rc) return rc;
@@ -1103,39 +1300,40 @@ static int run_backward(const DevShape& s, const CorePtrs& cores, const GroupPla
                      (size_t)(2 * s.p[2] + 1) * 4 + kRowsB * 2, st, plan, (int)G, (uint32_t)s.p[2]);
   rc = check_hip(hipGetLastError(), "fast3_dg2_reduce_kernel");
   if (rc) return rc;
-  hipLaunchKernelGGL((fast3_group_epilogue_kernel<Q0, Q1, Q2, R1, R2>), dim3((unsigned)((G + kGroupsC - 1) / kGroupsC)),
-                     dim3(64), 0, st, cores.c[0], cores.c[1], (uint32_t)s.p[0], (uint32_t)G, plan, d_cores.c[1]);
+  const int gpw = epi_groups_per_wave(s), slices = epi_slices(s);
+  hipLaunchKernelGGL((fast3_group_epilogue_kernel<Q0, Q1, Q2, R1, R2>), dim3((unsigned)slices, (unsigned)s.p[1]),
+                     dim3(64), 0, st, cores.c[0], cores.c[1], (uint32_t)s.p[0], (uint32_t)s.p[1], (uint32_t)gpw, plan);
   rc = check_hip(hipGetLastError(), "fast3_group_epilogue_kernel");
   if (rc) return rc;
   {
-    const int g2_floats = s.p[2] * C::ROW2;
-    const int outs = g2_floats + s.p[0] * C::ROW0;
-    hipLaunchKernelGGL(fast3_finalize_kernel, dim3((unsigned)((outs + 31) / 32)), dim3(256), 0, st, plan, tiles,
-                       s.p[0], s.p[1], g2_floats, (int)C::ROW0, Q2, R2, d_cores.c[0], d_cores.c[2]);
+    const int g2_floats = s.p[2] * C::ROW2, g1_floats = s.p[1] * C::ROW1;
+    const int outs = g2_floats + s.p[0] * C::ROW0 + g1_floats;
+    hipLaunchKernelGGL(fast3_finalize_kernel, dim3((unsigned)((outs + 31) / 32)), dim3(256), 0, st, plan, tiles, slices,
+                       s.p[0], s.p[1], g2_floats, (int)C::ROW0, g1_floats, Q2, R2, d_cores.c[0], d_cores.c[1], d_cores.c[2]);
   }
   profile_end(1, st);
   return check_hip(hipGetLastError(), "fast3_finalize_kernel");
 }
 
 int launch_backward_fast3(const DevShape& s, const CorePtrs& cores, const int64_t* indices,
-                          const int64_t* rowidx, int64_t nnz, const int32_t* nnz_dev,
-                          const float* d_output, const CorePtrsMut& d_cores, void* ws, int64_t ws_bytes,
+                          const int64_t* rowidx, const int64_t* offsets, int64_t nnz, const int32_t* nnz_dev,
+                          int64_t B, const float* d_output, const CorePtrsMut& d_cores, void* ws, int64_t ws_bytes,
                           const void* plan_buf, int64_t plan_bytes, hipStream_t st) {
-  // dG1 is accumulated with float atomics; dG0 and dG2 are written whole by the finalize kernel
+  // every core gradient is written whole by the finalize kernel
   for (int t = 0; t < s.T; ++t) {
-    if (nnz > 0 && t != 1) continue;
+    if (nnz > 0) continue;
     int rc = check_hip(hipMemsetAsync(d_cores.c[t], 0, (size_t)s.p[t] * s.row_len[t] * 4, st), "memset d_core");
     if (rc) return rc;
   }
   if (nnz <= 0) return TTEMB_OK;
   GroupPlan plan;
-  int rc = prepare(s, true, indices, rowidx, nullptr, nnz, nnz_dev, ws, ws_bytes, const_cast<void*>(plan_buf), plan_bytes,
-                   plan_buf != nullptr, &plan, st);
+  int rc = prepare(s, cores, true, indices, rowidx, offsets, nnz, nnz_dev, B, nullptr, ws, ws_bytes,
+                   const_cast<void*>(plan_buf), plan_bytes, plan_buf != nullptr, &plan, st);
   if (rc) return rc;
   switch (classify(s)) {
-    case kProducts: return run_backward<4, 5, 5, 16, 16>(s, cores, plan, nnz, d_output, d_cores, st);
-    case kArxiv: return run_backward<4, 4, 8, 8, 8>(s, cores, plan, nnz, d_output, d_cores, st);
-    case kPapers: return run_backward<8, 4, 4, 32, 32>(s, cores, plan, nnz, d_output, d_cores, st);
+    case kProducts: return run_backward<4, 5, 5, 16, 16>(s, cores, plan, nnz, B, d_output, d_cores, st);
+    case kArxiv: return run_backward<4, 4, 8, 8, 8>(s, cores, plan, nnz, B, d_output, d_cores, st);
+    case kPapers: return run_backward<8, 4, 4, 32, 32>(s, cores, plan, nnz, B, d_output, d_cores, st);
     default: return fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
   }
 }

@@ -73,7 +73,9 @@ int64_t ttemb_workspace_bytes(const ttemb_shape_t* shape, int32_t op, int64_t nn
 
 /* Bytes of an id-grouping plan for `nnz` ids (0 when the selected kernel family needs none).
  * ttemb_forward leaves its grouping of the ids in a caller buffer of this size; passing the same
- * buffer to the backward of the SAME (indices, rowidx, nnz, nnz_dev) skips the regrouping. */
+ * buffer to the backward of the SAME (indices, rowidx, nnz, nnz_dev) skips the regrouping.  The plan also
+ * carries the prefix products G0[i0].G1[i1] the forward used: a backward handed the plan differentiates the
+ * chain at those (the saved-tensor meaning of autograd); one that is not forms them from the cores it is given. */
 int64_t ttemb_plan_bytes(const ttemb_shape_t* shape, int64_t nnz);
 
 /* Select the kernel family used by later calls, process-wide (TTEMB_PATH_*). */
@@ -83,7 +85,8 @@ int ttemb_set_path(int32_t path);
  * main chain kernel of every ttemb_forward / ttemb_backward_* call is bracketed by
  * hipEvents on the call's stream.  ttemb_profile_read waits for the most recent bracket of
  * `which` (0 = forward chain kernel, 1 = all backward chain kernels, 2 = the backward chunk
- * kernel alone) and returns its duration in milliseconds.  Off by default; costs two event records per call when on. */
+ * kernel alone, 3 = the id-grouping pass including the prefix-product kernel) and returns its duration in
+ * milliseconds.  Off by default; costs two event records per call when on. */
 int ttemb_profile_enable(int32_t on);
 int ttemb_profile_read(int32_t which, float* ms_host);
 
