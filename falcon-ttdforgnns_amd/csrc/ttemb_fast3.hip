@@ -21,8 +21,6 @@
 #include <cstdlib>
 #include <cstring>
 
-#include <rocprim/device/device_scan.hpp>
-#include <rocprim/iterator/transform_iterator.hpp>
 
 
 namespace ttemb {
@@ -83,30 +81,98 @@ struct Cfg {
 };
 
 // ---------------------------------------------------------------------------------
-// Grouping pass: a counting sort of the live ids by group' = i1 * p0 + i0, cut into chunks
-// (three small kernels; rocprim's radix/merge sort needs ~20 launches and > 100 us at these sizes).
-//   key   = (i1 * p0 + i0) * p2 + i2   -- the id with its digits reordered: ids of one
-//           (i0, i1) group end up adjacent, and consecutive groups share i1;
-//   value = output row | kMultiBit when the bag holds several ids.
-// One returning atomic per id (its arrival rank inside the group) in the first kernel, ONE rocPRIM
-// exclusive scan that carries two running sums in a 64-bit word (ids before the group | chunks before
-// the group), and an atomic-free scatter.  The scatter also writes the *chunk table*: a chunk is <= 16
-// consecutive ids of one group, and its 16-byte descriptor {position, group, length | flags, first chunk
-// of the next group} is all the chain kernels need to walk the grouped ids -- they read descriptors with
-// scalar loads and never decode a key, compare neighbours or shuffle.  The order of ids inside a
-// group is arrival order: every consumer is insensitive to it except for fp32 summation order in
-// the backward.
+// Addressing helpers of the chain kernels.  Every global access of their inner loops goes through a buffer
+// descriptor with a per-lane 32-bit byte offset: an offset past the buffer (kOob) makes a load return zeros and
+// a store vanish, so ragged chunks need no branch around a memory instruction -- the instruction stream per
+// chunk is fixed, and the compiler can count outstanding operations exactly (a skipped instruction would force
+// every later wait to vmcnt(0), i.e. to drain the prefetch that was just issued).
 // ---------------------------------------------------------------------------------
-constexpr int kTile = 256;   // threads per workgroup in the grouping kernels
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr uint32_t kOob = 0xffffffffu;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load4(rsrc_t r, uint32_t voff) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ u32x4 buf_load4u(rsrc_t r, uint32_t voff) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0);
+}
+__device__ __forceinline__ uint32_t buf_load1u(rsrc_t r, uint32_t voff) {
+  return __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, 0, 0);
+}
+__device__ __forceinline__ void buf_store4(rsrc_t r, uint32_t voff, const float4& x) {
+  u32x4 v;
+  v.x = __float_as_uint(x.x);
+  v.y = __float_as_uint(x.y);
+  v.z = __float_as_uint(x.z);
+  v.w = __float_as_uint(x.w);
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, 0, 0);
+}
+__device__ __forceinline__ void buf_store1(rsrc_t r, uint32_t voff, float x) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), r, (int)voff, 0, 0);
+}
+
+// Chunk descriptors are read through the constant address space with a wave-uniform index: scalar loads
+// (s_load_dwordx4), which are counted by lgkmcnt, not vmcnt, and so never sit in the queue of the row loads.
+typedef const __attribute__((address_space(4))) uint32_t* desc_ptr;
+__device__ __forceinline__ uint4 load_desc(desc_ptr tab, uint32_t c, uint32_t nchunks) {
+  const uint32_t at = 4u * (c < nchunks ? c : nchunks - 1);
+  const uint32_t keep = c < nchunks ? 0xffffffffu : 0u;   // past the table: an empty chunk
+  return make_uint4(tab[at] & keep, tab[at + 1] & keep, tab[at + 2] & keep, tab[at + 3] & keep);
+}
+
+// ---------------------------------------------------------------------------------
+// Grouping pass: a two-digit counting sort of the live ids by group' = i1 * p0 + i0, cut into chunks.
+//   value = output row | kMultiBit when the bag holds several ids.
+// ids of one (i0, i1) group end up adjacent, consecutive groups share i1.  No global atomics (one returning
+// atomic per id capped the first version at ~16 G ids/s = 25 us) and no device-wide scan.  The group space is cut
+// into ranges of 2^shift groups (first digit), the id list into slices:
+//   decode   every id -> (group, i2, row | multi); LDS histogram of the slice over the ranges       [one workgroup per slice]
+//   spread   every id moves to its range (ranges in order, slices in order inside a range):
+//            cursor[range] from the slices' histograms, one returning LDS atomic per id             [one workgroup per slice]
+//   count    LDS histogram of a range's ids over its groups, exclusive prefix of (ids, chunks)
+//            inside the range, range totals                                                         [one workgroup per range]
+//   place    every id takes its final position with one returning LDS atomic; the id that opens
+//            a chunk writes its descriptor                                                          [one workgroup per range]
+// A chunk is <= 16 consecutive ids of one group; its 16-byte descriptor {position, group, length | flags, first
+// chunk of the next group} is all the chain kernels need to walk the grouped ids -- they read descriptors with
+// scalar loads and never decode a key, compare neighbours or shuffle.  The order of ids inside a group is
+// arrival order: every consumer is insensitive to it except for fp32 summation order in the backward.
+// ---------------------------------------------------------------------------------
+constexpr int kSortThreads = 1024;       // decode / spread: one workgroup per slice of the id list
+#ifndef TTEMB_RANGE_THREADS
+#define TTEMB_RANGE_THREADS 512
+#endif
+constexpr int kRangeThreads = TTEMB_RANGE_THREADS;   // count / place: one workgroup per range of groups
+#ifndef TTEMB_SORT_SLICE
+#define TTEMB_SORT_SLICE 2048
+#endif
+constexpr int kSliceIds = TTEMB_SORT_SLICE;   // ids per slice (target)
+constexpr int kMaxSlices = 1024;
+constexpr int kMaxRanges = 512;               // ranges of the group space (a power-of-two number of groups each)
+constexpr int kSortBatch = 8;                 // ids per thread whose loads are in flight together
 constexpr uint32_t kFirstBit = 0x100u, kLastBit = 0x200u;   // flags next to a chunk's length
+constexpr uint32_t kNoGroup = 0xffffffffu;
 
 struct GroupPlan {           // device pointers into the caller's plan buffer / workspace
-  uint32_t* keys_in;         // [nnz] ungrouped keys
-  uint32_t* vals_in;
-  uint32_t* rank_in;         // arrival rank of the id inside its group
+  uint32_t* grp_in;          // [nnz] ungrouped: group of the id (kNoGroup past the live count)
+  uint32_t* i2_in;           // [nnz] ungrouped: last index digit
+  uint32_t* vals_in;         // [nnz] ungrouped: output row | kMultiBit
+  uint32_t* grp_mid;         // [nnz] the same three, ordered by range
+  uint32_t* i2_mid;
+  uint32_t* vals_mid;
+  uint32_t* shist;           // [slices][ranges] place of slice s inside range r (arrival order of the slices)
+  uint32_t* rcount;          // [ranges] running / final id count of every range
+  uint32_t* rstart;          // [ranges + 1] first position of every range in the range-ordered arrays
+  uint64_t* lpre;            // [G] prefix of (ids | chunks << 32) inside the group's range
+  uint64_t* rtot;            // [ranges] (ids | chunks << 32) of every range
   uint32_t* i2s;             // [nnz] grouped: last index digit of the id
   uint32_t* vals;            // [nnz] grouped: output row | kMultiBit
-  uint32_t* counts;          // [G+1] ids per group (entry G stays 0)
+  uint32_t* counts;          // [G+1] ids per group
   uint64_t* gpre;            // [G+1] low word: first grouped position of the group; high word: its first chunk.
                              //       entry G = (live ids, chunks)
   uint4* ctab;               // [max_chunks] chunk descriptors
@@ -118,72 +184,256 @@ struct GroupPlan {           // device pointers into the caller's plan buffer / 
   float* g1part;             // [slices][p1][ROW1] per-slice partial dG1
 };
 
-__global__ __launch_bounds__(kTile) void fast3_prep_kernel(
-    const int64_t* __restrict__ indices, const int64_t* __restrict__ rowidx,
-    const int64_t* __restrict__ offsets, int64_t nnz,
-    const int32_t* __restrict__ nnz_dev, int64_t B, int D, float* __restrict__ zero_out, uint32_t sentinel,
-    uint32_t p0, uint32_t p1, uint32_t p2, GroupPlan plan) {
-  const int64_t n = (int64_t)blockIdx.x * kTile + threadIdx.x;
-  // rows whose bag does not hold exactly one id are zeroed here: the forward stores one-id bags and
-  // accumulates into the others (zero_out is null in the backward and when the caller cleared the output)
-  if (zero_out != nullptr && n < B && offsets[n + 1] - offsets[n] != 1) {
-    float4* o = reinterpret_cast<float4*>(zero_out + n * D);
-    for (int c = 0; c * 4 < D; ++c) o[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  const int64_t cnt = live_count(nnz, nnz_dev);
-  if (n >= cnt) return;
-  int64_t id = indices[n];
-  id = id < 0 ? 0 : (id >= (int64_t)sentinel ? (int64_t)sentinel - 1 : id);
-  int64_t row;
-  if (rowidx != nullptr) {
-    row = rowidx[n];
-  } else if (n < B && offsets[n] <= n && n < offsets[n + 1]) {
-    row = n;  // the usual case (every bag holds one id) costs two coalesced reads
-  } else {    // bag of position n: the last b with offsets[b] <= n  (tt_embeddings_cuda.cu:1349-1365)
-    int64_t lo = 0, hi = B;  // invariant: offsets[lo] <= n < offsets[hi]
-    while (hi - lo > 1) {
-      const int64_t mid = (lo + hi) >> 1;
-      if (offsets[mid] <= n) lo = mid; else hi = mid;
-    }
-    row = lo;
-  }
-  const bool multi = !bag_is_single(rowidx, offsets, n, cnt, row);
-  const uint32_t u = (uint32_t)id;
-  const uint32_t i0 = u / (p1 * p2);
-  const uint32_t rem = u - i0 * (p1 * p2);
-  const uint32_t i1 = rem / p2;
-  const uint32_t i2 = rem - i1 * p2;
-  const uint32_t group = i1 * p0 + i0;
-  plan.keys_in[n] = group * p2 + i2;
-  plan.vals_in[n] = (uint32_t)row | (multi ? kMultiBit : 0u);
-  plan.rank_in[n] = atomicAdd(&plan.counts[group], 1u);
+__device__ __forceinline__ uint64_t pack_count(uint32_t c) {   // ids in the low word, chunks of <= kChunk ids in the high word
+  return (uint64_t)c | ((uint64_t)((c + kChunk - 1) / kChunk) << 32);
 }
 
-// what the scan adds up per group: ids in the low word, chunks of <= kChunk ids in the high word
-struct PackCounts {
-  __host__ __device__ uint64_t operator()(uint32_t c) const {
-    return (uint64_t)c | ((uint64_t)((c + kChunk - 1) / kChunk) << 32);
+// exclusive prefix of v over the workgroup's NT threads; also the total
+template <typename T, int NT>
+__device__ __forceinline__ T block_exclusive(T v, T* wave_sums, T& total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  T incl = v;
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    T up;
+    if constexpr (sizeof(T) == 8) {
+      const uint32_t lo_w = __shfl_up((uint32_t)incl, d, kWave), hi_w = __shfl_up((uint32_t)((uint64_t)incl >> 32), d, kWave);
+      up = (T)((uint64_t)lo_w | ((uint64_t)hi_w << 32));
+    } else {
+      up = __shfl_up(incl, d, kWave);
+    }
+    if (lane >= d) incl += up;
   }
-};
+  if (lane == kWave - 1) wave_sums[wave] = incl;
+  __syncthreads();
+  T before = 0, all = 0;
+  for (int w = 0; w < NT / kWave; ++w) {
+    const T x = wave_sums[w];
+    if (w < wave) before += x;
+    all += x;
+  }
+  __syncthreads();
+  total = all;
+  return before + incl - v;
+}
 
-__global__ __launch_bounds__(kTile) void fast3_scatter_kernel(int64_t nnz, const int32_t* __restrict__ nnz_dev,
-                                                              uint32_t p2, GroupPlan plan) {
-  const int64_t n = (int64_t)blockIdx.x * kTile + threadIdx.x;
-  if (n >= live_count(nnz, nnz_dev)) return;
-  const uint32_t key = plan.keys_in[n];
-  const uint32_t g = key / p2;
-  const uint32_t rank = plan.rank_in[n];
-  const uint64_t pre = plan.gpre[g];
-  const uint32_t dst = (uint32_t)pre + rank;
-  plan.i2s[dst] = key - g * p2;
-  plan.vals[dst] = plan.vals_in[n];
-  if (rank % kChunk == 0) {  // this id opens a chunk of its group: it writes the descriptor
-    const uint32_t c = plan.counts[g];
-    const uint32_t chunks = (c + kChunk - 1) / kChunk, k = rank / kChunk;
-    const uint32_t first_chunk = (uint32_t)(pre >> 32);
-    const uint32_t len = c - rank < (uint32_t)kChunk ? c - rank : (uint32_t)kChunk;
-    plan.ctab[first_chunk + k] = make_uint4(dst, g, len | (k == 0 ? kFirstBit : 0u) | (k + 1 == chunks ? kLastBit : 0u),
-                                            first_chunk + chunks);
+__global__ __launch_bounds__(kSortThreads) void fast3_decode_kernel(
+    const int64_t* __restrict__ indices, const int64_t* __restrict__ rowidx,
+    const int64_t* __restrict__ offsets, uint32_t nnz, uint32_t per_slice,
+    const int32_t* __restrict__ nnz_dev, int64_t B, int D, float* __restrict__ zero_out, uint32_t sentinel,
+    uint32_t p0, uint32_t p1, uint32_t p2, uint32_t shift, uint32_t ranges, GroupPlan plan) {
+  __shared__ uint32_t hist[kMaxRanges];
+  for (uint32_t i = threadIdx.x; i < ranges; i += kSortThreads) hist[i] = 0u;
+  __syncthreads();
+  const int64_t cnt = live_count(nnz, nnz_dev);
+  const uint32_t s0 = blockIdx.x * per_slice;
+  // every slice also owns a share of the bags: rows whose bag does not hold exactly one id are zeroed here (the
+  // forward stores one-id bags and accumulates into the others; zero_out is null in the backward)
+  if (zero_out != nullptr) {
+    const int64_t per_b = (B + gridDim.x - 1) / gridDim.x;
+    const int64_t b1 = (blockIdx.x + 1) * per_b < B ? (blockIdx.x + 1) * per_b : B;
+    for (int64_t b = blockIdx.x * per_b + threadIdx.x; b < b1; b += kSortThreads)
+      if (offsets[b + 1] - offsets[b] != 1) {
+        float4* o = reinterpret_cast<float4*>(zero_out + b * D);
+        for (int c = 0; c * 4 < D; ++c) o[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+  }
+  const uint32_t s1 = s0 + per_slice < nnz ? s0 + per_slice : nnz;
+  constexpr int UD = 4;   // ids per thread whose loads are in flight together
+  for (uint32_t base = s0 + threadIdx.x; base < s1; base += kSortThreads * UD) {
+    int64_t idv[UD], o0[UD], o1[UD], rv[UD];
+#pragma unroll
+    for (int u = 0; u < UD; ++u) {
+      const uint32_t n = base + u * kSortThreads;
+      const bool on = n < s1 && (int64_t)n < cnt;
+      idv[u] = on ? indices[n] : 0;
+      rv[u] = on && rowidx != nullptr ? rowidx[n] : -1;
+      const bool direct = on && rowidx == nullptr && (int64_t)n < B;   // candidate for "bag n holds exactly id n"
+      o0[u] = direct ? offsets[n] : -1;
+      o1[u] = direct ? offsets[n + 1] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < UD; ++u) {
+      const uint32_t n = base + u * kSortThreads;
+      if (n >= s1) continue;
+      if ((int64_t)n >= cnt) {
+        plan.grp_in[n] = kNoGroup;
+        continue;
+      }
+      int64_t id = idv[u];
+      id = id < 0 ? 0 : (id >= (int64_t)sentinel ? (int64_t)sentinel - 1 : id);
+      int64_t row;
+      bool multi;
+      if (rowidx != nullptr) {
+        row = rv[u];
+        multi = !bag_is_single(rowidx, offsets, n, cnt, row);
+      } else if (o0[u] >= 0 && o0[u] <= (int64_t)n && (int64_t)n < o1[u]) {
+        row = n;  // the usual case (every bag holds one id) costs two coalesced reads
+        multi = o1[u] - o0[u] != 1;
+      } else {    // bag of position n: the last b with offsets[b] <= n  (tt_embeddings_cuda.cu:1349-1365)
+        int64_t lo = 0, hi = B;  // invariant: offsets[lo] <= n < offsets[hi]
+        while (hi - lo > 1) {
+          const int64_t mid = (lo + hi) >> 1;
+          if (offsets[mid] <= (int64_t)n) lo = mid; else hi = mid;
+        }
+        row = lo;
+        multi = offsets[row + 1] - offsets[row] != 1;
+      }
+      const uint32_t uu = (uint32_t)id;
+      const uint32_t i0 = uu / (p1 * p2);
+      const uint32_t rem = uu - i0 * (p1 * p2);
+      const uint32_t i1 = rem / p2;
+      const uint32_t group = i1 * p0 + i0;
+      plan.grp_in[n] = group;
+      plan.i2_in[n] = rem - i1 * p2;
+      plan.vals_in[n] = (uint32_t)row | (multi ? kMultiBit : 0u);
+      atomicAdd(&hist[group >> shift], 1u);
+    }
+  }
+  __syncthreads();
+  // this slice's place inside every range: arrival order of the slices (one returning atomic per slice and range;
+  // rcount was cleared before the launch and ends up holding the ranges' totals)
+  uint32_t* dst = plan.shist + (size_t)blockIdx.x * ranges;
+  for (uint32_t i = threadIdx.x; i < ranges; i += kSortThreads) dst[i] = atomicAdd(&plan.rcount[i], hist[i]);
+}
+
+__global__ __launch_bounds__(kSortThreads) void fast3_spread_kernel(uint32_t nnz, uint32_t per_slice, uint32_t shift,
+                                                                   uint32_t ranges, GroupPlan plan) {
+  __shared__ uint32_t cursor[kMaxRanges];
+  __shared__ uint32_t wave_sums[kSortThreads / kWave];
+  const uint32_t s = blockIdx.x;
+  // cursor[r] = ids of earlier ranges + this slice's place inside the range  (ranges <= kMaxRanges <= threads)
+  const uint32_t tot = threadIdx.x < ranges ? plan.rcount[threadIdx.x] : 0u;
+  const uint32_t mine = threadIdx.x < ranges ? plan.shist[(size_t)s * ranges + threadIdx.x] : 0u;
+  uint32_t all;
+  const uint32_t before = block_exclusive<uint32_t, kSortThreads>(tot, wave_sums, all);
+  if (threadIdx.x < ranges) {
+    cursor[threadIdx.x] = before + mine;
+    if (s == 0) plan.rstart[threadIdx.x] = before;
+  }
+  if (s == 0 && threadIdx.x == 0) plan.rstart[ranges] = all;
+  __syncthreads();
+  const uint32_t s0 = s * per_slice;
+  const uint32_t s1 = s0 + per_slice < nnz ? s0 + per_slice : nnz;
+  for (uint32_t base = s0 + threadIdx.x; base < s1; base += kSortThreads * kSortBatch) {
+    uint32_t g[kSortBatch], i2v[kSortBatch], vv[kSortBatch];   // all loads of the batch first
+#pragma unroll
+    for (int u = 0; u < kSortBatch; ++u) {
+      const uint32_t n = base + u * kSortThreads;
+      g[u] = n < s1 ? plan.grp_in[n] : kNoGroup;
+    }
+#pragma unroll
+    for (int u = 0; u < kSortBatch; ++u) {
+      const uint32_t n = base + u * kSortThreads;
+      const bool on = g[u] != kNoGroup;
+      i2v[u] = on ? plan.i2_in[n] : 0u;
+      vv[u] = on ? plan.vals_in[n] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < kSortBatch; ++u) {
+      if (g[u] == kNoGroup) continue;
+      const uint32_t dst = atomicAdd(&cursor[g[u] >> shift], 1u);
+      plan.grp_mid[dst] = g[u];
+      plan.i2_mid[dst] = i2v[u];
+      plan.vals_mid[dst] = vv[u];
+    }
+  }
+}
+
+__global__ __launch_bounds__(kRangeThreads) void fast3_count_kernel(uint32_t G, uint32_t shift, GroupPlan plan) {
+  extern __shared__ uint32_t hist[];   // [span]
+  __shared__ uint64_t wave_sums[kRangeThreads / kWave];
+  const uint32_t span = 1u << shift;
+  const uint32_t g0 = blockIdx.x << shift;
+  const uint32_t n0 = plan.rstart[blockIdx.x], n1 = plan.rstart[blockIdx.x + 1];
+  for (uint32_t i = threadIdx.x; i < span; i += kRangeThreads) hist[i] = 0u;
+  __syncthreads();
+  for (uint32_t base = n0 + threadIdx.x; base < n1; base += kRangeThreads * kSortBatch) {
+    uint32_t g[kSortBatch];
+#pragma unroll
+    for (int u = 0; u < kSortBatch; ++u) {
+      const uint32_t n = base + u * kRangeThreads;
+      g[u] = n < n1 ? plan.grp_mid[n] : kNoGroup;
+    }
+#pragma unroll
+    for (int u = 0; u < kSortBatch; ++u)
+      if (g[u] != kNoGroup) atomicAdd(&hist[g[u] - g0], 1u);
+  }
+  __syncthreads();
+  uint64_t carry = 0;
+  for (uint32_t base = 0; base < span; base += kRangeThreads) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t c = i < span ? hist[i] : 0u;
+    uint64_t total;
+    const uint64_t pre = block_exclusive<uint64_t, kRangeThreads>(i < span ? pack_count(c) : 0ull, wave_sums, total);
+    if (i < span && g0 + i < G) {
+      plan.counts[g0 + i] = c;
+      plan.lpre[g0 + i] = carry + pre;
+    }
+    carry += total;
+  }
+  if (threadIdx.x == 0) plan.rtot[blockIdx.x] = carry;
+}
+
+__global__ __launch_bounds__(kRangeThreads) void fast3_place_kernel(uint32_t nnz, uint32_t G, uint32_t shift, GroupPlan plan) {
+  extern __shared__ uint32_t lds_s[];   // [span] cursor | [span] first position | [span] count | [span] first chunk
+  __shared__ uint64_t range_base;
+  const uint32_t span = 1u << shift;
+  const uint32_t g0 = blockIdx.x << shift;
+  uint32_t* cursor = lds_s;
+  uint32_t* gfirst = cursor + span;
+  uint32_t* gcount = gfirst + span;
+  uint32_t* gchunk = gcount + span;
+  if (threadIdx.x < kWave) {   // (ids, chunks) of the ranges before this one
+    uint64_t v = 0;
+    for (uint32_t r = threadIdx.x; r < blockIdx.x; r += kWave) v += plan.rtot[r];
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) {
+      const uint32_t lo_w = __shfl_down((uint32_t)v, d, kWave), hi_w = __shfl_down((uint32_t)(v >> 32), d, kWave);
+      v += (uint64_t)lo_w | ((uint64_t)hi_w << 32);
+    }
+    if (threadIdx.x == 0) range_base = v;
+  }
+  __syncthreads();
+  const uint64_t base = range_base;
+  for (uint32_t i = threadIdx.x; i < span; i += kRangeThreads) {
+    const uint32_t g = g0 + i;
+    if (g < G) {
+      const uint64_t pre = base + plan.lpre[g];
+      gfirst[i] = cursor[i] = (uint32_t)pre;
+      gcount[i] = plan.counts[g];
+      gchunk[i] = (uint32_t)(pre >> 32);
+      plan.gpre[g] = pre;
+    }
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) plan.gpre[G] = base + plan.rtot[blockIdx.x];   // (live ids, chunks)
+  __syncthreads();
+  const uint32_t n0 = plan.rstart[blockIdx.x], n1 = plan.rstart[blockIdx.x + 1];
+  for (uint32_t b0 = n0 + threadIdx.x; b0 < n1; b0 += kRangeThreads * kSortBatch) {
+    uint32_t gl[kSortBatch], i2v[kSortBatch], vv[kSortBatch];   // all loads of the batch first
+#pragma unroll
+    for (int u = 0; u < kSortBatch; ++u) {
+      const uint32_t n = b0 + u * kRangeThreads;
+      const bool on = n < n1;
+      gl[u] = on ? plan.grp_mid[n] - g0 : kNoGroup;
+      i2v[u] = on ? plan.i2_mid[n] : 0u;
+      vv[u] = on ? plan.vals_mid[n] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < kSortBatch; ++u) {
+      if (gl[u] == kNoGroup) continue;
+      const uint32_t dst = atomicAdd(&cursor[gl[u]], 1u);
+      plan.i2s[dst] = i2v[u];
+      plan.vals[dst] = vv[u];
+      const uint32_t rank = dst - gfirst[gl[u]];
+      if (rank % kChunk == 0) {  // this id opens a chunk of its group: it writes the descriptor
+        const uint32_t c = gcount[gl[u]];
+        const uint32_t chunks = (c + kChunk - 1) / kChunk, k = rank / kChunk;
+        const uint32_t len = c - rank < (uint32_t)kChunk ? c - rank : (uint32_t)kChunk;
+        plan.ctab[gchunk[gl[u]] + k] = make_uint4(dst, g0 + gl[u], len | (k == 0 ? kFirstBit : 0u) | (k + 1 == chunks ? kLastBit : 0u),
+                                                  gchunk[gl[u]] + chunks);
+      }
+    }
   }
 }
 
@@ -249,51 +499,6 @@ __global__ __launch_bounds__(64) void fast3_prefix_kernel(const float* __restric
       }
     }
   }
-}
-
-// ---------------------------------------------------------------------------------
-// Addressing helpers of the chain kernels.  Every global access of their inner loops goes through a buffer
-// descriptor with a per-lane 32-bit byte offset: an offset past the buffer (kOob) makes a load return zeros and
-// a store vanish, so ragged chunks need no branch around a memory instruction -- the instruction stream per
-// chunk is fixed, and the compiler can count outstanding operations exactly (a skipped instruction would force
-// every later wait to vmcnt(0), i.e. to drain the prefetch that was just issued).
-// ---------------------------------------------------------------------------------
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-constexpr uint32_t kOob = 0xffffffffu;
-
-__device__ __forceinline__ rsrc_t make_rsrc(const void* p, uint32_t bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ float4 buf_load4(rsrc_t r, uint32_t voff) {
-  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0);
-  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
-__device__ __forceinline__ u32x4 buf_load4u(rsrc_t r, uint32_t voff) {
-  return __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0);
-}
-__device__ __forceinline__ uint32_t buf_load1u(rsrc_t r, uint32_t voff) {
-  return __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, 0, 0);
-}
-__device__ __forceinline__ void buf_store4(rsrc_t r, uint32_t voff, const float4& x) {
-  u32x4 v;
-  v.x = __float_as_uint(x.x);
-  v.y = __float_as_uint(x.y);
-  v.z = __float_as_uint(x.z);
-  v.w = __float_as_uint(x.w);
-  __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, 0, 0);
-}
-__device__ __forceinline__ void buf_store1(rsrc_t r, uint32_t voff, float x) {
-  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), r, (int)voff, 0, 0);
-}
-
-// Chunk descriptors are read through the constant address space with a wave-uniform index: scalar loads
-// (s_load_dwordx4), which are counted by lgkmcnt, not vmcnt, and so never sit in the queue of the row loads.
-typedef const __attribute__((address_space(4))) uint32_t* desc_ptr;
-__device__ __forceinline__ uint4 load_desc(desc_ptr tab, uint32_t c, uint32_t nchunks) {
-  const uint32_t at = 4u * (c < nchunks ? c : nchunks - 1);
-  const uint32_t keep = c < nchunks ? 0xffffffffu : 0u;   // past the table: an empty chunk
-  return make_uint4(tab[at] & keep, tab[at + 1] & keep, tab[at + 2] & keep, tab[at + 3] & keep);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1073,9 +1278,17 @@ bool fast3_supported(const DevShape& s) { return classify(s) != kNone; }
 
 static int64_t num_groups(const DevShape& s) { return (int64_t)s.p[0] * s.p[1]; }
 
-// rocPRIM's look-back scan needs a few bytes per block of ~1K items; reserve a generous bound so
-// that sizing the workspace needs no HIP call (the launch checks the real requirement)
-static int64_t scan_temp_bytes(int64_t G) { return 64 * 1024 + (G + 1) / 8; }
+// the grouping pass: slices of the id list; ranges of 2^shift groups each
+static int sort_slices(int64_t nnz) {
+  const int64_t s = (nnz + kSliceIds - 1) / kSliceIds;
+  return (int)(s < 1 ? 1 : (s > kMaxSlices ? kMaxSlices : s));
+}
+static int sort_shift(int64_t G) {
+  int shift = 0;
+  while (((G + (int64_t(1) << shift) - 1) >> shift) > kMaxRanges) ++shift;   // as many ranges as fit: <= kMaxRanges
+  return shift;
+}
+static int sort_ranges(int64_t G) { const int sh = sort_shift(G); return (int)((G + (int64_t(1) << sh) - 1) >> sh); }
 
 bool fast3_pays(const DevShape& s, int64_t nnz) { return nnz >= 2 * num_groups(s); }
 
@@ -1131,7 +1344,7 @@ static void carve_plan_part(const DevShape& s, int64_t nnz, char* base, GroupPla
 
 // workspace layout: [plan part unless external] [grouping scratch] [backward tables]
 static int64_t carve_workspace(const DevShape& s, int64_t nnz, bool bwd, bool plan_inside, bool need_grouping,
-                               char* base, GroupPlan* pl, char** scan_tmp) {
+                               char* base, GroupPlan* pl) {
   const int64_t G = num_groups(s);
   int64_t off = 0;
   auto take = [&](int64_t bytes) {
@@ -1144,16 +1357,26 @@ static int64_t carve_workspace(const DevShape& s, int64_t nnz, bool bwd, bool pl
     if (pl && p) carve_plan_part(s, nnz, p, pl);
   }
   if (need_grouping) {
-    uint32_t* a = (uint32_t*)take(nnz * 4);
-    uint32_t* b = (uint32_t*)take(nnz * 4);
-    uint32_t* c = (uint32_t*)take(nnz * 4);
-    char* t = take(scan_temp_bytes(G));
+    uint32_t* in[6];
+    for (int i = 0; i < 6; ++i) in[i] = (uint32_t*)take(nnz * 4);
+    uint32_t* sh = (uint32_t*)take((int64_t)sort_slices(nnz) * sort_ranges(G) * 4);
+    uint32_t* rs = (uint32_t*)take((sort_ranges(G) + 1) * 4);
+    uint32_t* rc = (uint32_t*)take(sort_ranges(G) * 4);
+    uint64_t* lp = (uint64_t*)take(G * 8);
+    uint64_t* rt = (uint64_t*)take(sort_ranges(G) * 8);
     if (pl) {
-      pl->keys_in = a;
-      pl->vals_in = b;
-      pl->rank_in = c;
+      pl->grp_in = in[0];
+      pl->i2_in = in[1];
+      pl->vals_in = in[2];
+      pl->grp_mid = in[3];
+      pl->i2_mid = in[4];
+      pl->vals_mid = in[5];
+      pl->shist = sh;
+      pl->rstart = rs;
+      pl->rcount = rc;
+      pl->lpre = lp;
+      pl->rtot = rt;
     }
-    if (scan_tmp) *scan_tmp = t;
   }
   if (bwd) {
     float* e = (float*)take(nnz * (int64_t)s.row_len[2] * 4);
@@ -1174,7 +1397,7 @@ static int64_t carve_workspace(const DevShape& s, int64_t nnz, bool bwd, bool pl
 
 int64_t fast3_workspace_bytes(const DevShape& s, int32_t op, int64_t nnz, int64_t B) {
   (void)B;
-  return carve_workspace(s, nnz, op == TTEMB_OP_BACKWARD, true, true, nullptr, nullptr, nullptr) + 256;
+  return carve_workspace(s, nnz, op == TTEMB_OP_BACKWARD, true, true, nullptr, nullptr) + 256;
 }
 
 // fill plan->{i2s, vals, counts, gpre, ctab} from the ids
@@ -1182,32 +1405,33 @@ static int run_prefix(const DevShape& s, const CorePtrs& cores, const GroupPlan&
 
 static int group_ids(const DevShape& s, const CorePtrs& cores, const int64_t* indices, const int64_t* rowidx,
                      const int64_t* offsets, int64_t nnz, const int32_t* nnz_dev, int64_t B, float* zero_out,
-                     GroupPlan* plan, char* scan_tmp, hipStream_t st) {
+                     GroupPlan* plan, hipStream_t st) {
   const int64_t G = num_groups(s);
-  size_t tmp_bytes = 0;
-  auto packed = rocprim::make_transform_iterator(plan->counts, PackCounts());
-  hipError_t e = rocprim::exclusive_scan(nullptr, tmp_bytes, packed, plan->gpre, (uint64_t)0, (size_t)(G + 1),
-                                         rocprim::plus<uint64_t>(), st, false);
-  if (e != hipSuccess) return check_hip(e, "exclusive_scan(size)");
-  if ((int64_t)tmp_bytes > scan_temp_bytes(G)) return fail(TTEMB_E_WORKSPACE, "scan scratch bound too small");
   const uint32_t sentinel = (uint32_t)((unsigned long long)s.L[0] * s.p[0]);
-  int rc = check_hip(hipMemsetAsync(plan->counts, 0, (size_t)(G + 1) * 4, st), "memset counts");
+  const int slices = sort_slices(nnz), shift = sort_shift(G), ranges = sort_ranges(G);
+  const uint32_t per_slice = (uint32_t)((nnz + slices - 1) / slices);
+  const size_t span = (size_t)1 << shift;
+  if (ranges > kMaxRanges || span * 16 > 64 * 1024) return fail(TTEMB_E_UNSUPPORTED, "too many (i0, i1) groups for the grouping pass");
+  int rc = check_hip(hipMemsetAsync(plan->rcount, 0, (size_t)align256(ranges * 4), st), "memset range counters");
   if (rc) return rc;
-  const unsigned tiles = (unsigned)((nnz + kTile - 1) / kTile);
-  const int64_t prep_threads = zero_out != nullptr && B > nnz ? B : nnz;
-  hipLaunchKernelGGL(fast3_prep_kernel, dim3((unsigned)((prep_threads + kTile - 1) / kTile)), dim3(kTile), 0, st, indices,
-                     rowidx, offsets, nnz, nnz_dev, B, s.D, zero_out, sentinel, (uint32_t)s.p[0], (uint32_t)s.p[1],
-                     (uint32_t)s.p[2], *plan);
-  rc = check_hip(hipGetLastError(), "fast3_prep_kernel");
+  hipLaunchKernelGGL(fast3_decode_kernel, dim3((unsigned)slices), dim3(kSortThreads), 0, st, indices, rowidx, offsets,
+                     (uint32_t)nnz, per_slice, nnz_dev, B, s.D, zero_out, sentinel, (uint32_t)s.p[0], (uint32_t)s.p[1],
+                     (uint32_t)s.p[2], (uint32_t)shift, (uint32_t)ranges, *plan);
+  rc = check_hip(hipGetLastError(), "fast3_decode_kernel");
   if (rc) return rc;
-  // gpre[g] = (first grouped position, first chunk) of group g; gpre[G] = (live ids, chunks)
-  e = rocprim::exclusive_scan(scan_tmp, tmp_bytes, packed, plan->gpre, (uint64_t)0, (size_t)(G + 1),
-                              rocprim::plus<uint64_t>(), st, false);
-  if (e != hipSuccess) return check_hip(e, "exclusive_scan");
-  hipLaunchKernelGGL(fast3_scatter_kernel, dim3(tiles), dim3(kTile), 0, st, nnz, nnz_dev, (uint32_t)s.p[2], *plan);
-  rc = check_hip(hipGetLastError(), "fast3_scatter_kernel");
+  hipLaunchKernelGGL(fast3_spread_kernel, dim3((unsigned)slices), dim3(kSortThreads), 0, st, (uint32_t)nnz, per_slice,
+                     (uint32_t)shift, (uint32_t)ranges, *plan);
+  rc = check_hip(hipGetLastError(), "fast3_spread_kernel");
   if (rc) return rc;
-  return run_prefix(s, cores, *plan, st);  // only `counts` is needed: could overlap the scan, but it is 5 us
+  hipLaunchKernelGGL(fast3_count_kernel, dim3((unsigned)ranges), dim3(kRangeThreads), span * 4, st, (uint32_t)G, (uint32_t)shift,
+                     *plan);
+  rc = check_hip(hipGetLastError(), "fast3_count_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(fast3_place_kernel, dim3((unsigned)ranges), dim3(kRangeThreads), span * 16, st, (uint32_t)nnz, (uint32_t)G,
+                     (uint32_t)shift, *plan);
+  rc = check_hip(hipGetLastError(), "fast3_place_kernel");
+  if (rc) return rc;
+  return run_prefix(s, cores, *plan, st);
 }
 
 // resolve where the plan lives, carve the workspace, group the ids unless a ready plan was passed
@@ -1217,15 +1441,14 @@ static int prepare(const DevShape& s, const CorePtrs& cores, bool bwd, const int
   memset(plan, 0, sizeof(*plan));
   const bool external = plan_buf != nullptr && plan_bytes >= fast3_plan_bytes(s, nnz);
   const bool reuse = external && plan_ready;
-  char* scan_tmp = nullptr;
-  const int64_t need = carve_workspace(s, nnz, bwd, !external, !reuse, reinterpret_cast<char*>(ws), plan, &scan_tmp);
+  const int64_t need = carve_workspace(s, nnz, bwd, !external, !reuse, reinterpret_cast<char*>(ws), plan);
   if (need > 0 && ws == nullptr) return fail(TTEMB_E_WORKSPACE, "fast path needs a workspace");
   if (need > ws_bytes)
     return fail(TTEMB_E_WORKSPACE, "fast path needs %lld workspace bytes, got %lld", (long long)need, (long long)ws_bytes);
   if (external) carve_plan_part(s, nnz, reinterpret_cast<char*>(plan_buf), plan);
   if (reuse) return TTEMB_OK;
   profile_begin(3, st);
-  const int rc = group_ids(s, cores, indices, rowidx, offsets, nnz, nnz_dev, B, zero_out, plan, scan_tmp, st);
+  const int rc = group_ids(s, cores, indices, rowidx, offsets, nnz, nnz_dev, B, zero_out, plan, st);
   profile_end(3, st);
   return rc;
 }
