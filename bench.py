@@ -55,11 +55,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a ROCm device (no CPU fallback)"
+    # rehearsal of the N > 1 code path on a one-GPU box: TTEMB_BENCH_REHEARSAL=1 puts every rank on GPU 0 and
+    # carries the all-reduce over gloo (RCCL needs one GPU per rank).  Never used for reported numbers.
+    rehearsal = os.environ.get("TTEMB_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
 
     import ttemb_native as nat
     from FBTT.tt_embeddings_ops import TTEmbeddingBag
@@ -84,9 +92,11 @@ def main():
         out = emb(id_sets[i % n_sets], offsets)
         out.backward(d_out)
         if dp is not None:
-            dp.step()
+            dp.step(overlap=True)   # the all-reduce runs under the next forward's grouping pass
 
     def fence():
+        if dp is not None:
+            dp.flush()              # the last step's update belongs to the timed region
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -101,29 +111,32 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     value = world * N * args.steps / elapsed
 
+    # roofline leg: kernels bracketed by HIP events on the stream they are launched on.
+    # slot 0 = forward chain kernel, slot 2 = backward chunk kernel, slot 1 = all backward chain kernels,
+    # slot 3 = grouping pass (counting sort + chunk table + prefix-product kernel).  Nominal work per
+    # lookup: forward F0 + F1 = 13 440 flop, backward 3 F0 + 2 F1 = 37 120 flop, 408 B each
+    # way (8 B id + one D-float row).  The chunk kernel's own share is the two per-id GEMMs of the backward
+    # (dP and the dG2 rows: 2 F1 = 6 400 flop) over 408 algorithmic bytes = 15.7 flop/B, under the
+    # fp32-MFMA ridge (157.3 TF / 8 TB/s = 19.7): it is priced against HBM.
+    # Every rank runs these steps (they contain the collective); rank 0 reports its own kernel times.
+    nat.profile_enable(True)
+    fwd_ms, bwd_ms, chunk_ms, group_ms = [], [], [], []
+    for i in range(10):
+        step(i)
+        fwd_ms.append(nat.profile_read(0))
+        bwd_ms.append(nat.profile_read(1))
+        chunk_ms.append(nat.profile_read(2))
+        group_ms.append(nat.profile_read(3))
+    nat.profile_enable(False)
+    fence()
+
     result = None
     if rank == 0:
-        # roofline leg: kernels bracketed by HIP events on the stream they are launched on.
-        # slot 0 = forward chain kernel, slot 2 = backward chunk kernel, slot 1 = all backward chain kernels,
-        # slot 3 = grouping pass (counting sort + chunk table + prefix-product kernel).  Nominal work per
-        # lookup: forward F0 + F1 = 13 440 flop, backward 3 F0 + 2 F1 = 37 120 flop, 408 B each
-        # way (8 B id + one D-float row).  The chunk kernel's own share is the two per-id GEMMs of the backward
-        # (dP and the dG2 rows: 2 F1 = 6 400 flop) over 408 algorithmic bytes = 15.7 flop/B, under the
-        # fp32-MFMA ridge (157.3 TF / 8 TB/s = 19.7): it is priced against HBM.
-        nat.profile_enable(True)
-        fwd_ms, bwd_ms, chunk_ms, group_ms = [], [], [], []
-        for i in range(10):
-            step(i)
-            fwd_ms.append(nat.profile_read(0))
-            bwd_ms.append(nat.profile_read(1))
-            chunk_ms.append(nat.profile_read(2))
-            group_ms.append(nat.profile_read(3))
-        nat.profile_enable(False)
         fwd, bwd, chunk = float(np.mean(fwd_ms)), float(np.mean(bwd_ms)), float(np.mean(chunk_ms))
         group = float(np.mean(group_ms))
         row_bytes = 8 + 4 * D

@@ -213,7 +213,18 @@ class TTLookupFunction(torch.autograd.Function):
         out = torch.empty((B, module.embedding_dim), dtype=torch.float32, device=indices.device)
         # the forward's grouping of the ids is kept for the backward of this very call
         ctx.plan = _nat.new_plan(module._shape, nnz, indices.device)
-        _nat.forward(module._shape, cores, indices, rowidx, offsets, nnz, nnz_dev, B, out, module._ws, ctx.plan)
+        pending = getattr(module, "_before_weights", None)
+        if pending is None:
+            _nat.forward(module._shape, cores, indices, rowidx, offsets, nnz, nnz_dev, B, out, module._ws, ctx.plan)
+        else:
+            # something still has to write the cores (ttemb_dist.TTDataParallel: the previous step's all-reduce +
+            # update): the id-only half of the forward is enqueued first so that it overlaps with it
+            if ctx.plan is not None:
+                _nat.forward(module._shape, cores, indices, rowidx, offsets, nnz, nnz_dev, B, out, module._ws, ctx.plan,
+                             phase=1)
+            pending()
+            _nat.forward(module._shape, cores, indices, rowidx, offsets, nnz, nnz_dev, B, out, module._ws, ctx.plan,
+                         phase=2 if ctx.plan is not None else 0)
         if ctx.live_cache and nnz > 0:
             _nat.cache_forward(cache_loc, rowidx, 0, nnz_dev, nnz, cache_weight.data, out, offsets)
         return out
@@ -343,6 +354,7 @@ class TableBatchedTTEmbeddingBag(nn.Module):
             self.cache_weight = None
         self.warmup = True
         self._dense_grad_out = None
+        self._before_weights = None   # set by ttemb_dist.TTDataParallel while an update of the cores is pending
         self._shape = _nat.make_shape(self.tt_p_shapes, self.tt_q_shapes, self.tt_ranks)
         self._ws = _nat.Workspace()
         self.register_load_state_dict_post_hook(TableBatchedTTEmbeddingBag._after_load)

@@ -298,10 +298,13 @@ int64_t ttemb_plan_bytes(const ttemb_shape_t* shape, int64_t nnz) {
   return use_fast3(ds, nnz, 0) ? fast3_plan_bytes(ds, nnz) : 0;
 }
 
-int ttemb_forward(const ttemb_shape_t* shape, const float* const* cores, const int64_t* indices,
-                  const int64_t* rowidx, const int64_t* offsets, int64_t nnz,
-                  const int32_t* nnz_dev, int64_t B, float* output, void* workspace,
-                  int64_t workspace_bytes, void* plan, int64_t plan_bytes, void* stream) {
+}  // extern "C"
+
+// phase 0 = the whole forward; 1 = everything that depends only on the ids; 2 = the rest (reads the cores)
+static int forward_phase(int phase, const ttemb_shape_t* shape, const float* const* cores, const int64_t* indices,
+                         const int64_t* rowidx, const int64_t* offsets, int64_t nnz,
+                         const int32_t* nnz_dev, int64_t B, float* output, void* workspace,
+                         int64_t workspace_bytes, void* plan, int64_t plan_bytes, void* stream) {
   DevShape ds;
   int rc = make_dev_shape(shape, &ds);
   if (rc) return rc;
@@ -314,6 +317,11 @@ int ttemb_forward(const ttemb_shape_t* shape, const float* const* cores, const i
   CorePtrs cp;
   for (int t = 0; t < TTEMB_MAX_CORES; ++t) cp.c[t] = t < ds.T ? cores[t] : nullptr;
   const bool f3 = nnz > 0 && use_fast3(ds, nnz, B);
+  if (phase == 1 && !f3) return TTEMB_OK;   // the generic kernels have no id-only half: phase 2 is their whole forward
+  if (phase == 2 && f3) {
+    return launch_forward_fast3(ds, cp, indices, rowidx, offsets, nnz, nnz_dev, B, output, offsets != nullptr, workspace,
+                                workspace_bytes, plan, plan_bytes, 2, reinterpret_cast<hipStream_t>(stream));
+  }
   if (rowidx == nullptr && offsets == nullptr && nnz > 0) return fail(TTEMB_E_BADARG, "rowidx and offsets are both null");
   char* ws = reinterpret_cast<char*>(workspace);
   // the row-index slot at the head of the workspace is part of the layout on both paths; the fast path derives
@@ -332,9 +340,35 @@ int ttemb_forward(const ttemb_shape_t* shape, const float* const* cores, const i
   if (rc || nnz == 0) return rc;
   if (f3)
     return launch_forward_fast3(ds, cp, indices, rowidx, offsets, nnz, nnz_dev, B, output, offsets != nullptr, workspace,
-                                workspace_bytes, plan, plan_bytes, st);
+                                workspace_bytes, plan, plan_bytes, phase, st);
   if (current_path() == TTEMB_PATH_FAST3) return fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
   return launch_forward_generic(ds, cp, indices, rowidx, offsets, nnz, nnz_dev, output, st);
+}
+
+extern "C" {
+
+int ttemb_forward(const ttemb_shape_t* shape, const float* const* cores, const int64_t* indices,
+                  const int64_t* rowidx, const int64_t* offsets, int64_t nnz,
+                  const int32_t* nnz_dev, int64_t B, float* output, void* workspace,
+                  int64_t workspace_bytes, void* plan, int64_t plan_bytes, void* stream) {
+  return forward_phase(0, shape, cores, indices, rowidx, offsets, nnz, nnz_dev, B, output, workspace, workspace_bytes, plan,
+                       plan_bytes, stream);
+}
+
+int ttemb_forward_group(const ttemb_shape_t* shape, const float* const* cores, const int64_t* indices,
+                        const int64_t* rowidx, const int64_t* offsets, int64_t nnz,
+                        const int32_t* nnz_dev, int64_t B, float* output, void* workspace,
+                        int64_t workspace_bytes, void* plan, int64_t plan_bytes, void* stream) {
+  return forward_phase(1, shape, cores, indices, rowidx, offsets, nnz, nnz_dev, B, output, workspace, workspace_bytes, plan,
+                       plan_bytes, stream);
+}
+
+int ttemb_forward_lookup(const ttemb_shape_t* shape, const float* const* cores, const int64_t* indices,
+                         const int64_t* rowidx, const int64_t* offsets, int64_t nnz,
+                         const int32_t* nnz_dev, int64_t B, float* output, void* workspace,
+                         int64_t workspace_bytes, void* plan, int64_t plan_bytes, void* stream) {
+  return forward_phase(2, shape, cores, indices, rowidx, offsets, nnz, nnz_dev, B, output, workspace, workspace_bytes, plan,
+                       plan_bytes, stream);
 }
 
 int ttemb_backward_dense(const ttemb_shape_t* shape, const float* const* cores,

@@ -57,12 +57,13 @@ bool fast3_pays(const DevShape& s, int64_t nnz);
 bool fast3_fits(const DevShape& s, int64_t nnz, int64_t B);  // enough ids per group for the grouped path to win
 int64_t fast3_workspace_bytes(const DevShape& s, int32_t op, int64_t nnz, int64_t B);
 int64_t fast3_plan_bytes(const DevShape& s, int64_t nnz);
+// phase: 0 = whole forward, 1 = id-only half (grouping into `plan`), 2 = lookup on a plan grouped by phase 1.
 // rowidx may be null when offsets is given (rows are derived while grouping); zero_rows: clear the output rows
 // of bags that do not hold exactly one id (needs offsets)
 int launch_forward_fast3(const DevShape& s, const CorePtrs& cores, const int64_t* indices,
                          const int64_t* rowidx, const int64_t* offsets, int64_t nnz,
                          const int32_t* nnz_dev, int64_t B, float* output, bool zero_rows, void* ws,
-                         int64_t ws_bytes, void* plan, int64_t plan_bytes, hipStream_t st);
+                         int64_t ws_bytes, void* plan, int64_t plan_bytes, int phase, hipStream_t st);
 int launch_backward_fast3(const DevShape& s, const CorePtrs& cores, const int64_t* indices,
                           const int64_t* rowidx, const int64_t* offsets, int64_t nnz, const int32_t* nnz_dev,
                           int64_t B, const float* d_output, const CorePtrsMut& d_cores, void* ws,

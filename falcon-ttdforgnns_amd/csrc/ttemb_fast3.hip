@@ -1429,26 +1429,29 @@ static int group_ids(const DevShape& s, const CorePtrs& cores, const int64_t* in
   if (rc) return rc;
   hipLaunchKernelGGL(fast3_place_kernel, dim3((unsigned)ranges), dim3(kRangeThreads), span * 16, st, (uint32_t)nnz, (uint32_t)G,
                      (uint32_t)shift, *plan);
-  rc = check_hip(hipGetLastError(), "fast3_place_kernel");
-  if (rc) return rc;
-  return run_prefix(s, cores, *plan, st);
+  return check_hip(hipGetLastError(), "fast3_place_kernel");
 }
 
 // resolve where the plan lives, carve the workspace, group the ids unless a ready plan was passed
+// plan_state: 0 = build the whole plan (grouping + prefix products), 1 = grouping only (the id-only half of a
+// two-phase forward), 2 = the plan is grouped, add the prefix products, 3 = the plan is complete
 static int prepare(const DevShape& s, const CorePtrs& cores, bool bwd, const int64_t* indices, const int64_t* rowidx,
                    const int64_t* offsets, int64_t nnz, const int32_t* nnz_dev, int64_t B, float* zero_out, void* ws,
-                   int64_t ws_bytes, void* plan_buf, int64_t plan_bytes, bool plan_ready, GroupPlan* plan, hipStream_t st) {
+                   int64_t ws_bytes, void* plan_buf, int64_t plan_bytes, int plan_state, GroupPlan* plan, hipStream_t st) {
   memset(plan, 0, sizeof(*plan));
   const bool external = plan_buf != nullptr && plan_bytes >= fast3_plan_bytes(s, nnz);
-  const bool reuse = external && plan_ready;
+  if (plan_state != 0 && !external) return fail(TTEMB_E_BADARG, "this call needs a plan buffer of ttemb_plan_bytes() bytes");
+  const bool reuse = plan_state >= 2;
   const int64_t need = carve_workspace(s, nnz, bwd, !external, !reuse, reinterpret_cast<char*>(ws), plan);
   if (need > 0 && ws == nullptr) return fail(TTEMB_E_WORKSPACE, "fast path needs a workspace");
   if (need > ws_bytes)
     return fail(TTEMB_E_WORKSPACE, "fast path needs %lld workspace bytes, got %lld", (long long)need, (long long)ws_bytes);
   if (external) carve_plan_part(s, nnz, reinterpret_cast<char*>(plan_buf), plan);
-  if (reuse) return TTEMB_OK;
+  if (plan_state == 3) return TTEMB_OK;
   profile_begin(3, st);
-  const int rc = group_ids(s, cores, indices, rowidx, offsets, nnz, nnz_dev, B, zero_out, plan, st);
+  int rc = TTEMB_OK;
+  if (plan_state <= 1) rc = group_ids(s, cores, indices, rowidx, offsets, nnz, nnz_dev, B, zero_out, plan, st);
+  if (rc == TTEMB_OK && plan_state != 1) rc = run_prefix(s, cores, *plan, st);
   profile_end(3, st);
   return rc;
 }
@@ -1490,12 +1493,12 @@ static int run_forward(const DevShape& s, const CorePtrs& cores, const GroupPlan
 int launch_forward_fast3(const DevShape& s, const CorePtrs& cores, const int64_t* indices,
                          const int64_t* rowidx, const int64_t* offsets, int64_t nnz, const int32_t* nnz_dev,
                          int64_t B, float* output, bool zero_rows, void* ws, int64_t ws_bytes, void* plan_buf,
-                         int64_t plan_bytes, hipStream_t st) {
+                         int64_t plan_bytes, int phase, hipStream_t st) {
   if (nnz <= 0) return TTEMB_OK;
   GroupPlan plan;
   int rc = prepare(s, cores, false, indices, rowidx, offsets, nnz, nnz_dev, B, zero_rows ? output : nullptr, ws, ws_bytes,
-                   plan_buf, plan_bytes, false, &plan, st);
-  if (rc) return rc;
+                   plan_buf, plan_bytes, phase, &plan, st);   // phase 0 / 1 / 2 = whole forward / ids only / lookup on a grouped plan
+  if (rc || phase == 1) return rc;
   switch (classify(s)) {
     case kProducts: return run_forward<4, 5, 5, 16, 16>(s, cores, plan, nnz, B, output, st);
     case kArxiv: return run_forward<4, 4, 8, 8, 8>(s, cores, plan, nnz, B, output, st);
@@ -1551,7 +1554,8 @@ int launch_backward_fast3(const DevShape& s, const CorePtrs& cores, const int64_
   if (nnz <= 0) return TTEMB_OK;
   GroupPlan plan;
   int rc = prepare(s, cores, true, indices, rowidx, offsets, nnz, nnz_dev, B, nullptr, ws, ws_bytes,
-                   const_cast<void*>(plan_buf), plan_bytes, plan_buf != nullptr, &plan, st);
+                   const_cast<void*>(plan_buf), plan_bytes,
+                   plan_buf != nullptr && plan_bytes >= fast3_plan_bytes(s, nnz) ? 3 : 0, &plan, st);
   if (rc) return rc;
   switch (classify(s)) {
     case kProducts: return run_backward<4, 5, 5, 16, 16>(s, cores, plan, nnz, B, d_output, d_cores, st);

@@ -69,6 +69,7 @@ class TTDataParallel:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.flat_weights: Optional[torch.Tensor] = None
         self.weight_views: List[torch.Tensor] = []
+        self._pending = None
         self.adopt_parameters()
         # the backward kernels write the core gradients straight into the bucket
         module._dense_grad_out = [v[0] if v.dim() == 3 and v.shape[0] == 1 else v
@@ -95,8 +96,15 @@ class TTDataParallel:
                 for p in self.bucket.params:
                     dist.broadcast(p.data, src, group=self.group)
 
-    def step(self, lr: Optional[float] = None) -> None:
-        """Call after ``loss.backward()``: all-reduce(sum) once, then w -= lr/world * g."""
+    def step(self, lr: Optional[float] = None, overlap: bool = False) -> None:
+        """Call after ``loss.backward()``: all-reduce(sum) once, then w -= lr/world * g.
+
+        ``overlap=True`` only *starts* the all-reduce: waiting for it and the update are deferred to the moment the
+        next ``forward`` needs the cores, i.e. after that forward's id-only work (grouping pass) has been enqueued --
+        the collective then runs under ~45 us of kernels that do not depend on it.  ``flush()`` (called by the
+        next forward, or by hand before reading the weights) finishes a deferred step.
+        """
+        self.flush()
         lr = float(self.module.learning_rate if lr is None else lr)
         b = self.bucket
         for v, p in zip(b.views, b.params):  # gradients that did not land in the bucket are packed
@@ -104,12 +112,29 @@ class TTDataParallel:
                 v.zero_()
             elif p.grad.data_ptr() != v.data_ptr():
                 v.copy_(p.grad)
+        for p in b.params:
+            p.grad = None
+        work = None
         if self.world > 1:
-            dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group)
+            work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=overlap)
+        self._pending = (work if overlap else None, lr)
+        if overlap:
+            self.module._before_weights = self.flush
+        else:
+            self.flush()
+
+    def flush(self) -> None:
+        """Finish a deferred step: wait for the all-reduce, apply the update."""
+        pending, self._pending = getattr(self, "_pending", None), None
+        self.module._before_weights = None
+        if pending is None:
+            return
+        work, lr = pending
+        if work is not None:
+            work.wait()
+        b = self.bucket
         if self._flat_ok():
             self.apply_fn(self.flat_weights, b.flat, lr / self.world)
         else:
             for p, g in zip(b.params, b.views):
                 self.apply_fn(p.data, g, lr / self.world)
-        for p in b.params:
-            p.grad = None

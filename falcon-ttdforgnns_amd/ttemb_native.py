@@ -28,7 +28,7 @@ PATH_AUTO, PATH_GENERIC, PATH_FAST3 = 0, 1, 2
 EXPORTED_SYMBOLS = (
     "ttemb_abi_version", "ttemb_last_error", "ttemb_workspace_bytes", "ttemb_plan_bytes", "ttemb_set_path",
     "ttemb_profile_enable", "ttemb_profile_read",
-    "ttemb_forward", "ttemb_backward_dense", "ttemb_backward_sgd", "ttemb_backward_adagrad",
+    "ttemb_forward", "ttemb_forward_group", "ttemb_forward_lookup", "ttemb_backward_dense", "ttemb_backward_sgd", "ttemb_backward_adagrad",
     "ttemb_sgd_step", "ttemb_adagrad_step", "ttemb_cache_update", "ttemb_cache_populate",
     "ttemb_preprocess", "ttemb_cache_forward", "ttemb_cache_backward_sgd",
     "ttemb_cache_backward_dense", "ttemb_cache_backward_rowwise_adagrad",
@@ -76,6 +76,8 @@ def _load() -> ctypes.CDLL:
     lib.ttemb_plan_bytes.restype = i64
     lib.ttemb_plan_bytes.argtypes = [shp, i64]
     lib.ttemb_forward.argtypes = [shp, vp, vp, vp, vp, i64, vp, i64, vp, vp, i64, vp, i64, vp]
+    lib.ttemb_forward_group.argtypes = lib.ttemb_forward.argtypes
+    lib.ttemb_forward_lookup.argtypes = lib.ttemb_forward.argtypes
     lib.ttemb_backward_dense.argtypes = [shp, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, i64, vp, i64, vp]
     lib.ttemb_backward_sgd.argtypes = [shp, vp, vp, vp, vp, i64, vp, i64, vp, f32, vp, i64, vp, i64, vp]
     lib.ttemb_backward_adagrad.argtypes = [shp, vp, vp, vp, vp, vp, i64, vp, i64, vp, f32, f32, vp, i64, vp, i64, vp]
@@ -203,13 +205,15 @@ def _plan_args(plan: Optional[torch.Tensor]):
 
 def forward(shape: Shape, cores: Sequence[torch.Tensor], indices: torch.Tensor, rowidx: torch.Tensor,
             offsets: Optional[torch.Tensor], nnz: int, nnz_dev: Optional[torch.Tensor], B: int,
-            output: torch.Tensor, ws: Workspace, plan: Optional[torch.Tensor] = None) -> None:
+            output: torch.Tensor, ws: Workspace, plan: Optional[torch.Tensor] = None, phase: int = 0) -> None:
+    """phase 0 = the whole forward; 1 = the id-only half (grouping into `plan`); 2 = the lookup on that plan."""
     dev = output.device
     w = ws.get(workspace_bytes(shape, OP_FORWARD, nnz, B), dev)
+    fn = (LIB.ttemb_forward, LIB.ttemb_forward_group, LIB.ttemb_forward_lookup)[phase]
     with _on_device(dev):
-        _check(LIB.ttemb_forward(ctypes.byref(shape), _ptr_array(cores), _ptr(indices), _ptr(rowidx),
-                                 _ptr(offsets), nnz, _ptr(nnz_dev), B, _ptr(output), _ptr(w), w.numel(),
-                                 *_plan_args(plan), _stream(output)))
+        _check(fn(ctypes.byref(shape), _ptr_array(cores), _ptr(indices), _ptr(rowidx),
+                  _ptr(offsets), nnz, _ptr(nnz_dev), B, _ptr(output), _ptr(w), w.numel(),
+                  *_plan_args(plan), _stream(output)))
 
 
 def backward_dense(shape: Shape, cores: Sequence[torch.Tensor], indices, rowidx, nnz: int, nnz_dev, B: int,

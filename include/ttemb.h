@@ -110,6 +110,25 @@ int ttemb_forward(const ttemb_shape_t* shape, const float* const* cores,
                   void* workspace, int64_t workspace_bytes, void* plan, int64_t plan_bytes,
                   void* stream);
 
+/* Two-phase forward, for a caller that wants to overlap the id-only work with something that still writes the
+ * cores (ttemb_dist.TTDataParallel: the all-reduce + update of the previous step):
+ *   ttemb_forward_group   everything that depends only on the ids -- the grouping pass into `plan`, bag rows,
+ *                         zeroing of the output rows of bags that do not hold exactly one id.  `cores` is not read.
+ *   ttemb_forward_lookup  the rest: prefix products and the chain kernel, on the plan the first call filled.
+ * Same arguments for both; `plan` (ttemb_plan_bytes() bytes) is required whenever ttemb_plan_bytes() != 0.
+ * ttemb_forward == group followed by lookup.  When the selected kernel family keeps no plan, group does nothing
+ * and lookup is the whole forward. */
+int ttemb_forward_group(const ttemb_shape_t* shape, const float* const* cores,
+                  const int64_t* indices, const int64_t* rowidx, const int64_t* offsets,
+                  int64_t nnz, const int32_t* nnz_dev, int64_t B, float* output,
+                  void* workspace, int64_t workspace_bytes, void* plan, int64_t plan_bytes,
+                  void* stream);
+int ttemb_forward_lookup(const ttemb_shape_t* shape, const float* const* cores,
+                  const int64_t* indices, const int64_t* rowidx, const int64_t* offsets,
+                  int64_t nnz, const int32_t* nnz_dev, int64_t B, float* output,
+                  void* workspace, int64_t workspace_bytes, void* plan, int64_t plan_bytes,
+                  void* stream);
+
 /* ---------------------------------------------------------------------------------
  * tt_dense_backward  (tt_embeddings.tt_dense_backward -- tt_embeddings.cpp:133-136,
  * tt_embeddings_cuda.cu:656-686, 421-654).  d_cores[t] (same shape as cores[t]) is

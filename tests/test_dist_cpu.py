@@ -41,8 +41,20 @@ def _worker(rank, world, port, out_dir):
         c.grad = gr.clone()
     dp.step()
     assert all(c.grad is None for c in m.tt_cores)
-    torch.save({"start": start, "grads": grads, "end": [c.detach().clone() for c in m.tt_cores]},
-               os.path.join(out_dir, f"rank{rank}.pt"))
+    end = [c.detach().clone() for c in m.tt_cores]
+    # the same step again, deferred: nothing changes until flush() (which the next forward calls before it reads
+    # the cores), then the result is the same update
+    for c, gr in zip(m.tt_cores, grads):
+        c.grad = gr.clone()
+    dp.step(overlap=True)
+    assert m._before_weights is not None and all(c.grad is None for c in m.tt_cores)
+    assert all(torch.equal(c.detach(), e) for c, e in zip(m.tt_cores, end))
+    m._before_weights()
+    assert m._before_weights is None
+    end2 = [c.detach().clone() for c in m.tt_cores]
+    dp.flush()   # idempotent
+    assert all(torch.equal(c.detach(), e) for c, e in zip(m.tt_cores, end2))
+    torch.save({"start": start, "grads": grads, "end": end, "end2": end2}, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -58,6 +70,10 @@ def test_dp_step_world2(tmp_path):
         for k in range(world):
             np.testing.assert_allclose(r[k]["end"][t].numpy(), want.numpy(), rtol=1e-6, atol=1e-7)
         assert torch.equal(r[0]["end"][t], r[1]["end"][t])  # replicas stay bit-identical
+        want2 = r[0]["end"][t] - 0.5 * mean_g                # the deferred (overlap=True) second step
+        for k in range(world):
+            np.testing.assert_allclose(r[k]["end2"][t].numpy(), want2.numpy(), rtol=1e-6, atol=1e-7)
+        assert torch.equal(r[0]["end2"][t], r[1]["end2"][t])
 
 
 def test_flat_bucket_layout():

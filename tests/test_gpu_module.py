@@ -400,7 +400,7 @@ def test_cache_live_on_the_fast_path(ops, orc):
                                    atol=1e-5 + 2e-4 * float(np.abs(lr * gr).max()))
 
 
-def _dp_gpu_worker(rank, world, port, out_dir):
+def _dp_gpu_worker(rank, world, port, out_dir, overlap=False):
     import os
     import sys
     from conftest import PKG, ROOT
@@ -427,15 +427,22 @@ def _dp_gpu_worker(rank, world, port, out_dir):
     d_out = (torch.rand(60000, 100, generator=g) - 0.5) * 0.02
     out = emb(ids.cuda(), torch.arange(60001).cuda())
     out.backward(d_out.cuda())
-    dp.step()
+    dp.step(overlap=overlap)
+    if overlap:  # the update is still pending; the next forward groups its ids, finishes the update, then looks up
+        assert emb._before_weights is not None
+    ids2 = ids[:50000].cuda()
+    with torch.no_grad():
+        out2 = emb(ids2, torch.arange(50001).cuda())
+    assert emb._before_weights is None
     torch.cuda.synchronize()
-    torch.save({"start": start, "ids": ids, "d_out": d_out, "end": [c.detach().cpu().clone() for c in emb.tt_cores]},
-               os.path.join(out_dir, f"rank{rank}.pt"))
+    torch.save({"start": start, "ids": ids, "d_out": d_out, "end": [c.detach().cpu().clone() for c in emb.tt_cores],
+                "out2": out2.cpu()}, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_data_parallel_step_two_ranks_on_gpu(orc, tmp_path):
+@pytest.mark.parametrize("overlap", [False, True])
+def test_data_parallel_step_two_ranks_on_gpu(orc, tmp_path, overlap):
     """TTDataParallel end to end with the real kernels: two ranks (gloo carries the GPU tensors; RCCL needs
     one GPU per rank), dense backward -> ONE all-reduce of the flattened core gradients -> fused SGD."""
     import socket
@@ -443,7 +450,7 @@ def test_data_parallel_step_two_ranks_on_gpu(orc, tmp_path):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mp.spawn(_dp_gpu_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_dp_gpu_worker, args=(2, port, str(tmp_path), overlap), nprocs=2, join=True)
     r = [torch.load(tmp_path / f"rank{k}.pt") for k in range(2)]
     p, q, R = [125, 140, 140], [4, 5, 5], [1, 16, 16, 1]
     cores = [c[0].numpy() for c in r[0]["start"]]
@@ -456,3 +463,9 @@ def test_data_parallel_step_two_ranks_on_gpu(orc, tmp_path):
             np.testing.assert_allclose(r[k]["end"][t][0].numpy(), want, rtol=0,
                                        atol=1e-5 + 2e-4 * float(np.abs(0.1 * (grads[0][t] + grads[1][t])).max()))
         assert torch.equal(r[0]["end"][t], r[1]["end"][t])  # replicas stay bit-identical
+    # the forward that followed the step used the UPDATED cores (with overlap the update ran between its two halves)
+    for k in range(2):
+        new_cores = [c[0].numpy() for c in r[k]["end"]]
+        ids2 = r[k]["ids"][:50000].numpy()
+        want_rows = orc.tt_rows(ids2, new_cores, p, q, R)
+        np.testing.assert_allclose(r[k]["out2"].numpy(), want_rows, rtol=1e-4, atol=1e-4 * float(np.abs(want_rows).max()))
