@@ -844,6 +844,7 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(const float* __rest
         for (int t = 0; t < C::RT2; ++t) dp[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 
+#if !(defined(TTEMB_ABL) && (TTEMB_ABL & 4))
     // ---- dP += dO (q0q1 x 16 q2) . G2s^T (16 q2 x r2) ----
 #pragma unroll
     for (int b4 = 0; b4 < kChunk / 4; ++b4)
@@ -865,12 +866,14 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(const float* __rest
         if (kk == Q2 - 1) __builtin_amdgcn_sched_barrier(0);  // keeps operand loads from piling up in registers
       }
 
+#endif
     // ---- E = P^T (r2 x q0q1) . dO (q0q1 x 16 q2) ----
     f32x4 e[C::RT2][C::NT2];
 #pragma unroll
     for (int t = 0; t < C::RT2; ++t)
 #pragma unroll
       for (int nt = 0; nt < C::NT2; ++nt) e[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#if !(defined(TTEMB_ABL) && (TTEMB_ABL & 8))
 #pragma unroll
     for (int s = 0; s < C::M2 / 4; ++s) {
       float av[C::RT2];
@@ -888,6 +891,7 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(const float* __rest
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();  // every LDS read of this chunk is done: the next chunk's rows may land
     __builtin_amdgcn_sched_barrier(0);

@@ -269,6 +269,30 @@ def test_fast_path_medium_batches_with_duplicates_and_bags(nat, orc, cfg, n_ids)
     assert_grads_close(grads, orc.tt_dense_backward(idx, offsets, d_out, cores, p, q, R), rel=2e-4)
 
 
+@pytest.mark.parametrize("p,q,R", [([5, 6, 7], [4, 5, 5], [1, 16, 16, 1]), ([3, 4, 6], [8, 4, 4], [1, 32, 32, 1]),
+                                   ([9, 8, 5], [4, 4, 8], [1, 8, 8, 1])])
+def test_fast_path_huge_groups_and_bags(nat, orc, p, q, R):
+    """Few (i0, i1) groups with ~1000 ids each (tens of chunks per group, groups that span several wavefronts'
+    descriptor ranges), one id repeated thousands of times, one bag holding thousands of ids, empty bags."""
+    set_path(nat, "fast3", q, R)
+    n_emb = int(np.prod(p))
+    rng = np.random.default_rng(11 + p[0])
+    cores = [(rng.standard_normal((p[t], R[t] * q[t] * R[t + 1])) * 0.3).astype(np.float32) for t in range(3)]
+    idx = rng.integers(0, n_emb, size=30000).astype(np.int64)
+    idx[5000:9000] = idx[0]                      # 4000 copies of one id
+    lens = np.concatenate([[0, 6000, 0, 1], rng.integers(0, 3, size=40000)])
+    lens = lens[np.cumsum(lens) <= idx.shape[0]]
+    idx = idx[: int(lens.sum())]
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    B, D = offsets.shape[0] - 1, int(np.prod(q))
+    out, _ = run_forward(nat, p, q, R, cores, idx, offsets)
+    want = orc.tt_forward(idx, offsets, cores, p, q, R)
+    np.testing.assert_allclose(out, want, rtol=1e-4, atol=1e-4 * float(np.abs(want).max()))
+    d_out = ((rng.random((B, D)) - 0.5) * 0.1).astype(np.float32)
+    grads = run_backward_dense(nat, p, q, R, cores, idx, offsets, d_out)
+    assert_grads_close(grads, orc.tt_dense_backward(idx, offsets, d_out, cores, p, q, R), rel=2e-4)
+
+
 @pytest.mark.parametrize("path", ["auto"])
 def test_full_size_properties_products(nat, orc, path):
     set_path(nat, path)
