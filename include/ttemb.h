@@ -59,8 +59,8 @@ enum {
 
 /* Kernel-selection knob for forward/backward (tests drive both; 0 is the default). */
 enum {
-  TTEMB_PATH_AUTO = 0,          /* fast path when the shape supports it and the batch has
-                                   at least ~2 ids per (i0,i1) group, else generic      */
+  TTEMB_PATH_AUTO = 0,          /* fast path when the shape supports it and the batch has at
+                                   least max(4096, p0*p1/4) ids (measured crossover), else generic */
   TTEMB_PATH_GENERIC = 1,       /* shape-generic wave-per-id kernels (T = 2..4)    */
   TTEMB_PATH_FAST3 = 2          /* sorted / grouped MFMA path, T == 3 only         */
 };
