@@ -227,10 +227,10 @@ static int resolve_rowidx(const int64_t** rowidx, const int64_t* offsets, int64_
 static int backward_into(const DevShape& ds, const CorePtrs& cp, const int64_t* indices,
                          const int64_t* rowidx, const int64_t* offsets, int64_t nnz, const int32_t* nnz_dev, int64_t B,
                          const float* d_output, const CorePtrsMut& dst, void* ws, int64_t ws_bytes,
-                         const void* plan, int64_t plan_bytes, hipStream_t st) {
+                         const void* plan, int64_t plan_bytes, hipStream_t st, const FusedUpdate* update = nullptr) {
   if (use_fast3(ds, nnz, B))
     return launch_backward_fast3(ds, cp, indices, rowidx, offsets, nnz, nnz_dev, B, d_output, dst, ws, ws_bytes, plan,
-                                 plan_bytes, st);
+                                 plan_bytes, st, update);
   if (current_path() == TTEMB_PATH_FAST3) return fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
   for (int t = 0; t < ds.T; ++t) {
     int rc = check_hip(hipMemsetAsync(dst.c[t], 0, (size_t)ds.p[t] * ds.row_len[t] * 4, st), "memset d_core");
@@ -432,8 +432,22 @@ static int fused_backward(const ttemb_shape_t* shape, float* const* cores, float
   int64_t rest = workspace_bytes - off;
   rc = resolve_rowidx(&rowidx, offsets, nnz, B, &rest_ws, &rest, st, use_fast3(ds, nnz, B));
   if (rc) return rc;
-  rc = backward_into(ds, cp, indices, rowidx, offsets, nnz, nnz_dev, B, d_output, gp, rest_ws, rest, plan, plan_bytes, st);
-  if (rc) return rc;
+  const bool f3 = use_fast3(ds, nnz, B);
+  bool aligned4 = true;
+  FusedUpdate upd;
+  memset(&upd, 0, sizeof(upd));
+  for (int t = 0; t < ds.T; ++t) {
+    upd.w[t] = cores[t];
+    upd.st[t] = opt_state ? opt_state[t] : nullptr;
+    aligned4 = aligned4 && cores[t] != nullptr && (!opt_state || opt_state[t] != nullptr);
+  }
+  if (!aligned4) return fail(TTEMB_E_BADARG, "null core / optimizer state");
+  upd.lr = lr;
+  upd.eps = eps;
+  // the grouped path applies the step inside its last kernel; the generic path writes gradients, then steps
+  rc = backward_into(ds, cp, indices, rowidx, offsets, nnz, nnz_dev, B, d_output, gp, rest_ws, rest, plan, plan_bytes, st,
+                     f3 ? &upd : nullptr);
+  if (rc || f3) return rc;
   Seg3 seg;
   memset(&seg, 0, sizeof(seg));
   int64_t nmax = 0;

@@ -64,10 +64,17 @@ int launch_forward_fast3(const DevShape& s, const CorePtrs& cores, const int64_t
                          const int64_t* rowidx, const int64_t* offsets, int64_t nnz,
                          const int32_t* nnz_dev, int64_t B, float* output, bool zero_rows, void* ws,
                          int64_t ws_bytes, void* plan, int64_t plan_bytes, int phase, hipStream_t st);
+// optimiser step folded into the last backward kernel (w == nullptr: none, gradients are written instead)
+struct FusedUpdate {
+  float* w[TTEMB_MAX_CORES];
+  float* st[TTEMB_MAX_CORES];   // Adagrad state, or null for SGD
+  float lr, eps;
+};
 int launch_backward_fast3(const DevShape& s, const CorePtrs& cores, const int64_t* indices,
                           const int64_t* rowidx, const int64_t* offsets, int64_t nnz, const int32_t* nnz_dev,
                           int64_t B, const float* d_output, const CorePtrsMut& d_cores, void* ws,
-                          int64_t ws_bytes, const void* plan, int64_t plan_bytes, hipStream_t st);
+                          int64_t ws_bytes, const void* plan, int64_t plan_bytes, hipStream_t st,
+                          const FusedUpdate* update = nullptr);
 
 // ---------------------------------------------------------------------------------
 // device helpers

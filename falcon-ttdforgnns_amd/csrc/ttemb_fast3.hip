@@ -1037,12 +1037,16 @@ __global__ __launch_bounds__(NWB * 64) void fast3_dg2_reduce_kernel(GroupPlan pl
 }
 
 // C. group epilogue: one wavefront per (i1, slice of `gpw` consecutive i0) -- groups are numbered i1 * p0 + i0.
-//    dG1[i1] += G0[i0]^T . dP accumulates in MFMA registers over the slice and leaves as the slice's own slab
-//    (plain stores; the first version flushed with float atomics: 2.8 M of them per launch bounded the kernel),
-//    the dG0 contribution dP . G1[i1]^T is stored per group.  The finalize kernel adds slabs and contributions.
-//    The loop body is the same instruction stream for every group: an empty group's dP load falls off its buffer
-//    (zeros), so it multiplies zeros and stores a zero contribution -- no branch around a memory instruction, the
-//    next group's operands are requested before this group's MFMAs and its stores are issued after them.
+//    The slice is walked 16/q0 groups at a time: their dP (q0 x q1 r2 each) stacked are one 16-row MFMA operand, so
+//        dG0 parts  = [dP of 16/q0 groups] (16 x q1r2) . G1[i1]^T (q1r2 x r1)      -- all 16 rows of the tile are real
+//        dG1[i1]   += [G0 rows of those groups]^T (r1 x 16) . [dP] (16 x q1r2)     -- K = 16 instead of q0
+//    (group by group the first product used q0 of 16 tile rows: 25 MFMAs per group against 10 now).
+//    dG1 accumulates in MFMA registers over the slice and leaves as the slice's own slab (plain stores; the first
+//    version flushed with float atomics: 2.8 M of them per launch bounded the kernel), the dG0 contribution is stored
+//    per group.  The finalize kernel adds slabs and contributions.  The loop body is the same instruction stream for
+//    every batch: an empty group's dP load falls off its buffer (zeros), so it multiplies zeros and stores a zero
+//    contribution -- no branch around a memory instruction; the next batch's operands are requested before this
+//    batch's MFMAs and its stores are issued after them.
 #ifndef TTEMB_EPI_SLICES
 #define TTEMB_EPI_SLICES 16
 #endif
@@ -1051,7 +1055,14 @@ template <int Q0, int Q1, int Q2, int R1, int R2>
 __global__ __launch_bounds__(64) void fast3_group_epilogue_kernel(
     const float* __restrict__ G0, const float* __restrict__ G1, uint32_t p0, uint32_t p1, uint32_t gpw, GroupPlan plan) {
   using C = Cfg<Q0, Q1, Q2, R1, R2>;
-  __shared__ __attribute__((aligned(16))) float dpbuf[C::P_FLOATS];
+  constexpr int GM = 16 / Q0;            // groups per batch: their q0 rows fill one 16-row MFMA tile
+  constexpr int LDD = C::N1 + 4;         // row stride of the staged dP rows (16-byte aligned rows)
+  constexpr int PF = C::M2 * R2;         // floats of one group's dP = q0 * N1
+  constexpr int BF4 = 16 * C::N1 / 4;    // float4 pieces of a batch's stacked dP
+  constexpr int NLB = (BF4 + kWave - 1) / kWave;
+  constexpr int KS3 = C::N1 / 4;
+  static_assert(16 % Q0 == 0 && C::N1 % 4 == 0, "q0 must divide the MFMA tile height");
+  __shared__ __attribute__((aligned(16))) float dpbuf[16 * LDD];
   __shared__ __attribute__((aligned(16))) float g1buf[R1 * C::LDG];
   const int lane = threadIdx.x;
   const int hi = lane >> 4, lo = lane & 15;
@@ -1060,10 +1071,6 @@ __global__ __launch_bounds__(64) void fast3_group_epilogue_kernel(
   const uint32_t i0_end = i0_begin + gpw < p0 ? i0_begin + gpw : p0;
   const uint32_t g_begin = i1 * p0 + i0_begin;
   const uint32_t G = p0 * p1;
-  constexpr int PF = C::M2 * R2;
-  constexpr int PER = (PF + kWave - 1) / kWave;
-  constexpr int KS0 = (Q0 + 3) / 4;
-  constexpr int KS3 = C::N1 / 4;
   const rsrc_t r_dp = make_rsrc(plan.dptab, G * (uint32_t)PF * 4u);
   const rsrc_t r_g0 = make_rsrc(G0, p0 * (uint32_t)C::ROW0 * 4u);
   const rsrc_t r_part = make_rsrc(plan.g0part, G * (uint32_t)C::ROW0 * 4u);
@@ -1077,24 +1084,27 @@ __global__ __launch_bounds__(64) void fast3_group_epilogue_kernel(
   // which of this wave's groups hold ids (one lane per group; gpw <= 64)
   const uint32_t cnt_l = (i0_begin + lane < i0_end) ? plan.counts[g_begin + lane] : 0u;
   const unsigned long long live = __ballot(cnt_l != 0);
-  float nxt[PER], nxt_g0[KS0][C::RT1];
-  auto request = [&](uint32_t k) {   // operands of the slice's k-th group; an empty or missing group reads zeros
-    const bool on = k < gpw && ((live >> k) & 1ull);
-    const uint32_t base = (g_begin + k) * (uint32_t)(PF * 4);
+  float4 nxt[NLB];
+  float nxt_g0[4][C::RT1];
+  auto request = [&](uint32_t k0) {   // operands of the batch of groups k0 .. k0 + GM - 1; an empty or missing group reads zeros
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int e = i * kWave + lane;
-      nxt[i] = __uint_as_float(buf_load1u(r_dp, (on && (PF % kWave == 0 || e < PF)) ? base + 4u * e : kOob));
+    for (int it = 0; it < NLB; ++it) {
+      const int e = it * kWave + lane;                  // float4 number e of the stacked [16][N1] block
+      const uint32_t gi = k0 + (uint32_t)(4 * e / PF);  // the group it belongs to
+      const bool on = (BF4 % kWave == 0 || e < BF4) && gi < gpw && ((live >> gi) & 1ull);
+      nxt[it] = buf_load4(r_dp, on ? (g_begin + k0) * (uint32_t)(PF * 4) + 16u * e : kOob);
     }
-    const uint32_t g0off = (i0_begin + k) * (uint32_t)(C::ROW0 * 4);
+    // A operand of the dG1 product: row c = 16 t + lo of G0^T, column rho = 4 s + hi = (group rho / q0, core row rho % q0)
 #pragma unroll
-    for (int s = 0; s < KS0; ++s)
+    for (int s = 0; s < 4; ++s) {
+      const int rho = 4 * s + hi;
+      const uint32_t gi = k0 + (uint32_t)(rho / Q0);
+      const bool on = gi < gpw && ((live >> gi) & 1ull);
 #pragma unroll
-      for (int t = 0; t < C::RT1; ++t) {
-        const int a = 4 * s + hi;
-        nxt_g0[s][t] = __uint_as_float(
-            buf_load1u(r_g0, (on && a < Q0 && 16 * t + lo < R1) ? g0off + 4u * (a * R1 + 16 * t + lo) : kOob));
-      }
+      for (int t = 0; t < C::RT1; ++t)
+        nxt_g0[s][t] = __uint_as_float(buf_load1u(
+            r_g0, (on && 16 * t + lo < R1) ? (i0_begin + gi) * (uint32_t)(C::ROW0 * 4) + 4u * ((rho % Q0) * R1 + 16 * t + lo) : kOob));
+    }
   };
   request(0);
   {
@@ -1115,53 +1125,48 @@ __global__ __launch_bounds__(64) void fast3_group_epilogue_kernel(
     }
   }
   const uint32_t n_here = i0_end - i0_begin;
-  for (uint32_t k = 0; k < n_here; ++k) {
-    // dP of the group -> LDS matrix [m2][c2]
-    float g0v[KS0][C::RT1];
+  for (uint32_t k0 = 0; k0 < n_here; k0 += GM) {
+    // the batch's stacked dP -> LDS [rho][n]
+    float g0v[4][C::RT1];
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int e = i * kWave + lane;
-      if (PF % kWave == 0 || e < PF) dpbuf[(e / R2) * C::LDA + e % R2] = nxt[i];
+    for (int it = 0; it < NLB; ++it) {
+      const int e = it * kWave + lane;
+      if (BF4 % kWave == 0 || e < BF4) *reinterpret_cast<float4*>(dpbuf + (4 * e / C::N1) * LDD + (4 * e) % C::N1) = nxt[it];
     }
 #pragma unroll
-    for (int s = 0; s < KS0; ++s)
+    for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int t = 0; t < C::RT1; ++t) g0v[s][t] = nxt_g0[s][t];
     __builtin_amdgcn_sched_barrier(0);
-    request(k + 1);
+    request(k0 + GM);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();  // one wavefront per workgroup: LDS hand-over only (a __syncthreads would also drain the prefetch)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // operands of both products are read from LDS first, then the MFMAs run back to back
-    float b1[KS0][C::NT1];
+    float b1[4][C::NT1];     // dG1: B[k = rho = 4 s + hi][n = 16 nt + lo]
 #pragma unroll
-    for (int s = 0; s < KS0; ++s) {
-      const int a = 4 * s + hi;
+    for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int nt = 0; nt < C::NT1; ++nt) {
-        const int n = 16 * nt + lo;
-        b1[s][nt] = a < Q0 ? dpbuf[(a * Q1 + n / R2) * C::LDA + n % R2] : 0.f;
-      }
-    }
-    float a3[KS3], b3[KS3][C::RT1];
+      for (int nt = 0; nt < C::NT1; ++nt) b1[s][nt] = dpbuf[(4 * s + hi) * LDD + 16 * nt + lo];
+    float a3[KS3], b3[KS3][C::RT1];   // dG0: A[rho = lo][k = n = 4 s + hi], B[k = n][c = 16 t + lo] = G1[c][n]
 #pragma unroll
     for (int s = 0; s < KS3; ++s) {
       const int n = 4 * s + hi;
-      a3[s] = lo < Q0 ? dpbuf[(lo * Q1 + n / R2) * C::LDA + n % R2] : 0.f;
+      a3[s] = dpbuf[lo * LDD + n];
 #pragma unroll
       for (int t = 0; t < C::RT1; ++t) b3[s][t] = 16 * t + lo < R1 ? g1buf[(16 * t + lo) * C::LDG + n] : 0.f;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();  // every LDS read of this group is done before the next dP lands
-    // dG1[i1] += G0[i0]^T (r1 x q0) . dP (q0 x q1 r2)
+    __builtin_amdgcn_wave_barrier();  // every LDS read of this batch is done before the next dP lands
+    // dG1[i1] += [G0 rows]^T (r1 x 16) . [dP] (16 x q1 r2)
 #pragma unroll
-    for (int s = 0; s < KS0; ++s)
+    for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int nt = 0; nt < C::NT1; ++nt)
 #pragma unroll
         for (int t = 0; t < C::RT1; ++t)
           g1acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(g0v[s][t], b1[s][nt], g1acc[t][nt], 0, 0, 0);
-    // dG0[i0] += dP (q0 x q1 r2) . G1[i1]^T (q1 r2 x r1); four interleaved accumulation chains
+    // dG0 parts = [dP] (16 x q1 r2) . G1[i1]^T (q1 r2 x r1); four interleaved accumulation chains
     f32x4 g0part[4][C::RT1];
 #pragma unroll
     for (int c = 0; c < 4; ++c)
@@ -1172,15 +1177,17 @@ __global__ __launch_bounds__(64) void fast3_group_epilogue_kernel(
 #pragma unroll
       for (int t = 0; t < C::RT1; ++t)
         g0part[s & 3][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[s], b3[s][t], g0part[s & 3][t], 0, 0, 0);
-    // the group's contribution to dG0 (zeros for an empty group): summed over i1 by fast3_finalize_kernel
-    const uint32_t dst0 = (g_begin + k) * (uint32_t)(C::ROW0 * 4);
+    // every group's contribution to dG0 (zeros for an empty group): summed over i1 by fast3_finalize_kernel.
+    // accumulator row 4 hi + r = rho = (group rho / q0, core row rho % q0), column c = 16 t + lo
 #pragma unroll
     for (int t = 0; t < C::RT1; ++t) {
       const f32x4 sum = (g0part[0][t] + g0part[1][t]) + (g0part[2][t] + g0part[3][t]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int a = 4 * hi + r;
-        buf_store1(r_part, (a < Q0 && 16 * t + lo < R1) ? dst0 + 4u * (a * R1 + 16 * t + lo) : kOob, sum[r]);
+        const int rho = 4 * hi + r;
+        const uint32_t gi = k0 + (uint32_t)(rho / Q0);
+        const bool on = gi < n_here && 16 * t + lo < R1;
+        buf_store1(r_part, on ? (g_begin + gi) * (uint32_t)(C::ROW0 * 4) + 4u * ((rho % Q0) * R1 + 16 * t + lo) : kOob, sum[r]);
       }
     }
   }
@@ -1197,14 +1204,27 @@ __global__ __launch_bounds__(64) void fast3_group_epilogue_kernel(
       }
 }
 
-// D. finalize: dG2 = sum of the per-tile slabs; dG0[i0] = sum over i1 of the per-group contributions of the
+// D. finalize (and, in the fused modes, the optimiser step: every core element is produced exactly once here, so
+// the update needs no gradient buffer and no extra launch): dG2 = sum of the per-tile slabs; dG0[i0] = sum over i1 of the per-group contributions of the
 // non-empty groups; dG1 = sum of the per-slice slabs.  A workgroup owns 32 consecutive outputs; its 8 lane
 // rows split the terms, so every load instruction reads 128 contiguous bytes per row and many
 // are in flight; the 8 partial sums meet in LDS.  Every output is written exactly once.
+__device__ __forceinline__ void finalize_emit(const FusedUpdate& upd, int t, float* __restrict__ grad, int idx, float g) {
+  if (upd.w[0] == nullptr) {   // dense mode: the gradient itself
+    grad[idx] = g;
+  } else if (upd.st[0] == nullptr) {   // fused SGD (tt_embeddings_cuda.cu:381-397), every row
+    upd.w[t][idx] -= upd.lr * g;
+  } else {                             // fused Adagrad (tt_embeddings_cuda.cu:399-419)
+    const float s2 = upd.st[t][idx] + g * g;
+    upd.st[t][idx] = s2;
+    upd.w[t][idx] -= upd.lr * g / (sqrtf(s2) + upd.eps);
+  }
+}
+
 __global__ __launch_bounds__(256) void fast3_finalize_kernel(GroupPlan plan, int tiles, int slices, int p0, int p1,
                                                              int g2_floats, int row0, int g1_floats, int q2, int r2,
                                                              float* __restrict__ dG0, float* __restrict__ dG1,
-                                                             float* __restrict__ dG2) {
+                                                             float* __restrict__ dG2, FusedUpdate upd) {
   __shared__ float part[8][33];
   const int x = threadIdx.x & 31, y = threadIdx.x >> 5;
   const int e = blockIdx.x * 32 + x;
@@ -1252,11 +1272,11 @@ __global__ __launch_bounds__(256) void fast3_finalize_kernel(GroupPlan plan, int
       const int row2 = q2 * r2;
       const int i2 = e / row2, w = e - i2 * row2;
       const int kk = w / r2, c2 = w - kk * r2;
-      dG2[i2 * row2 + c2 * q2 + kk] = tot;
+      finalize_emit(upd, 2, dG2, i2 * row2 + c2 * q2 + kk, tot);
     } else if (e < g2_floats + n0) {
-      dG0[e - g2_floats] = tot;
+      finalize_emit(upd, 0, dG0, e - g2_floats, tot);
     } else if (e < g2_floats + n0 + g1_floats) {
-      dG1[e - g2_floats - n0] = tot;
+      finalize_emit(upd, 1, dG1, e - g2_floats - n0, tot);
     }
   }
 }
@@ -1519,7 +1539,7 @@ int launch_forward_fast3(const DevShape& s, const CorePtrs& cores, const int64_t
 
 template <int Q0, int Q1, int Q2, int R1, int R2>
 static int run_backward(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int64_t nnz, int64_t B,
-                        const float* d_output, const CorePtrsMut& d_cores, hipStream_t st) {
+                        const float* d_output, const CorePtrsMut& d_cores, const FusedUpdate& upd, hipStream_t st) {
   using C = Cfg<Q0, Q1, Q2, R1, R2>;
   const int64_t G = num_groups(s);
   profile_begin(1, st);
@@ -1545,7 +1565,7 @@ static int run_backward(const DevShape& s, const CorePtrs& cores, const GroupPla
     const int g2_floats = s.p[2] * C::ROW2, g1_floats = s.p[1] * C::ROW1;
     const int outs = g2_floats + s.p[0] * C::ROW0 + g1_floats;
     hipLaunchKernelGGL(fast3_finalize_kernel, dim3((unsigned)((outs + 31) / 32)), dim3(256), 0, st, plan, tiles, slices,
-                       s.p[0], s.p[1], g2_floats, (int)C::ROW0, g1_floats, Q2, R2, d_cores.c[0], d_cores.c[1], d_cores.c[2]);
+                       s.p[0], s.p[1], g2_floats, (int)C::ROW0, g1_floats, Q2, R2, d_cores.c[0], d_cores.c[1], d_cores.c[2], upd);
   }
   profile_end(1, st);
   return check_hip(hipGetLastError(), "fast3_finalize_kernel");
@@ -1554,10 +1574,13 @@ static int run_backward(const DevShape& s, const CorePtrs& cores, const GroupPla
 int launch_backward_fast3(const DevShape& s, const CorePtrs& cores, const int64_t* indices,
                           const int64_t* rowidx, const int64_t* offsets, int64_t nnz, const int32_t* nnz_dev,
                           int64_t B, const float* d_output, const CorePtrsMut& d_cores, void* ws, int64_t ws_bytes,
-                          const void* plan_buf, int64_t plan_bytes, hipStream_t st) {
-  // every core gradient is written whole by the finalize kernel
+                          const void* plan_buf, int64_t plan_bytes, hipStream_t st, const FusedUpdate* update) {
+  FusedUpdate upd;
+  memset(&upd, 0, sizeof(upd));
+  if (update != nullptr) upd = *update;
+  // every core gradient is written whole by the finalize kernel (an empty call in a fused mode is a no-op)
   for (int t = 0; t < s.T; ++t) {
-    if (nnz > 0) continue;
+    if (nnz > 0 || update != nullptr) continue;
     int rc = check_hip(hipMemsetAsync(d_cores.c[t], 0, (size_t)s.p[t] * s.row_len[t] * 4, st), "memset d_core");
     if (rc) return rc;
   }
@@ -1568,9 +1591,9 @@ int launch_backward_fast3(const DevShape& s, const CorePtrs& cores, const int64_
                    plan_buf != nullptr && plan_bytes >= fast3_plan_bytes(s, nnz) ? 3 : 0, &plan, st);
   if (rc) return rc;
   switch (classify(s)) {
-    case kProducts: return run_backward<4, 5, 5, 16, 16>(s, cores, plan, nnz, B, d_output, d_cores, st);
-    case kArxiv: return run_backward<4, 4, 8, 8, 8>(s, cores, plan, nnz, B, d_output, d_cores, st);
-    case kPapers: return run_backward<8, 4, 4, 32, 32>(s, cores, plan, nnz, B, d_output, d_cores, st);
+    case kProducts: return run_backward<4, 5, 5, 16, 16>(s, cores, plan, nnz, B, d_output, d_cores, upd, st);
+    case kArxiv: return run_backward<4, 4, 8, 8, 8>(s, cores, plan, nnz, B, d_output, d_cores, upd, st);
+    case kPapers: return run_backward<8, 4, 4, 32, 32>(s, cores, plan, nnz, B, d_output, d_cores, upd, st);
     default: return fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
   }
 }
