@@ -546,58 +546,71 @@ __global__ __launch_bounds__(64) void fast3_forward_kernel(const float* __restri
   const rsrc_t r_p = make_rsrc(plan.ptab, G * (uint32_t)PF * 4u);
   const rsrc_t r_out = make_rsrc(out, out_bytes);
 
+  // Pipeline of one wavefront (k = the chunk being multiplied):
+  //     multiply chunk k out of LDS, rows -> LDS -> registers | G2 rows of k+1: registers -> LDS | offsets of k+2 from
+  //     its (i2, row) pairs | store the rows of k | load the G2 rows (and P) of k+2 | load the pairs of k+3
+  // Stores are issued only after everything the next steps wait for has been consumed, so no wait sits behind a store.
+  struct Offs {
+    uint32_t row, prow;   // byte offsets of this lane's pieces: G2 row, P (kOob = same group as before)
+  };
   auto fetch_meta = [&](const uint4& d, uint32_t& i2, uint32_t& val) {
     const uint32_t voff = b_l < (int)(d.z & 0xffu) ? (d.x + (uint32_t)b_l) * 4u : kOob;
     i2 = buf_load1u(r_i2, voff);   // unused slots read 0: row 0 stands in
     val = buf_load1u(r_val, voff);
   };
+  auto offsets = [&](const uint4& d, uint32_t i2, bool with_p) {
+    Offs o;
+    o.row = i2 * (uint32_t)(C::ROW2 * 4) + 16u * j_l;
+    o.prow = with_p ? d.y * (uint32_t)(PF * 4) + 16u * lane : kOob;
+    return o;
+  };
   float4 pre_g[NLG], pre_p[NLP];
-  auto request = [&](const uint4& d, uint32_t i2, bool with_p) {   // with_p is wave-uniform: only offsets change
-    const uint32_t row = i2 * (uint32_t)(C::ROW2 * 4) + 16u * j_l;
+  auto request = [&](const Offs& o) {
 #pragma unroll
     for (int k = 0; k < NLG; ++k)
-      pre_g[k] = buf_load4(r_g2, (F4G % 4 == 0 || j_l + 4 * k < F4G) ? row + 64u * k : kOob);
+      pre_g[k] = buf_load4(r_g2, (F4G % 4 == 0 || j_l + 4 * k < F4G) ? o.row + 64u * k : kOob);
 #pragma unroll
-    for (int it = 0; it < NLP; ++it) {
-      const int e = it * kWave + lane;
-      pre_p[it] = buf_load4(r_p, (with_p && (PF4 % kWave == 0 || e < PF4)) ? d.y * (uint32_t)(PF * 4) + 16u * e : kOob);
-    }
+    for (int it = 0; it < NLP; ++it)
+      pre_p[it] = buf_load4(r_p, (o.prow != kOob && (PF4 % kWave == 0 || it * kWave + lane < PF4)) ? o.prow + 1024u * it : kOob);
   };
-
-  uint4 d_cur = load_desc(ctab, c0, c1);
-  uint4 d_nxt = load_desc(ctab, c0 + 1, c1);   // past c1: an empty chunk
-  uint32_t i2_cur, val_cur, i2_nxt, val_nxt;
-  fetch_meta(d_cur, i2_cur, val_cur);
-  request(d_cur, i2_cur, true);
-  fetch_meta(d_nxt, i2_nxt, val_nxt);
-
-  for (uint32_t c = c0; c < c1; ++c) {
-    const int len = (int)(d_cur.z & 0xffu);
-    // ---- the prefix product of a new group -> LDS, as a (q0 q1) x r2 matrix (P rows are padded: b32 writes) ----
+  auto stage = [&](bool with_p) {   // registers -> LDS
+    if (with_p) {   // the prefix product of a new group, as a (q0 q1) x r2 matrix (P rows are padded: b32 writes)
 #pragma unroll
-    for (int it = 0; it < NLP; ++it) {
-      const int e = it * kWave + lane;
-      if ((c == c0 || (d_cur.z & kFirstBit)) && (PF4 % kWave == 0 || e < PF4)) {
-        float* dst = pbuf + (4 * e / R2) * C::LDA + (4 * e) % R2;
-        dst[0] = pre_p[it].x;
-        dst[1] = pre_p[it].y;
-        dst[2] = pre_p[it].z;
-        dst[3] = pre_p[it].w;
+      for (int it = 0; it < NLP; ++it) {
+        const int e = it * kWave + lane;
+        if (PF4 % kWave == 0 || e < PF4) {
+          float* dst = pbuf + (4 * e / R2) * C::LDA + (4 * e) % R2;
+          dst[0] = pre_p[it].x;
+          dst[1] = pre_p[it].y;
+          dst[2] = pre_p[it].z;
+          dst[3] = pre_p[it].w;
+        }
       }
     }
-    // ---- the chunk's G2 rows: registers -> LDS ----
 #pragma unroll
     for (int k = 0; k < NLG; ++k) {
       const int idx = j_l + 4 * k;
       if (F4G % 4 == 0 || idx < F4G) *reinterpret_cast<float4*>(bbuf + b_l * C::LDB + 4 * idx) = pre_g[k];
     }
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- next chunk's rows and the chunk after's indices go out now; they land while this one computes ----
+  };
+
+  // ---- prologue: chunk 0 into LDS, rows of chunk 1 and the pairs of chunk 2 in flight ----
+  uint4 d_cur = load_desc(ctab, c0, c1);
+  uint4 d_nxt = load_desc(ctab, c0 + 1, c1);   // past c1: an empty chunk
+  uint4 d_nn = load_desc(ctab, c0 + 2, c1);
+  uint32_t i2_a, val_cur, i2_b, val_nxt;
+  fetch_meta(d_cur, i2_a, val_cur);
+  fetch_meta(d_nxt, i2_b, val_nxt);
+  request(offsets(d_cur, i2_a, true));
+  stage(true);
+  __builtin_amdgcn_sched_barrier(0);
+  request(offsets(d_nxt, i2_b, (d_nxt.z & kFirstBit) != 0u));
+  uint32_t i2_nn, val_nn;
+  fetch_meta(d_nn, i2_nn, val_nn);
+
+  for (uint32_t c = c0;; ++c) {
+    const int len = (int)(d_cur.z & 0xffu);
     const uint32_t val = val_cur;
-    const uint4 d_nn = load_desc(ctab, c + 2, c1);
-    request(d_nxt, i2_nxt, (d_nxt.z & kFirstBit) != 0u);
-    uint32_t i2_nn, val_nn;
-    fetch_meta(d_nn, i2_nn, val_nn);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -638,45 +651,60 @@ __global__ __launch_bounds__(64) void fast3_forward_kernel(const float* __restri
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ---- 16-byte global stores: four lanes per row; all LDS reads first ----
+    // ---- this lane's pieces of its output row: LDS -> registers ----
+    float4 x[NLO];
+#pragma unroll
+    for (int k = 0; k < NLO; ++k) {
+      const int idx = j_l + 4 * k < D4 ? j_l + 4 * k : D4 - 1;
+      x[k] = *reinterpret_cast<const float4*>(obuf + b_l * C::LDO + 4 * idx);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // the row buffer has been read: the next chunk's G2 rows may land in it
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- G2 rows (and P) of the next chunk: registers -> LDS; then the offsets of the chunk after ----
+    stage((d_nxt.z & kFirstBit) != 0u);
+    const Offs o_nn = offsets(d_nn, i2_nn, (d_nn.z & kFirstBit) != 0u);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- 16-byte global stores, four lanes per row: no load is waited for behind these stores ----
     {
       const bool row_ok = b_l < len;
       const uint32_t row_off = (val & ~kMultiBit) * (uint32_t)(C::D * 4) + 16u * j_l;  // B*D*4 < 2^32: checked on the host
-      float4 x[NLO];
-#pragma unroll
-      for (int k = 0; k < NLO; ++k) {
-        const int idx = j_l + 4 * k < D4 ? j_l + 4 * k : D4 - 1;
-        x[k] = *reinterpret_cast<const float4*>(obuf + b_l * C::LDO + 4 * idx);
-      }
       if (__ballot(row_ok && (val & kMultiBit)) == 0ull) {  // the usual case: every bag of the chunk holds one id
 #pragma unroll
         for (int k = 0; k < NLO; ++k)
           buf_store4(r_out, (row_ok && (D4 % 4 == 0 || j_l + 4 * k < D4)) ? row_off + 64u * k : kOob, x[k]);
-      } else {
-        float* dst = out + (val & ~kMultiBit) * (uint32_t)C::D;
+      } else {  // bags with several ids accumulate with float atomics; the others keep the same seven stores
+        // (buffer atomics fault on an out-of-range offset instead of vanishing, so those sit in a branch)
+        const bool multi = (val & kMultiBit) != 0u;
 #pragma unroll
-        for (int k = 0; k < NLO; ++k) {
-          const int idx = j_l + 4 * k;
-          if (row_ok && (D4 % 4 == 0 || idx < D4)) {
-            if (val & kMultiBit) {
+        for (int k = 0; k < NLO; ++k)
+          buf_store4(r_out, (row_ok && !multi && (D4 % 4 == 0 || j_l + 4 * k < D4)) ? row_off + 64u * k : kOob, x[k]);
+        if (row_ok && multi) {
+          float* dst = out + (val & ~kMultiBit) * (uint32_t)C::D;
+#pragma unroll
+          for (int k = 0; k < NLO; ++k) {
+            const int idx = j_l + 4 * k;
+            if (D4 % 4 == 0 || idx < D4) {
               atomicAdd(dst + 4 * idx + 0, x[k].x);
               atomicAdd(dst + 4 * idx + 1, x[k].y);
               atomicAdd(dst + 4 * idx + 2, x[k].z);
               atomicAdd(dst + 4 * idx + 3, x[k].w);
-            } else {
-              *reinterpret_cast<float4*>(dst + 4 * idx) = x[k];
             }
           }
         }
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    if (c + 1 >= c1) break;
+    // ---- loads of the chunk after next, pairs of the one after that ----
+    request(o_nn);
     d_cur = d_nxt;
     d_nxt = d_nn;
     val_cur = val_nxt;
-    i2_nxt = i2_nn;
     val_nxt = val_nn;
+    d_nn = load_desc(ctab, c + 3, c1);
+    fetch_meta(d_nn, i2_nn, val_nn);
   }
 }
 
