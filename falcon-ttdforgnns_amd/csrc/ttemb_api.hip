@@ -102,6 +102,26 @@ static bool use_fast3(const DevShape& s, int64_t nnz, int64_t B) {
   return path == TTEMB_PATH_FAST3 || fast3_pays(s, nnz);
 }
 
+__global__ void zero_words_kernel(uint32_t* __restrict__ p, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 3 < n && (reinterpret_cast<uintptr_t>(p + i) & 15) == 0) {
+      *reinterpret_cast<uint4*>(p + i) = make_uint4(0u, 0u, 0u, 0u);
+    } else {
+      for (size_t j = i; j < n && j < i + 4; ++j) p[j] = 0u;
+    }
+  }
+}
+
+int launch_zero(void* p, size_t bytes, hipStream_t st, const char* what) {
+  if (bytes == 0) return TTEMB_OK;
+  const size_t n = bytes / 4;
+  size_t blocks = (n / 4 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+  hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<uint32_t*>(p), n);
+  return check_hip(hipGetLastError(), what);
+}
+
 // rows whose bag length is not 1 must be zero before the lookups accumulate into them
 __global__ void zero_rows_kernel(const int64_t* __restrict__ offsets, int64_t B, int D,
                                  float* __restrict__ out) {
@@ -233,7 +253,7 @@ static int backward_into(const DevShape& ds, const CorePtrs& cp, const int64_t* 
                                  plan_bytes, st, update);
   if (current_path() == TTEMB_PATH_FAST3) return fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
   for (int t = 0; t < ds.T; ++t) {
-    int rc = check_hip(hipMemsetAsync(dst.c[t], 0, (size_t)ds.p[t] * ds.row_len[t] * 4, st), "memset d_core");
+    int rc = launch_zero(dst.c[t], (size_t)ds.p[t] * ds.row_len[t] * 4, st, "zero d_core");
     if (rc) return rc;
   }
   return launch_backward_generic(ds, cp, indices, rowidx, nnz, nnz_dev, d_output, dst, st);
@@ -330,7 +350,7 @@ static int forward_phase(int phase, const ttemb_shape_t* shape, const float* con
   if (rc) return rc;
   workspace = ws;
   if (offsets == nullptr) {
-    rc = check_hip(hipMemsetAsync(output, 0, (size_t)B * ds.D * 4, st), "memset output");
+    rc = launch_zero(output, (size_t)B * ds.D * 4, st, "zero output");
   } else if (!f3) {
     const int threads = 256;
     hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)((B + threads - 1) / threads)), dim3(threads), 0,
@@ -590,7 +610,7 @@ int ttemb_cache_backward_dense(const int32_t* cache_loc, const int64_t* rowidx, 
   if (C > 0 && !d_cache_weight) return fail(TTEMB_E_BADARG, "null buffer");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (C > 0) {
-    rc = check_hip(hipMemsetAsync(d_cache_weight, 0, (size_t)C * D * 4, st), "memset d_cache_weight");
+    rc = launch_zero(d_cache_weight, (size_t)C * D * 4, st, "zero d_cache_weight");
     if (rc) return rc;
   }
   if (nnz > 0 && !d_output) return fail(TTEMB_E_BADARG, "null buffer");

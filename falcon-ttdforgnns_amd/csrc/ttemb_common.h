@@ -76,6 +76,10 @@ int launch_backward_fast3(const DevShape& s, const CorePtrs& cores, const int64_
                           int64_t ws_bytes, const void* plan, int64_t plan_bytes, hipStream_t st,
                           const FusedUpdate* update = nullptr);
 
+// zero `bytes` (a multiple of 4) at `p` with a kernel on `st`.  Used instead of hipMemsetAsync everywhere: inside a
+// captured HIP graph (ROCm 7.2) a memset node was seen to race the kernel node that follows it.
+int launch_zero(void* p, size_t bytes, hipStream_t st, const char* what);
+
 // ---------------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------------

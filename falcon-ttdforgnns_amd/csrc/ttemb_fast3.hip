@@ -1470,7 +1470,7 @@ static int group_ids(const DevShape& s, const CorePtrs& cores, const int64_t* in
   const uint32_t per_slice = (uint32_t)((nnz + slices - 1) / slices);
   const size_t span = (size_t)1 << shift;
   if (ranges > kMaxRanges || span * 16 > 64 * 1024) return fail(TTEMB_E_UNSUPPORTED, "too many (i0, i1) groups for the grouping pass");
-  int rc = check_hip(hipMemsetAsync(plan->rcount, 0, (size_t)align256(ranges * 4), st), "memset range counters");
+  int rc = launch_zero(plan->rcount, (size_t)ranges * 4, st, "zero range counters");   // never hipMemsetAsync: see launch_zero
   if (rc) return rc;
   hipLaunchKernelGGL(fast3_decode_kernel, dim3((unsigned)slices), dim3(kSortThreads), 0, st, indices, rowidx, offsets,
                      (uint32_t)nnz, per_slice, nnz_dev, B, s.D, zero_out, sentinel, (uint32_t)s.p[0], (uint32_t)s.p[1],
@@ -1609,7 +1609,7 @@ int launch_backward_fast3(const DevShape& s, const CorePtrs& cores, const int64_
   // every core gradient is written whole by the finalize kernel (an empty call in a fused mode is a no-op)
   for (int t = 0; t < s.T; ++t) {
     if (nnz > 0 || update != nullptr) continue;
-    int rc = check_hip(hipMemsetAsync(d_cores.c[t], 0, (size_t)s.p[t] * s.row_len[t] * 4, st), "memset d_core");
+    int rc = launch_zero(d_cores.c[t], (size_t)s.p[t] * s.row_len[t] * 4, st, "zero d_core");
     if (rc) return rc;
   }
   if (nnz <= 0) return TTEMB_OK;

@@ -171,3 +171,48 @@ def test_state_dict_interchange_and_cache_survives_reload(ops):
     emb4 = ops.TTEmbeddingBag(N_NODES, D, R, P, Q, **kw)
     emb4.load_state_dict(emb3.state_dict())
     assert emb4.warmup
+
+
+@pytest.mark.parametrize("n", [2048, 16384])
+def test_training_step_replays_from_a_hip_graph(ops, n):
+    """The library only enqueues on the caller's stream (no sync, no hidden allocation, no memset node), so a whole
+    step -- forward, backward, fused SGD -- can be captured once and replayed; 2 048 ids take the wave-per-id kernels,
+    16 384 the grouped MFMA path.  Replays must leave the cores where the same number of eager steps leaves them."""
+    torch.manual_seed(4)
+    rng = np.random.default_rng(4)
+    emb = ops.TTEmbeddingBag(2449029, 100, [16, 16], [125, 140, 140], [4, 5, 5], sparse=True, use_cache=False,
+                             weight_dist="normal", learning_rate=0.05)
+    for c in emb.tt_cores:
+        c.data.mul_(300.0)
+    ids = torch.from_numpy(rng.choice(2449029, size=n, replace=False).astype(np.int64)).cuda()
+    offs = torch.arange(n + 1, device="cuda")
+    d_out = (torch.rand(n, 100, device="cuda") - 0.5) * 0.02
+
+    def step():
+        emb(ids, offs).backward(d_out)
+
+    start = [c.detach().clone() for c in emb.tt_cores]
+    for _ in range(4):
+        step()
+    torch.cuda.synchronize()
+    want = [c.detach().clone() for c in emb.tt_cores]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):      # warm-up on a side stream, as torch.cuda.graphs asks for
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    for c, s0 in zip(emb.tt_cores, start):
+        c.data.copy_(s0)
+    for _ in range(4):
+        graph.replay()
+    torch.cuda.synchronize()
+    for c, w in zip(emb.tt_cores, want):
+        assert torch.isfinite(c).all()
+        assert (c.detach() - w).abs().max().item() <= 1e-5 + 1e-4 * w.abs().max().item()
+    for _ in range(100):               # back-to-back replays (this is what exposed the memset-node race)
+        graph.replay()
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(c).all() for c in emb.tt_cores)
