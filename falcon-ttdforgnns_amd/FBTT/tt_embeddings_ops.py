@@ -207,8 +207,9 @@ class TTLookupFunction(torch.autograd.Function):
                 *tt_cores: torch.Tensor) -> torch.Tensor:
         ctx.module, ctx.table, ctx.B = module, table, B
         ctx.live_cache = cache_loc is not None
-        ctx.save_for_backward(indices, rowidx, nnz_dev, cache_loc, offsets)
-        cores = _nat.core_views(tt_cores, table)
+        # integer inputs, never differentiated: kept on ctx directly (save_for_backward costs version bookkeeping)
+        ctx.inputs = (indices, rowidx, nnz_dev, cache_loc, offsets)
+        cores = _nat.core_ptrs(tt_cores, table)
         nnz = indices.numel()
         out = torch.empty((B, module.embedding_dim), dtype=torch.float32, device=indices.device)
         # the forward's grouping of the ids is kept for the backward of this very call
@@ -232,10 +233,11 @@ class TTLookupFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_output: torch.Tensor):
         m, table, B = ctx.module, ctx.table, ctx.B
-        indices, rowidx, nnz_dev, cache_loc, offsets = ctx.saved_tensors
+        indices, rowidx, nnz_dev, cache_loc, offsets = ctx.inputs
         nnz = indices.numel()
-        d_output = d_output.contiguous().float()
-        cores = _nat.core_views(m.tt_cores, table)
+        if d_output.dtype != torch.float32 or not d_output.is_contiguous():
+            d_output = d_output.contiguous().float()
+        cores = _nat.core_ptrs(m.tt_cores, table)
         n_fixed = 9
         if m.sparse:
             if m.optimizer in _SGD_LIKE:
@@ -245,16 +247,23 @@ class TTLookupFunction(torch.autograd.Function):
                     _nat.cache_backward_sgd(cache_loc, rowidx, 0, nnz_dev, nnz, d_output,
                                             float(m.learning_rate), m.cache_weight.data)
             else:
-                state = _nat.core_views(list(m.optimizer_state), table)
+                state = _nat.core_ptrs(list(m.optimizer_state), table)
                 _nat.backward_adagrad(m._shape, cores, state, indices, rowidx, nnz, nnz_dev, B, d_output,
                                       float(m.learning_rate), float(m.eps), m._ws, ctx.plan, offsets)
                 if ctx.live_cache and nnz > 0:
                     _nat.cache_backward_rowwise_adagrad(cache_loc, rowidx, 0, nnz_dev, nnz, d_output,
                                                         float(m.learning_rate), float(m.eps),
                                                         m.cache_optimizer_state, m.cache_weight.data)
-            return (None,) * (n_fixed + len(cores))
-        # a data-parallel wrapper may have provided one flat bucket for the gradients (ttemb_dist)
-        grads = getattr(m, "_dense_grad_out", None) or [torch.empty_like(c) for c in cores]
+            return (None,) * (n_fixed + len(m.tt_cores))
+        # a data-parallel wrapper may have provided one flat bucket for the gradients (ttemb_dist): they are then
+        # produced straight into it and nothing is handed back to autograd (no AccumulateGrad, no views)
+        bucket = getattr(m, "_dense_grad_out", None)
+        if bucket is not None and not ctx.live_cache:
+            _nat.backward_dense(m._shape, cores, indices, rowidx, nnz, nnz_dev, B, d_output, bucket, m._ws, ctx.plan,
+                                offsets)
+            m._bucket_filled = True
+            return (None,) * (n_fixed + len(m.tt_cores))
+        grads = bucket or [torch.empty_like(c[table] if c.dim() == 3 else c) for c in m.tt_cores]
         _nat.backward_dense(m._shape, cores, indices, rowidx, nnz, nnz_dev, B, d_output, grads, m._ws, ctx.plan,
                             offsets)
         d_cache = None
@@ -355,6 +364,7 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         self.warmup = True
         self._dense_grad_out = None
         self._before_weights = None   # set by ttemb_dist.TTDataParallel while an update of the cores is pending
+        self._bucket_filled = False   # set by the backward when it wrote the core gradients into the wrapper's bucket
         self._shape = _nat.make_shape(self.tt_p_shapes, self.tt_q_shapes, self.tt_ranks)
         self._ws = _nat.Workspace()
         self.register_load_state_dict_post_hook(TableBatchedTTEmbeddingBag._after_load)
@@ -462,6 +472,10 @@ class TTEmbeddingBag(TableBatchedTTEmbeddingBag):
         # [1, B, D] view: selecting table 0 would cost a zero-fill + copy of B*D floats in backward
         if not indices.is_cuda:
             raise RuntimeError("TTEmbeddingBag.forward needs tensors on a ROCm device; there is no CPU fallback")
-        indices, offsets = indices.long().contiguous(), offsets.long().contiguous()
-        self.update_cache(indices)
+        if indices.dtype != torch.int64 or not indices.is_contiguous():
+            indices = indices.long().contiguous()
+        if offsets.dtype != torch.int64 or not offsets.is_contiguous():
+            offsets = offsets.long().contiguous()
+        if self.use_cache:
+            self.update_cache(indices)
         return self._lookup_one_table(0, offsets.numel() - 1, indices, offsets)

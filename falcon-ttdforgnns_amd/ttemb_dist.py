@@ -104,16 +104,20 @@ class TTDataParallel:
         the collective then runs under ~45 us of kernels that do not depend on it.  ``flush()`` (called by the
         next forward, or by hand before reading the weights) finishes a deferred step.
         """
-        self.flush()
+        if self._pending is not None:
+            self.flush()
         lr = float(self.module.learning_rate if lr is None else lr)
         b = self.bucket
-        for v, p in zip(b.views, b.params):  # gradients that did not land in the bucket are packed
-            if p.grad is None:
-                v.zero_()
-            elif p.grad.data_ptr() != v.data_ptr():
-                v.copy_(p.grad)
-        for p in b.params:
-            p.grad = None
+        if getattr(self.module, "_bucket_filled", False) and len(b.params) == self.n_cores:
+            self.module._bucket_filled = False   # the backward wrote every core gradient straight into the bucket
+        else:
+            for v, p in zip(b.views, b.params):  # gradients that did not land in the bucket are packed
+                if p.grad is None:
+                    v.zero_()
+                elif p.grad.data_ptr() != v.data_ptr():
+                    v.copy_(p.grad)
+            for p in b.params:
+                p.grad = None
         work = None
         if self.world > 1:
             work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=overlap)

@@ -117,7 +117,9 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return t.data_ptr() if t.numel() > 0 else None
 
 
-def _ptr_array(ts: Sequence[torch.Tensor]):
+def _ptr_array(ts):
+    if isinstance(ts, ctypes.Array):   # already a pointer array (core_ptrs)
+        return ts
     arr = (ctypes.c_void_p * MAX_CORES)()
     for i, t in enumerate(ts):
         if t.dtype != torch.float32:
@@ -164,8 +166,12 @@ class Workspace:
         return self.buf
 
 
+_size_cache: dict = {}   # (kind, shape bytes, op, nnz, B) -> bytes; emptied when the kernel family changes
+
+
 def set_path(path: int) -> None:
     _check(LIB.ttemb_set_path(path))
+    _size_cache.clear()
 
 
 def profile_enable(on: bool) -> None:
@@ -179,18 +185,37 @@ def profile_read(which: int) -> float:
     return float(ms.value)
 
 
+def _shape_key(shape: Optional[Shape]):
+    if shape is None:
+        return None
+    k = getattr(shape, "_key", None)
+    if k is None:
+        k = shape._key = bytes(shape)
+    return k
+
+
 def workspace_bytes(shape: Optional[Shape], op: int, nnz: int, B: int) -> int:
-    n = LIB.ttemb_workspace_bytes(ctypes.byref(shape) if shape is not None else None, op, nnz, B)
-    if n < 0:
-        _check(int(n))
-    return int(n)
+    key = ("w", _shape_key(shape), op, nnz, B)
+    n = _size_cache.get(key)
+    if n is None:
+        n = LIB.ttemb_workspace_bytes(ctypes.byref(shape) if shape is not None else None, op, nnz, B)
+        if n < 0:
+            _check(int(n))
+        n = _size_cache[key] = int(n)
+        if len(_size_cache) > 4096:
+            _size_cache.clear()
+    return n
 
 
 def plan_bytes(shape: Shape, nnz: int) -> int:
-    n = LIB.ttemb_plan_bytes(ctypes.byref(shape), nnz)
-    if n < 0:
-        _check(int(n))
-    return int(n)
+    key = ("p", _shape_key(shape), nnz)
+    n = _size_cache.get(key)
+    if n is None:
+        n = LIB.ttemb_plan_bytes(ctypes.byref(shape), nnz)
+        if n < 0:
+            _check(int(n))
+        n = _size_cache[key] = int(n)
+    return n
 
 
 def new_plan(shape: Shape, nnz: int, device: torch.device) -> Optional[torch.Tensor]:
@@ -325,6 +350,17 @@ def cache_backward_rowwise_adagrad(cache_loc, rowidx, start: int, start_dev, nnz
                                                         nnz, _ptr(d_output), cache_weight.shape[1], lr, eps,
                                                         _ptr(state_sum), _ptr(cache_weight),
                                                         _stream(d_output)))
+
+
+def core_ptrs(tt_cores: Sequence[torch.Tensor], table: int = 0):
+    """Pointer array of the per-table [p_t, row] slices of [num_tables, p_t, row] parameters: what core_views gives,
+    without creating view tensors (this sits on the host path of every step)."""
+    arr = (ctypes.c_void_p * MAX_CORES)()
+    for i, c in enumerate(tt_cores):
+        if c.dtype != torch.float32 or not c.is_cuda or not c.is_contiguous():
+            raise RuntimeError("tt_cores must be contiguous float32 tensors on a ROCm device (no CPU fallback)")
+        arr[i] = c.data_ptr() + (table * c.stride(0) * 4 if c.dim() == 3 and table else 0)
+    return arr
 
 
 def core_views(tt_cores: Sequence[torch.Tensor], table: int = 0) -> List[torch.Tensor]:

@@ -11,18 +11,32 @@ for p in (ROOT, os.path.join(ROOT, "falcon-ttdforgnns_amd")):
 import torch
 from FBTT.tt_embeddings_ops import TTEmbeddingBag
 
-emb = TTEmbeddingBag(2449029, 100, [16, 16], [125, 140, 140], [4, 5, 5], sparse=True, use_cache=False,
+mode = sys.argv[1] if len(sys.argv) > 1 else "sparse"       # sparse | dp (data-parallel path at world 1)
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
+emb = TTEmbeddingBag(2449029, 100, [16, 16], [125, 140, 140], [4, 5, 5], sparse=(mode == "sparse"), use_cache=False,
                      weight_dist="normal", learning_rate=0.01)
-ids = torch.randperm(2449029)[:2048].cuda()
-offs = torch.arange(2049).cuda()
-d = torch.rand(2048, 100, device="cuda")
-for _ in range(50):
+dp = None
+if mode != "sparse":
+    from ttemb_dist import TTDataParallel
+    dp = TTDataParallel(emb)
+ids = torch.randperm(2449029)[:n].cuda()
+offs = torch.arange(n + 1).cuda()
+d = torch.rand(n, 100, device="cuda")
+
+
+def step():
     emb(ids, offs).backward(d)
+    if dp is not None:
+        dp.step(overlap=True)
+
+
+for _ in range(50):
+    step()
 torch.cuda.synchronize()
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(500):
-    emb(ids, offs).backward(d)
+    step()
 torch.cuda.synchronize()
 pr.disable()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
