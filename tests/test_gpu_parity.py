@@ -326,3 +326,45 @@ def test_full_size_properties_products(nat, orc, path):
     fd = float(((plus.astype(np.float64) - minus) * d1).sum() / (2 * eps))
     an = float(sum((g.astype(np.float64) * d).sum() for g, d in zip(g1, direction)))
     assert abs(fd - an) <= 2e-3 * max(abs(an), 1.0), (fd, an)
+
+
+@pytest.mark.parametrize("live", [0, 1, 7000])
+def test_fast_path_with_a_device_side_live_count(nat, orc, live):
+    """The launch is sized by nnz, the kernels use the device-side count (what ttemb_preprocess leaves behind): only
+    the first `live` ids exist.  0 and 1 are the degenerate ends (no chunk at all / one chunk of one id); rows are
+    derived from `offsets` (rowidx NULL) and the two-phase forward (group, then lookup) must give the same."""
+    p, q, R, n_emb = CONFIGS["products"]
+    set_path(nat, "fast3", q, R)
+    rng = np.random.default_rng(3 + live)
+    cores = [(rng.standard_normal((p[t], R[t] * q[t] * R[t + 1])) * 0.3).astype(np.float32) for t in range(3)]
+    N = 9000
+    idx = rng.integers(0, n_emb, size=N).astype(np.int64)
+    offsets = np.arange(N + 1, dtype=np.int64)
+    shape = nat.make_shape(p, q, R)
+    ws = nat.Workspace()
+    c = [dev(x) for x in cores]
+    d_idx, d_offs = dev(idx, torch.int64), dev(offsets, torch.int64)
+    cnt = torch.tensor([live], dtype=torch.int32, device="cuda")
+    want = np.zeros((N, 100), dtype=np.float32)
+    want[:live] = orc.tt_rows(idx[:live], cores, p, q, R) if live else 0.0
+    outs = []
+    for two_phase in (False, True):
+        out = torch.full((N, 100), float("nan"), device="cuda")
+        plan = nat.new_plan(shape, N, out.device)
+        if two_phase:
+            nat.forward(shape, c, d_idx, None, d_offs, N, cnt, N, out, ws, plan, phase=1)
+            nat.forward(shape, c, d_idx, None, d_offs, N, cnt, N, out, ws, plan, phase=2)
+        else:
+            nat.forward(shape, c, d_idx, None, d_offs, N, cnt, N, out, ws, plan)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        # bags of one id are written by exactly one writer: this call for live ids, ttemb_cache_forward for the rest
+        np.testing.assert_allclose(got[:live], want[:live], rtol=1e-5, atol=1e-4)
+        outs.append(got[:live])
+        d_out = ((rng.random((N, 100)) - 0.5) * 0.1).astype(np.float32)
+        grads = [torch.full_like(x, float("nan")) for x in c]
+        nat.backward_dense(shape, c, d_idx, None, N, cnt, N, dev(d_out), grads, ws, plan, d_offs)
+        torch.cuda.synchronize()
+        ref = orc.tt_dense_backward(idx[:live], np.arange(live + 1), d_out[:live], cores, p, q, R)
+        assert_grads_close([g.cpu().numpy() for g in grads], ref, rel=2e-4)
+    assert np.array_equal(outs[0], outs[1])
