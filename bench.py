@@ -154,6 +154,13 @@ def main():
                     traffic = json.load(fh)["kernels"][dom_name]["hbm_bytes"]
         except (OSError, KeyError, ValueError):
             traffic = None
+        mfma_busy = None   # MFMA-pipe busy fraction of that kernel from the committed PMC pass (tools/mfma_util.sh)
+        try:
+            if N == 409600 and args.path == "auto":
+                with open(os.path.join(ROOT, "profiles", "r01_mfma_util.json")) as fh:
+                    mfma_busy = json.load(fh)["kernels"][dom_name]["mfma_util"]
+        except (OSError, KeyError, ValueError):
+            mfma_busy = None
         tf = lambda flops, ms: N * flops / (ms * 1e-3) / 1e12
         roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1),
                     "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -161,6 +168,7 @@ def main():
                     "kernel_ms": round(dom_ms, 4), "algorithmic_bytes_per_lookup": row_bytes,
                     "kernel_flops_per_lookup": dom_flops,
                     "kernel_mfma_frac": round(tf(dom_flops, dom_ms) / PEAK_F32_MFMA_TFLOPS, 4),
+                    "kernel_mfma_busy_pmc": mfma_busy,
                     "traffic_gbs": None if traffic is None else round(traffic / (dom_ms * 1e-3) / 1e9, 1),
                     "fwd_kernel_ms": round(fwd, 4), "bwd_chunk_kernel_ms": round(chunk, 4),
                     "bwd_chain_ms": round(bwd, 4), "grouping_ms": round(group, 4),
@@ -169,6 +177,9 @@ def main():
                     "fwd_chain_mfma_frac": round(tf(FWD_FLOPS, fwd + group) / PEAK_F32_MFMA_TFLOPS, 4),
                     "bwd_chain_nominal_tflops": round(tf(BWD_FLOPS, bwd), 3),
                     "bwd_chain_mfma_frac": round(tf(BWD_FLOPS, bwd) / PEAK_F32_MFMA_TFLOPS, 4),
+                    # the whole chain contraction, forward + backward, charged with the grouping pass as well
+                    "chain_nominal_tflops": round(tf(FWD_FLOPS + BWD_FLOPS, fwd + group + bwd), 3),
+                    "chain_mfma_frac": round(tf(FWD_FLOPS + BWD_FLOPS, fwd + group + bwd) / PEAK_F32_MFMA_TFLOPS, 4),
                     "fwd_row_store_gbs": round(N * row_bytes / (fwd * 1e-3) / 1e9, 1),
                     "peak_f32_mfma_tflops": PEAK_F32_MFMA_TFLOPS}
         # latency regime of the metric's "batch 2048": 2048 unique ids per step (sparse batch -> generic
