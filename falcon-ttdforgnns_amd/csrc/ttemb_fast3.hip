@@ -78,6 +78,7 @@ struct Cfg {
   static_assert(R1 % 4 == 0 && R2 % 4 == 0, "ranks must be multiples of the MFMA K");
   static_assert(N1 % 16 == 0, "q1*r2 must tile by 16");
   static_assert(D % 4 == 0 && ROW2 % 4 == 0, "rows move as float4");
+  static_assert(ROW2 <= 256, "the dG2 reduce reads one E row per wavefront load");
 };
 
 // ---------------------------------------------------------------------------------
@@ -1312,21 +1313,32 @@ __global__ __launch_bounds__(256) void fast3_finalize_kernel(GroupPlan plan, int
 // ---------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------
-enum Fast3Kind { kNone = 0, kProducts, kArxiv, kPapers };
+// The (q, ranks) shapes with an instantiated chain: the three BASELINE.json configurations first, then the other
+// 3-core shapes the reference's run scripts train with (q = 4,4,8 / 4,5,5 / 8,4,4 at rank 16; the rank sweep of
+// the products shape).  q0 has to divide the MFMA tile height, so q = 5,5,4 and 5,4,5 stay on the generic path.
+#define TTEMB_FAST3_SHAPES(X) \
+  X(4, 5, 5, 16, 16)          \
+  X(4, 4, 8, 8, 8)            \
+  X(8, 4, 4, 32, 32)          \
+  X(4, 4, 8, 16, 16)          \
+  X(8, 4, 4, 16, 16)          \
+  X(4, 5, 5, 32, 32)          \
+  X(4, 4, 8, 32, 32)
 
-static Fast3Kind classify(const DevShape& s) {
-  if (s.T != 3) return kNone;
-  if ((long long)s.L[0] * s.p[0] >= 0x7fffffffll) return kNone;  // ids must fit the uint32 sort key
-  auto is = [&](int q0, int q1, int q2, int r1, int r2) {
-    return s.q[0] == q0 && s.q[1] == q1 && s.q[2] == q2 && s.R[1] == r1 && s.R[2] == r2;
-  };
-  if (is(4, 5, 5, 16, 16)) return kProducts;
-  if (is(4, 4, 8, 8, 8)) return kArxiv;
-  if (is(8, 4, 4, 32, 32)) return kPapers;
-  return kNone;
+static bool shape_is(const DevShape& s, int q0, int q1, int q2, int r1, int r2) {
+  return s.q[0] == q0 && s.q[1] == q1 && s.q[2] == q2 && s.R[1] == r1 && s.R[2] == r2;
 }
 
-bool fast3_supported(const DevShape& s) { return classify(s) != kNone; }
+static bool classify(const DevShape& s) {
+  if (s.T != 3) return false;
+  if ((long long)s.L[0] * s.p[0] >= 0x7fffffffll) return false;  // ids must fit the uint32 sort key
+#define TTEMB_X(a, b, c, d, e) if (shape_is(s, a, b, c, d, e)) return true;
+  TTEMB_FAST3_SHAPES(TTEMB_X)
+#undef TTEMB_X
+  return false;
+}
+
+bool fast3_supported(const DevShape& s) { return classify(s); }
 
 static int64_t num_groups(const DevShape& s) { return (int64_t)s.p[0] * s.p[1]; }
 
@@ -1350,11 +1362,12 @@ bool fast3_pays(const DevShape& s, int64_t nnz) {
   return nnz >= (by_groups > 4096 ? by_groups : 4096);
 }
 
-// the chain kernels address every table through 32-bit byte offsets (buffer descriptors): 4 GiB each
+// the chain kernels address every table through 32-bit byte offsets (buffer descriptors): 4 GiB each; the dG2
+// reduce keeps two counters per i2 in LDS (p2 <= 4096: 36 KB); p1 is a grid.y extent
 bool fast3_fits(const DevShape& s, int64_t nnz, int64_t B) {
   const int64_t lim = int64_t(1) << 32;
   return B * s.D * 4 < lim && nnz * (int64_t)s.row_len[2] * 4 < lim &&
-         num_groups(s) * (int64_t)s.q[0] * s.q[1] * s.R[2] * 4 < lim && s.p[2] < 65536;
+         num_groups(s) * (int64_t)s.q[0] * s.q[1] * s.R[2] * 4 < lim && s.p[2] <= 4096 && s.p[1] < 65536;
 }
 
 #ifndef TTEMB_ROWS_B
@@ -1524,12 +1537,12 @@ static int run_prefix_t(const DevShape& s, const CorePtrs& cores, const GroupPla
 }
 
 static int run_prefix(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, hipStream_t st) {
-  switch (classify(s)) {
-    case kProducts: return run_prefix_t<4, 5, 5, 16, 16>(s, cores, plan, st);
-    case kArxiv: return run_prefix_t<4, 4, 8, 8, 8>(s, cores, plan, st);
-    case kPapers: return run_prefix_t<8, 4, 4, 32, 32>(s, cores, plan, st);
-    default: return fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
+  if (classify(s)) {
+#define TTEMB_X(a, b, c, d, e) if (shape_is(s, a, b, c, d, e)) return run_prefix_t<a, b, c, d, e>(s, cores, plan, st);
+    TTEMB_FAST3_SHAPES(TTEMB_X)
+#undef TTEMB_X
   }
+  return fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
 }
 
 static unsigned chunk_waves(const DevShape& s, int64_t nnz, int per_wave) {
@@ -1557,12 +1570,12 @@ int launch_forward_fast3(const DevShape& s, const CorePtrs& cores, const int64_t
   int rc = prepare(s, cores, false, indices, rowidx, offsets, nnz, nnz_dev, B, zero_rows ? output : nullptr, ws, ws_bytes,
                    plan_buf, plan_bytes, phase, &plan, st);   // phase 0 / 1 / 2 = whole forward / ids only / lookup on a grouped plan
   if (rc || phase == 1) return rc;
-  switch (classify(s)) {
-    case kProducts: return run_forward<4, 5, 5, 16, 16>(s, cores, plan, nnz, B, output, st);
-    case kArxiv: return run_forward<4, 4, 8, 8, 8>(s, cores, plan, nnz, B, output, st);
-    case kPapers: return run_forward<8, 4, 4, 32, 32>(s, cores, plan, nnz, B, output, st);
-    default: return fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
+  if (classify(s)) {
+#define TTEMB_X(a, b, c, d, e) if (shape_is(s, a, b, c, d, e)) return run_forward<a, b, c, d, e>(s, cores, plan, nnz, B, output, st);
+    TTEMB_FAST3_SHAPES(TTEMB_X)
+#undef TTEMB_X
   }
+  return fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
 }
 
 template <int Q0, int Q1, int Q2, int R1, int R2>
@@ -1618,12 +1631,12 @@ int launch_backward_fast3(const DevShape& s, const CorePtrs& cores, const int64_
                    const_cast<void*>(plan_buf), plan_bytes,
                    plan_buf != nullptr && plan_bytes >= fast3_plan_bytes(s, nnz) ? 3 : 0, &plan, st);
   if (rc) return rc;
-  switch (classify(s)) {
-    case kProducts: return run_backward<4, 5, 5, 16, 16>(s, cores, plan, nnz, B, d_output, d_cores, upd, st);
-    case kArxiv: return run_backward<4, 4, 8, 8, 8>(s, cores, plan, nnz, B, d_output, d_cores, upd, st);
-    case kPapers: return run_backward<8, 4, 4, 32, 32>(s, cores, plan, nnz, B, d_output, d_cores, upd, st);
-    default: return fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
+  if (classify(s)) {
+#define TTEMB_X(a, b, c, d, e) if (shape_is(s, a, b, c, d, e)) return run_backward<a, b, c, d, e>(s, cores, plan, nnz, B, d_output, d_cores, upd, st);
+    TTEMB_FAST3_SHAPES(TTEMB_X)
+#undef TTEMB_X
   }
+  return fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
 }
 
 }  // namespace ttemb

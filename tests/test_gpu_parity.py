@@ -16,7 +16,9 @@ from conftest import ROW_CASES, TINY_CASES, golden_cores, load_golden, seeded_co
 pytestmark = pytest.mark.gpu
 
 PATHS = ["generic", "auto", "fast3"]
-FAST3_SHAPES = {(4, 5, 5, 16, 16), (4, 4, 8, 8, 8), (8, 4, 4, 32, 32)}  # (q0, q1, q2, r1, r2) of the MFMA path
+# (q0, q1, q2, r1, r2) of the MFMA path: the BASELINE.json shapes, then the other 3-core shapes of the reference's scripts
+FAST3_SHAPES = {(4, 5, 5, 16, 16), (4, 4, 8, 8, 8), (8, 4, 4, 32, 32), (4, 4, 8, 16, 16), (8, 4, 4, 16, 16),
+                (4, 5, 5, 32, 32), (4, 4, 8, 32, 32)}
 
 
 @pytest.fixture(scope="module")
@@ -288,6 +290,38 @@ def test_fast_path_huge_groups_and_bags(nat, orc, p, q, R):
     out, _ = run_forward(nat, p, q, R, cores, idx, offsets)
     want = orc.tt_forward(idx, offsets, cores, p, q, R)
     np.testing.assert_allclose(out, want, rtol=1e-4, atol=1e-4 * float(np.abs(want).max()))
+    d_out = ((rng.random((B, D)) - 0.5) * 0.1).astype(np.float32)
+    grads = run_backward_dense(nat, p, q, R, cores, idx, offsets, d_out)
+    assert_grads_close(grads, orc.tt_dense_backward(idx, offsets, d_out, cores, p, q, R), rel=2e-4)
+
+
+@pytest.mark.parametrize("p,q,R,n_ids", [
+    ([125, 140, 140], [4, 4, 8], [1, 16, 16, 1], 40000),   # run_ogbn-arxiv scripts: D = 128 at rank 16
+    ([40, 30, 50], [8, 4, 4], [1, 16, 16, 1], 30000),
+    ([30, 20, 40], [4, 5, 5], [1, 32, 32, 1], 30000),
+    ([25, 30, 35], [4, 4, 8], [1, 32, 32, 1], 30000),
+    ([7, 300, 900], [4, 4, 8], [1, 16, 16, 1], 20000),      # p2 near the reduce kernel's bucket limit
+])
+def test_fast_path_script_shapes(nat, orc, p, q, R, n_ids):
+    """The other (q, rank) shapes the reference's run scripts train with, on the grouped MFMA path: uniform ids plus
+    dense windows, duplicates, multi-id and empty bags, against the oracle."""
+    set_path(nat, "fast3", q, R)
+    n_emb = int(np.prod(p))
+    rng = np.random.default_rng(17 + p[0] + R[1])
+    cores = [(rng.standard_normal((p[t], R[t] * q[t] * R[t + 1])) * 0.3).astype(np.float32) for t in range(3)]
+    starts = rng.integers(0, n_emb - 300, size=100)
+    local = (starts[:, None] + rng.integers(0, 300, size=(100, n_ids // 200))).reshape(-1)
+    idx = np.concatenate([local, rng.integers(0, n_emb, size=n_ids - local.shape[0])]).astype(np.int64)
+    idx[:500] = idx[500:1000]
+    rng.shuffle(idx)
+    lens = rng.integers(0, 4, size=n_ids)
+    lens = lens[np.cumsum(lens) <= n_ids]
+    idx = idx[: int(lens.sum())]
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    B, D = offsets.shape[0] - 1, int(np.prod(q))
+    out, _ = run_forward(nat, p, q, R, cores, idx, offsets)
+    want = orc.tt_forward(idx, offsets, cores, p, q, R)
+    np.testing.assert_allclose(out, want, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(want).max())))
     d_out = ((rng.random((B, D)) - 0.5) * 0.1).astype(np.float32)
     grads = run_backward_dense(nat, p, q, R, cores, idx, offsets, d_out)
     assert_grads_close(grads, orc.tt_dense_backward(idx, offsets, d_out, cores, p, q, R), rel=2e-4)

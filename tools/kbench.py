@@ -14,7 +14,11 @@ import ttemb_native as nat
 
 CFG = {"products": ([125, 140, 140], [4, 5, 5], [1, 16, 16, 1], 2449029),
        "arxiv": ([56, 60, 51], [4, 4, 8], [1, 8, 8, 1], 169343),
-       "papers": ([500, 560, 400], [8, 4, 4], [1, 32, 32, 1], 111059956)}
+       "papers": ([500, 560, 400], [8, 4, 4], [1, 32, 32, 1], 111059956),
+       # the reference's run scripts: ogbn-arxiv / D = 128 at rank 16 on the products factorisation
+       "arxiv_r16": ([125, 140, 140], [4, 4, 8], [1, 16, 16, 1], 2449029),
+       "q844_r16": ([125, 140, 140], [8, 4, 4], [1, 16, 16, 1], 2449029),
+       "products_r32": ([125, 140, 140], [4, 5, 5], [1, 32, 32, 1], 2449029)}
 
 
 def main():
