@@ -376,18 +376,18 @@ __global__ __launch_bounds__(kRangeThreads) void fast3_count_kernel(uint32_t G, 
   if (threadIdx.x == 0) plan.rtot[blockIdx.x] = carry;
 }
 
-__global__ __launch_bounds__(kRangeThreads) void fast3_place_kernel(uint32_t nnz, uint32_t G, uint32_t shift, GroupPlan plan) {
-  extern __shared__ uint32_t lds_s[];   // [span] cursor | [span] first position | [span] count | [span] first chunk
-  __shared__ uint64_t range_base;
+__device__ __forceinline__ void place_range(const uint32_t range, const uint32_t ranges, uint32_t G, uint32_t shift,
+                                            const GroupPlan& plan, uint32_t* lds_s, uint64_t& range_base) {
+  // lds_s: [span] cursor | [span] first position | [span] count | [span] first chunk
   const uint32_t span = 1u << shift;
-  const uint32_t g0 = blockIdx.x << shift;
+  const uint32_t g0 = range << shift;
   uint32_t* cursor = lds_s;
   uint32_t* gfirst = cursor + span;
   uint32_t* gcount = gfirst + span;
   uint32_t* gchunk = gcount + span;
   if (threadIdx.x < kWave) {   // (ids, chunks) of the ranges before this one
     uint64_t v = 0;
-    for (uint32_t r = threadIdx.x; r < blockIdx.x; r += kWave) v += plan.rtot[r];
+    for (uint32_t r = threadIdx.x; r < range; r += kWave) v += plan.rtot[r];
 #pragma unroll
     for (int d = kWave / 2; d > 0; d >>= 1) {
       const uint32_t lo_w = __shfl_down((uint32_t)v, d, kWave), hi_w = __shfl_down((uint32_t)(v >> 32), d, kWave);
@@ -407,9 +407,9 @@ __global__ __launch_bounds__(kRangeThreads) void fast3_place_kernel(uint32_t nnz
       plan.gpre[g] = pre;
     }
   }
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) plan.gpre[G] = base + plan.rtot[blockIdx.x];   // (live ids, chunks)
+  if (range == ranges - 1 && threadIdx.x == 0) plan.gpre[G] = base + plan.rtot[range];   // (live ids, chunks)
   __syncthreads();
-  const uint32_t n0 = plan.rstart[blockIdx.x], n1 = plan.rstart[blockIdx.x + 1];
+  const uint32_t n0 = plan.rstart[range], n1 = plan.rstart[range + 1];
   for (uint32_t b0 = n0 + threadIdx.x; b0 < n1; b0 += kRangeThreads * kSortBatch) {
     uint32_t gl[kSortBatch], i2v[kSortBatch], vv[kSortBatch];   // all loads of the batch first
 #pragma unroll
@@ -438,6 +438,12 @@ __global__ __launch_bounds__(kRangeThreads) void fast3_place_kernel(uint32_t nnz
   }
 }
 
+__global__ __launch_bounds__(kRangeThreads) void fast3_place_kernel(uint32_t nnz, uint32_t G, uint32_t shift, GroupPlan plan) {
+  extern __shared__ uint32_t lds_s[];
+  __shared__ uint64_t range_base;
+  place_range(blockIdx.x, gridDim.x, G, shift, plan, lds_s, range_base);
+}
+
 // ---------------------------------------------------------------------------------
 // Prefix products: P[g] = G0[i0] . G1[i1]  (q0 x q1 r2, kept as a (q0 q1) x r2 matrix) for every
 // non-empty group, once per call, into a table the chain kernels read like any other operand.
@@ -451,14 +457,13 @@ __global__ __launch_bounds__(kRangeThreads) void fast3_place_kernel(uint32_t nnz
 #endif
 constexpr int kPrefixGroups = TTEMB_PREFIX_GROUPS;   // values of i0 per wavefront
 template <int Q0, int Q1, int Q2, int R1, int R2>
-__global__ __launch_bounds__(64) void fast3_prefix_kernel(const float* __restrict__ G0, const float* __restrict__ G1,
-                                                          uint32_t p0, GroupPlan plan) {
+__device__ __forceinline__ void prefix_unit(const float* __restrict__ G0, const float* __restrict__ G1, uint32_t p0,
+                                            const GroupPlan& plan, uint32_t i0_block, uint32_t i1, int lane) {
   using C = Cfg<Q0, Q1, Q2, R1, R2>;
   constexpr int GM = 16 / Q0;  // groups per MFMA tile
   static_assert(16 % Q0 == 0, "q0 must divide the MFMA tile height");
-  const int lane = threadIdx.x, hi = lane >> 4, lo = lane & 15;
-  const uint32_t i1 = blockIdx.y;
-  const uint32_t i0_begin = blockIdx.x * kPrefixGroups;
+  const int hi = lane >> 4, lo = lane & 15;
+  const uint32_t i0_begin = i0_block * kPrefixGroups;
   const uint32_t i0_end = i0_begin + kPrefixGroups < p0 ? i0_begin + kPrefixGroups : p0;
   // any work at all?  (one lane per i0 of the slice)
   const uint32_t my = i0_begin + lane;
@@ -500,6 +505,32 @@ __global__ __launch_bounds__(64) void fast3_prefix_kernel(const float* __restric
       }
     }
   }
+}
+
+template <int Q0, int Q1, int Q2, int R1, int R2>
+__global__ __launch_bounds__(64) void fast3_prefix_kernel(const float* __restrict__ G0, const float* __restrict__ G1,
+                                                          uint32_t p0, GroupPlan plan) {
+  prefix_unit<Q0, Q1, Q2, R1, R2>(G0, G1, p0, plan, blockIdx.x, blockIdx.y, (int)threadIdx.x);
+}
+
+// The last grouping step and the prefix products in one launch (both only need the group counts): workgroups
+// [0, ranges) place their range, the rest take kRangeThreads / 64 prefix units each -- two latency-bound kernels
+// share the machine instead of queueing.
+template <int Q0, int Q1, int Q2, int R1, int R2>
+__global__ __launch_bounds__(kRangeThreads) void fast3_place_prefix_kernel(uint32_t ranges, uint32_t G, uint32_t shift,
+                                                                          const float* __restrict__ G0,
+                                                                          const float* __restrict__ G1, uint32_t p0,
+                                                                          uint32_t p1, GroupPlan plan) {
+  extern __shared__ uint32_t lds_s[];
+  __shared__ uint64_t range_base;
+  if (blockIdx.x < ranges) {
+    place_range(blockIdx.x, ranges, G, shift, plan, lds_s, range_base);
+    return;
+  }
+  const uint32_t blocks0 = (p0 + kPrefixGroups - 1) / kPrefixGroups;
+  const uint32_t unit = (blockIdx.x - ranges) * (kRangeThreads / kWave) + (threadIdx.x >> 6);
+  if (unit >= blocks0 * p1) return;
+  prefix_unit<Q0, Q1, Q2, R1, R2>(G0, G1, p0, plan, unit % blocks0, unit / blocks0, (int)(threadIdx.x & 63));
 }
 
 // ---------------------------------------------------------------------------------
@@ -1473,10 +1504,11 @@ int64_t fast3_workspace_bytes(const DevShape& s, int32_t op, int64_t nnz, int64_
 
 // fill plan->{i2s, vals, counts, gpre, ctab} from the ids
 static int run_prefix(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, hipStream_t st);
+static int run_place_prefix(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int ranges, int shift, hipStream_t st);
 
 static int group_ids(const DevShape& s, const CorePtrs& cores, const int64_t* indices, const int64_t* rowidx,
                      const int64_t* offsets, int64_t nnz, const int32_t* nnz_dev, int64_t B, float* zero_out,
-                     GroupPlan* plan, hipStream_t st) {
+                     bool with_prefix, GroupPlan* plan, hipStream_t st) {
   const int64_t G = num_groups(s);
   const uint32_t sentinel = (uint32_t)((unsigned long long)s.L[0] * s.p[0]);
   const int slices = sort_slices(nnz), shift = sort_shift(G), ranges = sort_ranges(G);
@@ -1498,6 +1530,7 @@ static int group_ids(const DevShape& s, const CorePtrs& cores, const int64_t* in
                      *plan);
   rc = check_hip(hipGetLastError(), "fast3_count_kernel");
   if (rc) return rc;
+  if (with_prefix) return run_place_prefix(s, cores, *plan, ranges, shift, st);
   hipLaunchKernelGGL(fast3_place_kernel, dim3((unsigned)ranges), dim3(kRangeThreads), span * 16, st, (uint32_t)nnz, (uint32_t)G,
                      (uint32_t)shift, *plan);
   return check_hip(hipGetLastError(), "fast3_place_kernel");
@@ -1521,8 +1554,9 @@ static int prepare(const DevShape& s, const CorePtrs& cores, bool bwd, const int
   if (plan_state == 3) return TTEMB_OK;
   profile_begin(3, st);
   int rc = TTEMB_OK;
-  if (plan_state <= 1) rc = group_ids(s, cores, indices, rowidx, offsets, nnz, nnz_dev, B, zero_out, plan, st);
-  if (rc == TTEMB_OK && plan_state != 1) rc = run_prefix(s, cores, *plan, st);
+  // building the whole plan: the prefix products ride in the last grouping launch
+  if (plan_state <= 1) rc = group_ids(s, cores, indices, rowidx, offsets, nnz, nnz_dev, B, zero_out, plan_state == 0, plan, st);
+  if (rc == TTEMB_OK && plan_state == 2) rc = run_prefix(s, cores, *plan, st);
   profile_end(3, st);
   return rc;
 }
@@ -1539,6 +1573,26 @@ static int run_prefix_t(const DevShape& s, const CorePtrs& cores, const GroupPla
 static int run_prefix(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, hipStream_t st) {
   if (classify(s)) {
 #define TTEMB_X(a, b, c, d, e) if (shape_is(s, a, b, c, d, e)) return run_prefix_t<a, b, c, d, e>(s, cores, plan, st);
+    TTEMB_FAST3_SHAPES(TTEMB_X)
+#undef TTEMB_X
+  }
+  return fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
+}
+
+template <int Q0, int Q1, int Q2, int R1, int R2>
+static int run_place_prefix_t(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int ranges, int shift,
+                              hipStream_t st) {
+  const unsigned units = (unsigned)((s.p[0] + kPrefixGroups - 1) / kPrefixGroups) * (unsigned)s.p[1];
+  const unsigned per_wg = kRangeThreads / kWave;
+  hipLaunchKernelGGL((fast3_place_prefix_kernel<Q0, Q1, Q2, R1, R2>), dim3((unsigned)ranges + (units + per_wg - 1) / per_wg),
+                     dim3(kRangeThreads), ((size_t)16 << shift), st, (uint32_t)ranges, (uint32_t)num_groups(s), (uint32_t)shift,
+                     cores.c[0], cores.c[1], (uint32_t)s.p[0], (uint32_t)s.p[1], plan);
+  return check_hip(hipGetLastError(), "fast3_place_prefix_kernel");
+}
+
+static int run_place_prefix(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int ranges, int shift, hipStream_t st) {
+  if (classify(s)) {
+#define TTEMB_X(a, b, c, d, e) if (shape_is(s, a, b, c, d, e)) return run_place_prefix_t<a, b, c, d, e>(s, cores, plan, ranges, shift, st);
     TTEMB_FAST3_SHAPES(TTEMB_X)
 #undef TTEMB_X
   }
