@@ -550,6 +550,11 @@ __global__ __launch_bounds__(kRangeThreads) void fast3_place_prefix_kernel(uint3
 #define TTEMB_CPW_BWD 2
 #endif
 constexpr int kCPWF = TTEMB_CPW_FWD, kCPWB = TTEMB_CPW_BWD;   // chunk descriptors per wavefront
+#ifdef TTEMB_NO_ALIGN_ROWS
+constexpr bool kAlignRows = false;
+#else
+constexpr bool kAlignRows = true;   // rows of the caller's [B, D] tensors move as aligned 64-byte blocks
+#endif
 
 template <int Q0, int Q1, int Q2, int R1, int R2>
 __global__ __launch_bounds__(64) void fast3_forward_kernel(const float* __restrict__ G2, GroupPlan plan, uint32_t G,
@@ -570,7 +575,7 @@ __global__ __launch_bounds__(64) void fast3_forward_kernel(const float* __restri
   const uint32_t c1 = c0 + kCPWF < nchunks ? c0 + kCPWF : nchunks;
 
   constexpr int F4G = C::ROW2 / 4, NLG = (F4G + 3) / 4;     // float4 pieces of a G2 row / per lane
-  constexpr int D4 = C::D / 4, NLO = (D4 + 3) / 4;          // float4 pieces of an output row / per lane
+  constexpr int D4 = C::D / 4, NLO = (D4 % 4 == 0 || !kAlignRows) ? (D4 + 3) / 4 : (D4 + 6) / 4;   // float4 pieces of an output row / per lane
   constexpr int PF = C::M2 * R2, PF4 = PF / 4, NLP = (PF4 + kWave - 1) / kWave;
   const desc_ptr ctab = (desc_ptr)plan.ctab;
   const rsrc_t r_i2 = make_rsrc(plan.i2s, nnz * 4u), r_val = make_rsrc(plan.vals, nnz * 4u);
@@ -684,10 +689,15 @@ __global__ __launch_bounds__(64) void fast3_forward_kernel(const float* __restri
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // ---- this lane's pieces of its output row: LDS -> registers ----
+    // Rows of D floats start on a 16-byte slot that is `sh` slots past a 64-byte boundary: the four lanes of an id
+    // take the pieces of one ALIGNED 64-byte block per instruction (piece 4k + j - sh), so a store instruction
+    // never straddles two 64-byte halves of a cache line (D a multiple of 16: sh = 0, nothing changes).
+    const int sh = kAlignRows && D4 % 4 != 0 ? (int)(((val & 3u) * (uint32_t)(D4 & 3)) & 3u) : 0;
     float4 x[NLO];
 #pragma unroll
     for (int k = 0; k < NLO; ++k) {
-      const int idx = j_l + 4 * k < D4 ? j_l + 4 * k : D4 - 1;
+      const int pc = 4 * k + j_l - sh;
+      const int idx = pc < 0 ? 0 : (pc < D4 ? pc : D4 - 1);
       x[k] = *reinterpret_cast<const float4*>(obuf + b_l * C::LDO + 4 * idx);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -702,23 +712,28 @@ __global__ __launch_bounds__(64) void fast3_forward_kernel(const float* __restri
     // ---- 16-byte global stores, four lanes per row: no load is waited for behind these stores ----
     {
       const bool row_ok = b_l < len;
-      const uint32_t row_off = (val & ~kMultiBit) * (uint32_t)(C::D * 4) + 16u * j_l;  // B*D*4 < 2^32: checked on the host
+      // B*D*4 < 2^32: checked on the host (the offset of a piece before the row wraps; those pieces are masked)
+      const uint32_t row_off = (val & ~kMultiBit) * (uint32_t)(C::D * 4) + 16u * (uint32_t)(j_l - sh);
+      auto piece_ok = [&](int k) {   // piece 4k + j - sh lies inside the row (only the first / last k can miss)
+        const int pc = 4 * k + j_l - sh;
+        return (k > 0 || pc >= 0) && (4 * k + 3 < D4 || pc < D4);
+      };
       if (__ballot(row_ok && (val & kMultiBit)) == 0ull) {  // the usual case: every bag of the chunk holds one id
 #pragma unroll
         for (int k = 0; k < NLO; ++k)
-          buf_store4(r_out, (row_ok && (D4 % 4 == 0 || j_l + 4 * k < D4)) ? row_off + 64u * k : kOob, x[k]);
+          buf_store4(r_out, (row_ok && piece_ok(k)) ? row_off + 64u * k : kOob, x[k]);
       } else {  // bags with several ids accumulate with float atomics; the others keep the same seven stores
         // (buffer atomics fault on an out-of-range offset instead of vanishing, so those sit in a branch)
         const bool multi = (val & kMultiBit) != 0u;
 #pragma unroll
         for (int k = 0; k < NLO; ++k)
-          buf_store4(r_out, (row_ok && !multi && (D4 % 4 == 0 || j_l + 4 * k < D4)) ? row_off + 64u * k : kOob, x[k]);
+          buf_store4(r_out, (row_ok && !multi && piece_ok(k)) ? row_off + 64u * k : kOob, x[k]);
         if (row_ok && multi) {
           float* dst = out + (val & ~kMultiBit) * (uint32_t)C::D;
 #pragma unroll
           for (int k = 0; k < NLO; ++k) {
-            const int idx = j_l + 4 * k;
-            if (D4 % 4 == 0 || idx < D4) {
+            const int idx = 4 * k + j_l - sh;
+            if (piece_ok(k)) {
               atomicAdd(dst + 4 * idx + 0, x[k].x);
               atomicAdd(dst + 4 * idx + 1, x[k].y);
               atomicAdd(dst + 4 * idx + 2, x[k].z);
@@ -784,7 +799,7 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(const float* __rest
   }
 
   constexpr int F4G = C::ROW2 / 4, NLG = (F4G + 3) / 4;   // float4 pieces of a G2 row / per lane (4 lanes per id)
-  constexpr int F4D = C::D / 4, NLD = (F4D + 3) / 4;      // float4 pieces of a d_output row / per lane
+  constexpr int F4D = C::D / 4, NLD = (F4D % 4 == 0 || !kAlignRows) ? (F4D + 3) / 4 : (F4D + 6) / 4;      // float4 pieces of a d_output row / per lane
   constexpr int PF = C::M2 * R2, PF4 = PF / 4, NLP = (PF4 + kWave - 1) / kWave;
   const desc_ptr ctab = (desc_ptr)plan.ctab;
   const rsrc_t r_i2 = make_rsrc(plan.i2s, nnz * 4u), r_val = make_rsrc(plan.vals, nnz * 4u);
@@ -817,6 +832,7 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(const float* __rest
   // behind a store; rows travel through registers and are in flight during one whole multiply.
   struct Offs {
     uint32_t row, grow, prow;   // byte offsets of this lane's pieces: G2 row, d_output row (kOob = no id), P
+    int sh;                     // 16-byte slots between the last 64-byte boundary and the start of the d_output row
   };
   auto fetch_meta = [&](const uint4& d, uint32_t& i2, uint32_t& val) {
     const uint32_t voff = b_l < (int)(d.z & 0xffu) ? (d.x + (uint32_t)b_l) * 4u : kOob;
@@ -827,21 +843,30 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(const float* __rest
     Offs o;
     o.row = i2 * (uint32_t)(C::ROW2 * 4) + 16u * j_l;
 #if defined(TTEMB_ABL) && (TTEMB_ABL & 2)
+    o.sh = 0;
     o.grow = b_l < (int)(d.z & 0xffu) ? (val & 1023u) * (uint32_t)(C::D * 4) + 16u * j_l : kOob;  // ablation: cache-resident rows
 #else
-    o.grow = b_l < (int)(d.z & 0xffu) ? (val & ~kMultiBit) * (uint32_t)(C::D * 4) + 16u * j_l : kOob;  // B*D*4 < 2^32 (host)
+    // the four lanes of an id load the pieces of one aligned 64-byte block per instruction (see the forward kernel)
+    o.sh = kAlignRows && F4D % 4 != 0 ? (int)(((val & 3u) * (uint32_t)(F4D & 3)) & 3u) : 0;
+    o.grow = b_l < (int)(d.z & 0xffu) ? (val & ~kMultiBit) * (uint32_t)(C::D * 4) + 16u * (uint32_t)(j_l - o.sh) : kOob;  // B*D*4 < 2^32 (host)
 #endif
     o.prow = (d.z & kFirstBit) ? d.y * (uint32_t)(PF * 4) + 16u * lane : kOob;
     return o;
   };
   float4 pre_g[NLG], pre_d[NLD], pre_p[NLP];
+  int sh_pre = 0;   // the shift of the d_output rows now in pre_d
+  auto dpiece_ok = [&](int k, int sh) {   // piece 4k + j - sh lies inside the row (only the first / last k can miss)
+    const int pc = 4 * k + j_l - sh;
+    return (k > 0 || pc >= 0) && (4 * k + 3 < F4D || pc < F4D);
+  };
   auto request = [&](const Offs& o) {
+    sh_pre = o.sh;
 #pragma unroll
     for (int k = 0; k < NLG; ++k)
       pre_g[k] = buf_load4(r_g2, (F4G % 4 == 0 || j_l + 4 * k < F4G) ? o.row + 64u * k : kOob);
 #pragma unroll
     for (int k = 0; k < NLD; ++k)
-      pre_d[k] = buf_load4(r_do, (o.grow != kOob && (F4D % 4 == 0 || j_l + 4 * k < F4D)) ? o.grow + 64u * k : kOob);
+      pre_d[k] = buf_load4(r_do, (o.grow != kOob && dpiece_ok(k, o.sh)) ? o.grow + 64u * k : kOob);
 #pragma unroll
     for (int it = 0; it < NLP; ++it)
       pre_p[it] = buf_load4(r_p, (o.prow != kOob && (PF4 % kWave == 0 || it * kWave + lane < PF4)) ? o.prow + 1024u * it : kOob);
@@ -862,8 +887,8 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(const float* __rest
     }
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
-      const int idx = j_l + 4 * k;
-      if (F4D % 4 == 0 || idx < F4D) *reinterpret_cast<float4*>(dbuf + b_l * C::LDOB + 4 * idx) = pre_d[k];
+      const int idx = 4 * k + j_l - sh_pre;
+      if (dpiece_ok(k, sh_pre)) *reinterpret_cast<float4*>(dbuf + b_l * C::LDOB + 4 * idx) = pre_d[k];
     }
   };
 
