@@ -327,6 +327,59 @@ def test_fast_path_script_shapes(nat, orc, p, q, R, n_ids):
     assert_grads_close(grads, orc.tt_dense_backward(idx, offsets, d_out, cores, p, q, R), rel=2e-4)
 
 
+def _random_bags(rng, n_emb, n_ids):
+    """ids with duplicates, bag lengths 0..3 with a long bag and empty bags in between"""
+    lens = np.concatenate([[0, 37, 0], rng.integers(0, 4, size=n_ids)])
+    lens = lens[np.cumsum(lens) <= n_ids]
+    nnz = int(lens.sum())
+    idx = rng.integers(0, n_emb, size=nnz).astype(np.int64)
+    if nnz > 8:
+        idx[: nnz // 8] = idx[nnz // 8: 2 * (nnz // 8)]
+        idx[-1], idx[-2] = n_emb - 1, 0
+    return idx, np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_shapes_generic(nat, orc, seed):
+    """Seeded sweep of table shapes the wave-per-id kernels must take: T in {2, 3, 4}, q factors 1..8, ranks 1..24
+    (not multiples of 4), p factors down to 1; D a multiple of 4 as the reference requires."""
+    rng = np.random.default_rng(1000 + seed)
+    T = int(rng.integers(2, 5))
+    p = [int(x) for x in rng.integers(1, 40, size=T)]
+    q = [int(x) for x in rng.integers(1, 9, size=T)]
+    if int(np.prod(q)) % 4:   # embedding_dim must be a multiple of 4, as in the reference (tt_embeddings_cuda.cu:993)
+        q[int(rng.integers(0, T))] *= 4
+    R = [1] + [int(x) for x in rng.integers(1, 25, size=T - 1)] + [1]
+    nat.set_path(nat.PATH_GENERIC)
+    cores = [(rng.standard_normal((p[t], R[t] * q[t] * R[t + 1])) * 0.4).astype(np.float32) for t in range(T)]
+    idx, offsets = _random_bags(rng, int(np.prod(p)), int(rng.integers(1, 3000)))
+    out, _ = run_forward(nat, p, q, R, cores, idx, offsets)
+    want = orc.tt_forward(idx, offsets, cores, p, q, R)
+    np.testing.assert_allclose(out, want, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(want).max())))
+    d_out = ((rng.random(want.shape) - 0.5) * 0.2).astype(np.float32)
+    grads = run_backward_dense(nat, p, q, R, cores, idx, offsets, d_out)
+    assert_grads_close(grads, orc.tt_dense_backward(idx, offsets, d_out, cores, p, q, R), rel=2e-4)
+
+
+@pytest.mark.parametrize("shape", sorted(FAST3_SHAPES))
+@pytest.mark.parametrize("seed", [0, 1])
+def test_random_tables_fast_path(nat, orc, shape, seed):
+    """Every instantiated (q, ranks) shape of the grouped MFMA path on random table factorisations (p0, p1 from 1 up,
+    p2 up to 300) and random bags."""
+    q, R = list(shape[:3]), [1, shape[3], shape[4], 1]
+    set_path(nat, "fast3", q, R)
+    rng = np.random.default_rng(77 * seed + sum(shape))
+    p = [int(rng.integers(1, 60)), int(rng.integers(1, 60)), int(rng.integers(1, 300))]
+    cores = [(rng.standard_normal((p[t], R[t] * q[t] * R[t + 1])) * 0.3).astype(np.float32) for t in range(3)]
+    idx, offsets = _random_bags(rng, int(np.prod(p)), int(rng.integers(500, 20000)))
+    out, _ = run_forward(nat, p, q, R, cores, idx, offsets)
+    want = orc.tt_forward(idx, offsets, cores, p, q, R)
+    np.testing.assert_allclose(out, want, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(want).max())))
+    d_out = ((rng.random(want.shape) - 0.5) * 0.2).astype(np.float32)
+    grads = run_backward_dense(nat, p, q, R, cores, idx, offsets, d_out)
+    assert_grads_close(grads, orc.tt_dense_backward(idx, offsets, d_out, cores, p, q, R), rel=2e-4)
+
+
 @pytest.mark.parametrize("cfg,N", [("products", 409600), ("arxiv", 169343), ("papers", 819200)])
 def test_full_size_properties(nat, orc, cfg, N):
     """BASELINE.json sizes (products: the frontier of a 2048-seed batch; arxiv: every node, the full-graph pattern of
