@@ -288,10 +288,13 @@ __device__ __forceinline__ int64_t live_start(int64_t start, const int32_t* star
   return start > nnz ? nnz : start;
 }
 
-// One wavefront walks kIdsPerWave cached ids; per id lanes 0..D/4-1 move one float4 each.
-// single-id bags: plain store when the caller vouches (offsets) that no TT id shares the row,
-// read-modify-write when only the cached part is known to be alone in it; else float atomics.
-constexpr int kIdsPerWave = 8;
+// Forward: lanes are tied to ids four by four (lane = 4 * id + piece, 16 ids per wavefront step): every lane loads
+// the 16-byte pieces j, j + 4, ... of "its" cached row and stores them into its output row, so the index loads, the
+// bag test and up to eight row pieces per lane are all in flight together (one wavefront per id with D/4 of 64
+// lanes busy ran at 2 TB/s: a chain of four dependent loads per id).
+// single-id bags: plain store when the caller vouches (offsets) that no TT id shares the row, read-modify-write when
+// only the cached part is known to be alone in it; else float atomics.
+constexpr int kIdsPerWave = 32;   // two steps of 16 ids
 
 __global__ __launch_bounds__(256) void cache_forward_kernel(const int32_t* __restrict__ loc,
                                                             const int64_t* __restrict__ rowidx,
@@ -302,35 +305,57 @@ __global__ __launch_bounds__(256) void cache_forward_kernel(const int32_t* __res
                                                             float* __restrict__ out) {
   const int64_t s0 = live_start(start, start_dev, nnz);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b_l = lane >> 2, j_l = lane & 3;
   const int64_t first = s0 + ((int64_t)blockIdx.x * 4 + wave) * kIdsPerWave;
+  if (first >= nnz) return;
   const int D4 = D >> 2;
-#pragma unroll 2
-  for (int k = 0; k < kIdsPerWave; ++k) {
-    const int64_t n = first + k;
-    if (n >= nnz) return;
-    const int64_t row = rowidx[n];
-    bool alone, store_only = false;
-    if (offsets != nullptr) {
-      alone = offsets[row + 1] - offsets[row] == 1;
-      store_only = alone;
-    } else {
-      alone = (n == s0 || rowidx[n - 1] != row) && (n + 1 >= nnz || rowidx[n + 1] != row);
-    }
-    const float4* w = reinterpret_cast<const float4*>(weight + (int64_t)loc[n] * D);
-    float* o = out + row * D;
-    for (int c = lane; c < D4; c += kWave) {
-      const float4 v = w[c];
-      if (store_only) {
-        reinterpret_cast<float4*>(o)[c] = v;
-      } else if (alone) {
-        float4 cur = reinterpret_cast<float4*>(o)[c];
-        cur.x += v.x; cur.y += v.y; cur.z += v.z; cur.w += v.w;
-        reinterpret_cast<float4*>(o)[c] = cur;
+  int64_t row[kIdsPerWave / 16];
+  int32_t l[kIdsPerWave / 16];
+  bool on[kIdsPerWave / 16];
+#pragma unroll
+  for (int c = 0; c < kIdsPerWave / 16; ++c) {
+    const int64_t n = first + 16 * c + b_l;
+    on[c] = n < nnz;
+    row[c] = on[c] ? rowidx[n] : 0;
+    l[c] = on[c] ? loc[n] : 0;
+  }
+#pragma unroll
+  for (int c = 0; c < kIdsPerWave / 16; ++c) {
+    const int64_t n = first + 16 * c + b_l;
+    bool alone = false, store_only = false;
+    if (on[c]) {
+      if (offsets != nullptr) {
+        alone = offsets[row[c] + 1] - offsets[row[c]] == 1;
+        store_only = alone;
       } else {
-        atomicAdd(&o[4 * c + 0], v.x);
-        atomicAdd(&o[4 * c + 1], v.y);
-        atomicAdd(&o[4 * c + 2], v.z);
-        atomicAdd(&o[4 * c + 3], v.w);
+        alone = (n == s0 || rowidx[n - 1] != row[c]) && (n + 1 >= nnz || rowidx[n + 1] != row[c]);
+      }
+    }
+    const float4* w = reinterpret_cast<const float4*>(weight + (int64_t)l[c] * D);
+    float* o = out + row[c] * D;
+    for (int base = 0; base < D4; base += 32) {   // eight pieces per lane at a time
+      float4 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int pc = base + 4 * k + j_l;
+        v[k] = (on[c] && pc < D4) ? w[pc] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int pc = base + 4 * k + j_l;
+        if (!on[c] || pc >= D4) continue;
+        if (store_only) {
+          reinterpret_cast<float4*>(o)[pc] = v[k];
+        } else if (alone) {
+          float4 cur = reinterpret_cast<float4*>(o)[pc];
+          cur.x += v[k].x; cur.y += v[k].y; cur.z += v[k].z; cur.w += v[k].w;
+          reinterpret_cast<float4*>(o)[pc] = cur;
+        } else {
+          atomicAdd(&o[4 * pc + 0], v[k].x);
+          atomicAdd(&o[4 * pc + 1], v[k].y);
+          atomicAdd(&o[4 * pc + 2], v[k].z);
+          atomicAdd(&o[4 * pc + 3], v[k].w);
+        }
       }
     }
   }
@@ -338,7 +363,11 @@ __global__ __launch_bounds__(256) void cache_forward_kernel(const int32_t* __res
 
 // scale == -lr : cache_backward_sgd ; scale == 1 : cache_backward_dense (target pre-zeroed).
 // Duplicate ids may hit one cache row, so the adds are float atomics -- issued as whole rows of
-// consecutive floats (64 lanes = 256 contiguous bytes per instruction, the full-rate shape).
+// consecutive floats (64 lanes = 256 contiguous bytes per instruction, the full-rate shape).  A wavefront takes
+// kScatterIds ids: their (row, location) pairs are loaded by one lane each, then every gradient piece of the step is
+// requested before the first atomic is issued.
+constexpr int kScatterIds = 8;
+
 __global__ __launch_bounds__(256) void cache_scatter_add_kernel(const int32_t* __restrict__ loc,
                                                                 const int64_t* __restrict__ rowidx,
                                                                 int64_t start, const int32_t* start_dev,
@@ -347,14 +376,35 @@ __global__ __launch_bounds__(256) void cache_scatter_add_kernel(const int32_t* _
                                                                 float scale, float* __restrict__ target) {
   const int64_t s0 = live_start(start, start_dev, nnz);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t first = s0 + ((int64_t)blockIdx.x * 4 + wave) * kIdsPerWave;
-#pragma unroll 2
-  for (int k = 0; k < kIdsPerWave; ++k) {
-    const int64_t n = first + k;
-    if (n >= nnz) return;
-    const float* g = grad + rowidx[n] * D;
-    float* t = target + (int64_t)loc[n] * D;
-    for (int e = lane; e < D; e += kWave) atomicAdd(&t[e], g[e] * scale);
+  const int64_t first = s0 + ((int64_t)blockIdx.x * 4 + wave) * kScatterIds;
+  if (first >= nnz) return;
+  const int64_t mine = first + lane;
+  const bool have = lane < kScatterIds && mine < nnz;
+  const int64_t my_row = have ? rowidx[mine] : 0;
+  const int32_t my_loc = have ? loc[mine] : 0;
+  const int n_here = (int)(nnz - first < kScatterIds ? nnz - first : kScatterIds);
+  for (int base = 0; base < D; base += 2 * kWave) {   // two 64-float pieces per id at a time
+    float v[kScatterIds][2];
+#pragma unroll
+    for (int k = 0; k < kScatterIds; ++k) {
+      const int64_t r = __shfl(my_row, k, kWave);
+      const float* g = grad + r * D;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int e = base + h * kWave + lane;
+        v[k][h] = (k < n_here && e < D) ? g[e] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kScatterIds; ++k) {
+      const int32_t lk = __shfl(my_loc, k, kWave);
+      float* t = target + (int64_t)lk * D;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int e = base + h * kWave + lane;
+        if (k < n_here && e < D) atomicAdd(&t[e], v[k][h] * scale);
+      }
+    }
   }
 }
 
@@ -393,6 +443,7 @@ __global__ __launch_bounds__(256) void cache_rowwise_adagrad_kernel(
 
 static inline unsigned wave_blocks(int64_t nnz) { return (unsigned)((nnz + 3) / 4); }
 static inline unsigned multi_blocks(int64_t nnz) { return (unsigned)((nnz + 4 * kIdsPerWave - 1) / (4 * kIdsPerWave)); }
+static inline unsigned scatter_blocks(int64_t nnz) { return (unsigned)((nnz + 4 * kScatterIds - 1) / (4 * kScatterIds)); }
 
 int launch_cache_forward(const int32_t* loc, const int64_t* rowidx, const int64_t* offsets, int64_t start,
                          const int32_t* start_dev, int64_t nnz, const float* weight, int64_t D,
@@ -409,7 +460,7 @@ int launch_cache_scatter_add(const int32_t* loc, const int64_t* rowidx, int64_t 
                              float scale, float* target, hipStream_t st) {
   const int64_t span = start_dev ? nnz : nnz - start;
   if (span <= 0) return TTEMB_OK;
-  hipLaunchKernelGGL(cache_scatter_add_kernel, dim3(multi_blocks(span)), dim3(256), 0, st, loc, rowidx,
+  hipLaunchKernelGGL(cache_scatter_add_kernel, dim3(scatter_blocks(span)), dim3(256), 0, st, loc, rowidx,
                      start, start_dev, nnz, grad, (int)D, scale, target);
   return check_hip(hipGetLastError(), "cache_scatter_add_kernel");
 }
