@@ -181,51 +181,100 @@ __global__ void rowidx_kernel(const int64_t* __restrict__ offsets, int64_t B, in
   for (int64_t l = lo; l < hi; ++l) rowidx[l] = b;
 }
 
-__global__ void cache_lookup_kernel(const int64_t* __restrict__ indices, int64_t nnz,
-                                    const int64_t* __restrict__ keys,
-                                    const int32_t* __restrict__ state, uint32_t H,
-                                    int32_t* __restrict__ is_tt, int32_t* __restrict__ loc) {
-  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= nnz) return;
-  const int32_t slot = table_find(indices[n], keys, H);
+// Stable partition in two launches: the lookup counts the TT (uncached) ids of every 256-id block; the scatter
+// kernel adds up the counts of the blocks before its own (a few hundred coalesced loads), ranks its ids with a
+// ballot, finds their bags and writes the three partitioned arrays.  (rowidx expansion + lookup + a rocPRIM scan
+// -- two launches -- + scatter were five launches and 36 us for 409 600 ids.)
+constexpr int kPartThreads = 256;
+
+__global__ __launch_bounds__(kPartThreads) void cache_lookup_kernel(const int64_t* __restrict__ indices, int64_t nnz,
+                                                                    const int64_t* __restrict__ keys,
+                                                                    const int32_t* __restrict__ state, uint32_t H,
+                                                                    int32_t* __restrict__ loc,
+                                                                    int32_t* __restrict__ blockcnt) {
+  const int64_t n = (int64_t)blockIdx.x * kPartThreads + threadIdx.x;
   int32_t where = -1;
-  if (slot >= 0) where = state[slot];
-  is_tt[n] = where < 0 ? 1 : 0;
-  loc[n] = where;
+  if (n < nnz) {
+    const int32_t slot = table_find(indices[n], keys, H);
+    if (slot >= 0) where = state[slot];
+    loc[n] = where;   // < 0: not cached, the id goes through the TT chain
+  }
+  const int c = __syncthreads_count(n < nnz && where < 0);
+  if (threadIdx.x == 0) blockcnt[blockIdx.x] = c;
+}
+
+// bag of position n: the last b with offsets[b] <= n  (tt_embeddings_cuda.cu:1349-1365 expands the same map)
+__device__ __forceinline__ int64_t bag_of_position(const int64_t* __restrict__ offsets, int64_t B, int64_t n) {
+  if (n < B) {   // the usual case: every bag holds one id
+    const int64_t o0 = offsets[n], o1 = offsets[n + 1];
+    if (o0 <= n && n < o1) return n;
+  }
+  int64_t lo = 0, hi = B;  // invariant: offsets[lo] <= n < offsets[hi]
+  while (hi - lo > 1) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (offsets[mid] <= n) lo = mid; else hi = mid;
+  }
+  return lo;
 }
 
 // selected (TT) items keep input order at the front; rejected (cached) items fill the
 // tail from the end backwards -- the order cub::DevicePartition::Flagged produces and
 // the reference's cache kernels therefore see (tt_embeddings_cuda.cu:1448-1490).
-__global__ void partition_scatter_kernel(int64_t nnz, const int32_t* __restrict__ is_tt,
-                                         const int32_t* __restrict__ pos,
-                                         const int64_t* __restrict__ indices,
-                                         const int64_t* __restrict__ rowidx,
-                                         const int32_t* __restrict__ loc,
-                                         int64_t* __restrict__ indices_out,
-                                         int64_t* __restrict__ rowidx_out,
-                                         int32_t* __restrict__ loc_out,
-                                         int32_t* __restrict__ nnz_tt) {
-  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(kPartThreads) void partition_scatter_kernel(int64_t nnz, int64_t B,
+                                                                         const int64_t* __restrict__ offsets,
+                                                                         const int32_t* __restrict__ blockcnt,
+                                                                         const int64_t* __restrict__ indices,
+                                                                         const int32_t* __restrict__ loc,
+                                                                         int64_t* __restrict__ indices_out,
+                                                                         int64_t* __restrict__ rowidx_out,
+                                                                         int32_t* __restrict__ loc_out,
+                                                                         int32_t* __restrict__ nnz_tt) {
+  __shared__ int wave_cnt[kPartThreads / kWave];
+  __shared__ int64_t before_block;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t n = (int64_t)blockIdx.x * kPartThreads + threadIdx.x;
+  int64_t id = 0, row = 0;
+  int32_t where = 0;
+  if (n < nnz) {   // independent of the counts: issued first
+    id = indices[n];
+    where = loc[n];
+    row = bag_of_position(offsets, B, n);
+  }
+  if (wave == 0) {
+    int64_t v = 0;
+    for (int64_t b = lane; b < (int64_t)blockIdx.x; b += kWave) v += blockcnt[b];
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) {
+      const uint32_t lo_w = __shfl_down((uint32_t)v, d, kWave), hi_w = __shfl_down((uint32_t)((uint64_t)v >> 32), d, kWave);
+      v += (int64_t)((uint64_t)lo_w | ((uint64_t)hi_w << 32));
+    }
+    if (lane == 0) before_block = v;
+  }
+  const bool f = n < nnz && where < 0;
+  const unsigned long long ball = __ballot(f);
+  if (lane == 0) wave_cnt[wave] = __popcll(ball);
+  __syncthreads();
+  int64_t before = before_block + __popcll(ball & ((1ull << lane) - 1ull));
+  int total = 0;
+  for (int w = 0; w < kPartThreads / kWave; ++w) {
+    if (w < wave) before += wave_cnt[w];
+    total += wave_cnt[w];
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *nnz_tt = (int32_t)(before_block + total);
   if (n >= nnz) return;
-  const int32_t f = is_tt[n];
-  const int64_t before = pos[n];
   const int64_t dst = f ? before : (nnz - 1 - (n - before));
-  indices_out[dst] = indices[n];
-  rowidx_out[dst] = rowidx[n];
-  loc_out[dst] = loc[n];
-  if (n == nnz - 1) *nnz_tt = (int32_t)(before + f);
+  indices_out[dst] = id;
+  rowidx_out[dst] = row;
+  loc_out[dst] = where;
 }
 
 __global__ void set_count_kernel(int32_t* dst, int32_t v) { *dst = v; }
 
+static int64_t part_blocks(int64_t nnz) { return (nnz + kPartThreads - 1) / kPartThreads; }
+
 int64_t preprocess_workspace_bytes(int64_t nnz) {
-  size_t tmp = 0;
-  int32_t* nul = nullptr;
-  hipError_t e = rocprim::exclusive_scan(nullptr, tmp, nul, nul, 0, (size_t)(nnz > 0 ? nnz : 1),
-                                         rocprim::plus<int32_t>(), (hipStream_t)0, false);
-  if (e != hipSuccess) return -1;
-  return align256(nnz * 8) + 3 * align256(nnz * 4) + align256((int64_t)tmp) + 256;
+  if (nnz < 0) nnz = 0;
+  return align256(nnz * 4) + align256(part_blocks(nnz > 0 ? nnz : 1) * 4) + 256;   // cache locations, per-block counts
 }
 
 int launch_rowidx(const int64_t* offsets, int64_t B, int64_t nnz, int64_t* rowidx, hipStream_t st) {
@@ -245,36 +294,21 @@ int launch_partition(const int64_t* indices, const int64_t* offsets, int64_t nnz
                      const int64_t* hashtbl, const int32_t* state, int64_t H, int64_t* indices_out,
                      int64_t* rowidx_out, int32_t* loc_out, int32_t* nnz_tt_dev, void* ws,
                      int64_t ws_bytes, hipStream_t st) {
-  char* base = reinterpret_cast<char*>(ws);
-  int64_t* rowidx_tmp = reinterpret_cast<int64_t*>(base);
-  base += align256(nnz * 8);
-  int32_t* is_tt = reinterpret_cast<int32_t*>(base);
-  base += align256(nnz * 4);
-  int32_t* pos = reinterpret_cast<int32_t*>(base);
-  base += align256(nnz * 4);
-  int32_t* loc = reinterpret_cast<int32_t*>(base);
-  base += align256(nnz * 4);
-  size_t tmp_bytes = 0;
-  hipError_t e = rocprim::exclusive_scan(nullptr, tmp_bytes, is_tt, pos, 0, (size_t)nnz,
-                                         rocprim::plus<int32_t>(), st, false);
-  if (e != hipSuccess) return check_hip(e, "exclusive_scan(size)");
-  const int64_t need = (base - reinterpret_cast<char*>(ws)) + (int64_t)tmp_bytes;
+  const int64_t need = preprocess_workspace_bytes(nnz);
   if (need > ws_bytes)
     return fail(TTEMB_E_WORKSPACE, "preprocess needs %lld workspace bytes, got %lld", (long long)need,
                 (long long)ws_bytes);
-  int rc = launch_rowidx(offsets, B, nnz, rowidx_tmp, st);
+  char* base = reinterpret_cast<char*>(ws);
+  int32_t* loc = reinterpret_cast<int32_t*>(base);
+  base += align256(nnz * 4);
+  int32_t* blockcnt = reinterpret_cast<int32_t*>(base);
+  const int64_t blocks = part_blocks(nnz);
+  hipLaunchKernelGGL(cache_lookup_kernel, dim3((unsigned)blocks), dim3(kPartThreads), 0, st, indices, nnz,
+                     hashtbl, state, (uint32_t)H, loc, blockcnt);
+  int rc = check_hip(hipGetLastError(), "cache_lookup_kernel");
   if (rc) return rc;
-  const int threads = 256;
-  const int64_t blocks = (nnz + threads - 1) / threads;
-  hipLaunchKernelGGL(cache_lookup_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, indices, nnz,
-                     hashtbl, state, (uint32_t)H, is_tt, loc);
-  rc = check_hip(hipGetLastError(), "cache_lookup_kernel");
-  if (rc) return rc;
-  e = rocprim::exclusive_scan(base, tmp_bytes, is_tt, pos, 0, (size_t)nnz, rocprim::plus<int32_t>(),
-                              st, false);
-  if (e != hipSuccess) return check_hip(e, "exclusive_scan");
-  hipLaunchKernelGGL(partition_scatter_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, nnz, is_tt,
-                     pos, indices, rowidx_tmp, loc, indices_out, rowidx_out, loc_out, nnz_tt_dev);
+  hipLaunchKernelGGL(partition_scatter_kernel, dim3((unsigned)blocks), dim3(kPartThreads), 0, st, nnz, B, offsets,
+                     blockcnt, indices, loc, indices_out, rowidx_out, loc_out, nnz_tt_dev);
   return check_hip(hipGetLastError(), "partition_scatter_kernel");
 }
 
