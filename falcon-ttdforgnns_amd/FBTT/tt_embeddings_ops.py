@@ -245,7 +245,8 @@ class TTLookupFunction(torch.autograd.Function):
                                   float(m.learning_rate), m._ws, ctx.plan, offsets)
                 if ctx.live_cache and nnz > 0:
                     _nat.cache_backward_sgd(cache_loc, rowidx, 0, nnz_dev, nnz, d_output,
-                                            float(m.learning_rate), m.cache_weight.data)
+                                            float(m.learning_rate), m.cache_weight.data,
+                                            nnz_dev[1:] if nnz_dev.numel() > 1 else None)
             else:
                 state = _nat.core_ptrs(list(m.optimizer_state), table)
                 _nat.backward_adagrad(m._shape, cores, state, indices, rowidx, nnz, nnz_dev, B, d_output,
@@ -269,7 +270,8 @@ class TTLookupFunction(torch.autograd.Function):
         d_cache = None
         if ctx.live_cache:
             d_cache = torch.empty_like(m.cache_weight.data)
-            _nat.cache_backward_dense(cache_loc, rowidx, 0, nnz_dev, nnz, d_output, d_cache)
+            _nat.cache_backward_dense(cache_loc, rowidx, 0, nnz_dev, nnz, d_output, d_cache,
+                                      nnz_dev[1:] if nnz_dev.numel() > 1 else None)
         full = []
         for t, g in enumerate(grads):
             if m.num_tables == 1:
@@ -428,9 +430,17 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         rowidx = torch.empty(nnz, dtype=torch.int64, device=dev)
         part = torch.empty_like(indices)
         loc = torch.empty(nnz, dtype=torch.int32, device=dev)
-        nnz_tt = torch.empty(1, dtype=torch.int32, device=dev)
+        # [number of TT ids, "a cache row occurs twice in this batch"]: both stay on the device.  The second word lets
+        # the cache backward update rows with one writer each without float atomics; it comes from per-row stamps
+        # of a per-call epoch (module scratch, not part of the state dict).
+        nnz_tt = torch.empty(2, dtype=torch.int32, device=dev)
+        stamp = getattr(self, "_dup_stamp", None)
+        if stamp is None or stamp.device != dev or stamp.numel() != self.cache_weight.shape[0]:
+            stamp = self._dup_stamp = torch.zeros(self.cache_weight.shape[0], dtype=torch.int32, device=dev)
+            self._dup_epoch = 0
+        self._dup_epoch = self._dup_epoch % 0x7FFFFFFE + 1
         _nat.preprocess(indices, offsets, B, False, self.hashtbl, self.cache_state, part, rowidx, loc, nnz_tt,
-                        self._ws)
+                        self._ws, stamp, self._dup_epoch)
         return TTLookupFunction.apply(self, table, B, part, rowidx, offsets, nnz_tt, loc, self.cache_weight,
                                       *self.tt_cores)
 

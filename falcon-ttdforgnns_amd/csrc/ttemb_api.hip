@@ -550,8 +550,10 @@ int ttemb_cache_populate(const ttemb_shape_t* shape, const float* const* cores, 
 int ttemb_preprocess(const int64_t* indices, const int64_t* offsets, int64_t nnz, int64_t B,
                      int32_t warmup, const int64_t* hashtbl, const int32_t* cache_state, int64_t H,
                      int64_t* indices_out, int64_t* rowidx_out, int32_t* cache_loc_out,
-                     int32_t* nnz_tt_dev, void* workspace, int64_t workspace_bytes, void* stream) {
+                     int32_t* nnz_tt_dev, int32_t* dup_stamp, int32_t epoch, void* workspace, int64_t workspace_bytes,
+                     void* stream) {
   if (nnz < 0 || B < 0) return fail(TTEMB_E_BADARG, "negative size");
+  if (dup_stamp != nullptr && epoch == 0) return fail(TTEMB_E_BADARG, "epoch 0 is the value of a fresh stamp array");
   if (nnz > 0x7fffffffll) return fail(TTEMB_E_BADARG, "nnz exceeds int32 range");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const bool passthrough = warmup != 0 || H == 0;
@@ -571,7 +573,7 @@ int ttemb_preprocess(const int64_t* indices, const int64_t* offsets, int64_t nnz
     return fail(TTEMB_E_BADARG, "null buffer");
   if (indices_out == indices) return fail(TTEMB_E_BADARG, "partition cannot run in place");
   return launch_partition(indices, offsets, nnz, B, hashtbl, cache_state, H, indices_out, rowidx_out,
-                          cache_loc_out, nnz_tt_dev, workspace, workspace_bytes, st);
+                          cache_loc_out, nnz_tt_dev, dup_stamp, epoch, workspace, workspace_bytes, st);
 }
 
 static int check_cache_args(const void* loc, const void* rowidx, int64_t start, int64_t nnz, int64_t D) {
@@ -593,17 +595,17 @@ int ttemb_cache_forward(const int32_t* cache_loc, const int64_t* rowidx, const i
 
 int ttemb_cache_backward_sgd(const int32_t* cache_loc, const int64_t* rowidx, int64_t start,
                              const int32_t* start_dev, int64_t nnz, const float* d_output, int64_t D,
-                             float lr, float* cache_weight, void* stream) {
+                             float lr, float* cache_weight, const int32_t* dup_dev, void* stream) {
   int rc = check_cache_args(cache_loc, rowidx, start, nnz, D);
   if (rc) return rc;
   if (nnz > 0 && (!cache_weight || !d_output)) return fail(TTEMB_E_BADARG, "null buffer");
   return launch_cache_scatter_add(cache_loc, rowidx, start, start_dev, nnz, d_output, D, -lr,
-                                  cache_weight, reinterpret_cast<hipStream_t>(stream));
+                                  cache_weight, dup_dev, reinterpret_cast<hipStream_t>(stream));
 }
 
 int ttemb_cache_backward_dense(const int32_t* cache_loc, const int64_t* rowidx, int64_t start,
                                const int32_t* start_dev, int64_t nnz, const float* d_output, int64_t D,
-                               int64_t C, float* d_cache_weight, void* stream) {
+                               int64_t C, float* d_cache_weight, const int32_t* dup_dev, void* stream) {
   int rc = check_cache_args(cache_loc, rowidx, start, nnz, D);
   if (rc) return rc;
   if (C < 0) return fail(TTEMB_E_BADARG, "negative cache rows");
@@ -615,7 +617,7 @@ int ttemb_cache_backward_dense(const int32_t* cache_loc, const int64_t* rowidx, 
   }
   if (nnz > 0 && !d_output) return fail(TTEMB_E_BADARG, "null buffer");
   return launch_cache_scatter_add(cache_loc, rowidx, start, start_dev, nnz, d_output, D, 1.0f,
-                                  d_cache_weight, st);
+                                  d_cache_weight, dup_dev, st);
 }
 
 int ttemb_cache_backward_rowwise_adagrad(const int32_t* cache_loc, const int64_t* rowidx, int64_t start,

@@ -16,14 +16,14 @@ int launch_rowidx(const int64_t* offsets, int64_t B, int64_t nnz, int64_t* rowid
 int launch_set_count(int32_t* dst, int32_t v, hipStream_t st);
 int launch_partition(const int64_t* indices, const int64_t* offsets, int64_t nnz, int64_t B,
                      const int64_t* hashtbl, const int32_t* state, int64_t H, int64_t* indices_out,
-                     int64_t* rowidx_out, int32_t* loc_out, int32_t* nnz_tt_dev, void* ws,
-                     int64_t ws_bytes, hipStream_t st);
+                     int64_t* rowidx_out, int32_t* loc_out, int32_t* nnz_tt_dev, int32_t* dup_stamp, int32_t epoch,
+                     void* ws, int64_t ws_bytes, hipStream_t st);
 int launch_cache_forward(const int32_t* loc, const int64_t* rowidx, const int64_t* offsets, int64_t start,
                          const int32_t* start_dev, int64_t nnz, const float* weight, int64_t D,
                          float* out, hipStream_t st);
 int launch_cache_scatter_add(const int32_t* loc, const int64_t* rowidx, int64_t start,
                              const int32_t* start_dev, int64_t nnz, const float* grad, int64_t D,
-                             float scale, float* target, hipStream_t st);
+                             float scale, float* target, const int32_t* unique_dev, hipStream_t st);
 int launch_cache_rowwise_adagrad(const int32_t* loc, const int64_t* rowidx, int64_t start,
                                  const int32_t* start_dev, int64_t nnz, const float* grad, int64_t D,
                                  float lr, float eps, float* state_sum, float* weight, hipStream_t st);

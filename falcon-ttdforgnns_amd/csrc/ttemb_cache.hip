@@ -191,16 +191,21 @@ __global__ __launch_bounds__(kPartThreads) void cache_lookup_kernel(const int64_
                                                                     const int64_t* __restrict__ keys,
                                                                     const int32_t* __restrict__ state, uint32_t H,
                                                                     int32_t* __restrict__ loc,
-                                                                    int32_t* __restrict__ blockcnt) {
+                                                                    int32_t* __restrict__ blockcnt,
+                                                                    int32_t* __restrict__ dup_stamp, int32_t epoch) {
   const int64_t n = (int64_t)blockIdx.x * kPartThreads + threadIdx.x;
   int32_t where = -1;
+  bool dup = false;
   if (n < nnz) {
     const int32_t slot = table_find(indices[n], keys, H);
     if (slot >= 0) where = state[slot];
     loc[n] = where;   // < 0: not cached, the id goes through the TT chain
+    // a cache row met twice in one call (stamp == this call's epoch already): its backward adds need atomics
+    if (dup_stamp != nullptr && where >= 0) dup = atomicExch(&dup_stamp[where], epoch) == epoch;
   }
   const int c = __syncthreads_count(n < nnz && where < 0);
-  if (threadIdx.x == 0) blockcnt[blockIdx.x] = c;
+  const int d = __syncthreads_or(dup);
+  if (threadIdx.x == 0) blockcnt[blockIdx.x] = c | (d ? (int32_t)0x80000000 : 0);   // bit 31: a duplicate in this block
 }
 
 // bag of position n: the last b with offsets[b] <= n  (tt_embeddings_cuda.cu:1349-1365 expands the same map)
@@ -228,7 +233,7 @@ __global__ __launch_bounds__(kPartThreads) void partition_scatter_kernel(int64_t
                                                                          int64_t* __restrict__ indices_out,
                                                                          int64_t* __restrict__ rowidx_out,
                                                                          int32_t* __restrict__ loc_out,
-                                                                         int32_t* __restrict__ nnz_tt) {
+                                                                         int32_t* __restrict__ nnz_tt, bool write_dups) {
   __shared__ int wave_cnt[kPartThreads / kWave];
   __shared__ int64_t before_block;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -240,9 +245,19 @@ __global__ __launch_bounds__(kPartThreads) void partition_scatter_kernel(int64_t
     where = loc[n];
     row = bag_of_position(offsets, B, n);
   }
+  const bool last = blockIdx.x == gridDim.x - 1;   // the last block sees every count: it also gathers the duplicate bits
   if (wave == 0) {
     int64_t v = 0;
-    for (int64_t b = lane; b < (int64_t)blockIdx.x; b += kWave) v += blockcnt[b];
+    int dups = 0;
+    for (int64_t b = lane; b < (int64_t)blockIdx.x + (last ? 1 : 0); b += kWave) {
+      const int32_t c = blockcnt[b];
+      if (b < (int64_t)blockIdx.x) v += c & 0x7fffffff;
+      dups |= c < 0;
+    }
+    if (last && nnz_tt != nullptr && write_dups) {
+      const unsigned long long any = __ballot(dups != 0);
+      if (lane == 0) nnz_tt[1] = any != 0ull ? 1 : 0;
+    }
 #pragma unroll
     for (int d = kWave / 2; d > 0; d >>= 1) {
       const uint32_t lo_w = __shfl_down((uint32_t)v, d, kWave), hi_w = __shfl_down((uint32_t)((uint64_t)v >> 32), d, kWave);
@@ -260,7 +275,7 @@ __global__ __launch_bounds__(kPartThreads) void partition_scatter_kernel(int64_t
     if (w < wave) before += wave_cnt[w];
     total += wave_cnt[w];
   }
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *nnz_tt = (int32_t)(before_block + total);
+  if (last && threadIdx.x == 0) nnz_tt[0] = (int32_t)(before_block + total);
   if (n >= nnz) return;
   const int64_t dst = f ? before : (nnz - 1 - (n - before));
   indices_out[dst] = id;
@@ -292,8 +307,8 @@ int launch_set_count(int32_t* dst, int32_t v, hipStream_t st) {
 
 int launch_partition(const int64_t* indices, const int64_t* offsets, int64_t nnz, int64_t B,
                      const int64_t* hashtbl, const int32_t* state, int64_t H, int64_t* indices_out,
-                     int64_t* rowidx_out, int32_t* loc_out, int32_t* nnz_tt_dev, void* ws,
-                     int64_t ws_bytes, hipStream_t st) {
+                     int64_t* rowidx_out, int32_t* loc_out, int32_t* nnz_tt_dev, int32_t* dup_stamp, int32_t epoch,
+                     void* ws, int64_t ws_bytes, hipStream_t st) {
   const int64_t need = preprocess_workspace_bytes(nnz);
   if (need > ws_bytes)
     return fail(TTEMB_E_WORKSPACE, "preprocess needs %lld workspace bytes, got %lld", (long long)need,
@@ -304,11 +319,11 @@ int launch_partition(const int64_t* indices, const int64_t* offsets, int64_t nnz
   int32_t* blockcnt = reinterpret_cast<int32_t*>(base);
   const int64_t blocks = part_blocks(nnz);
   hipLaunchKernelGGL(cache_lookup_kernel, dim3((unsigned)blocks), dim3(kPartThreads), 0, st, indices, nnz,
-                     hashtbl, state, (uint32_t)H, loc, blockcnt);
+                     hashtbl, state, (uint32_t)H, loc, blockcnt, dup_stamp, epoch);
   int rc = check_hip(hipGetLastError(), "cache_lookup_kernel");
   if (rc) return rc;
   hipLaunchKernelGGL(partition_scatter_kernel, dim3((unsigned)blocks), dim3(kPartThreads), 0, st, nnz, B, offsets,
-                     blockcnt, indices, loc, indices_out, rowidx_out, loc_out, nnz_tt_dev);
+                     blockcnt, indices, loc, indices_out, rowidx_out, loc_out, nnz_tt_dev, dup_stamp != nullptr);
   return check_hip(hipGetLastError(), "partition_scatter_kernel");
 }
 
@@ -407,9 +422,44 @@ __global__ __launch_bounds__(256) void cache_scatter_add_kernel(const int32_t* _
                                                                 int64_t start, const int32_t* start_dev,
                                                                 int64_t nnz,
                                                                 const float* __restrict__ grad, int D,
-                                                                float scale, float* __restrict__ target) {
+                                                                float scale, float* __restrict__ target,
+                                                                const int32_t* __restrict__ unique_dev) {
   const int64_t s0 = live_start(start, start_dev, nnz);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (unique_dev != nullptr && *unique_dev == 0) {
+    // no cache row occurs twice in this call (ttemb_preprocess checked): every row has one writer, so the update is a
+    // plain read-modify-write, four lanes per row with all pieces in flight, 32 ids per wavefront like the forward
+    const int b_l = lane >> 2, j_l = lane & 3;
+    const int D4 = D >> 2;
+    const int64_t first_u = s0 + ((int64_t)blockIdx.x * 4 + wave) * kIdsPerWave;
+#pragma unroll
+    for (int c = 0; c < kIdsPerWave / 16; ++c) {
+      const int64_t n = first_u + 16 * c + b_l;
+      if (n >= nnz) continue;
+      const float4* g = reinterpret_cast<const float4*>(grad + rowidx[n] * D);
+      float4* t = reinterpret_cast<float4*>(target + (int64_t)loc[n] * D);
+      for (int base = 0; base < D4; base += 32) {
+        float4 gv[8], tv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int pc = base + 4 * k + j_l;
+          if (pc < D4) {
+            gv[k] = g[pc];
+            tv[k] = t[pc];
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int pc = base + 4 * k + j_l;
+          if (pc < D4) {
+            tv[k].x += gv[k].x * scale; tv[k].y += gv[k].y * scale; tv[k].z += gv[k].z * scale; tv[k].w += gv[k].w * scale;
+            t[pc] = tv[k];
+          }
+        }
+      }
+    }
+    return;
+  }
   const int64_t first = s0 + ((int64_t)blockIdx.x * 4 + wave) * kScatterIds;
   if (first >= nnz) return;
   const int64_t mine = first + lane;
@@ -491,11 +541,11 @@ int launch_cache_forward(const int32_t* loc, const int64_t* rowidx, const int64_
 
 int launch_cache_scatter_add(const int32_t* loc, const int64_t* rowidx, int64_t start,
                              const int32_t* start_dev, int64_t nnz, const float* grad, int64_t D,
-                             float scale, float* target, hipStream_t st) {
+                             float scale, float* target, const int32_t* unique_dev, hipStream_t st) {
   const int64_t span = start_dev ? nnz : nnz - start;
   if (span <= 0) return TTEMB_OK;
   hipLaunchKernelGGL(cache_scatter_add_kernel, dim3(scatter_blocks(span)), dim3(256), 0, st, loc, rowidx,
-                     start, start_dev, nnz, grad, (int)D, scale, target);
+                     start, start_dev, nnz, grad, (int)D, scale, target, unique_dev);
   return check_hip(hipGetLastError(), "cache_scatter_add_kernel");
 }
 

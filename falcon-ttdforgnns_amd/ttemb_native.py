@@ -85,10 +85,10 @@ def _load() -> ctypes.CDLL:
     lib.ttemb_adagrad_step.argtypes = [vp, vp, vp, i64, f32, f32, vp]
     lib.ttemb_cache_update.argtypes = [vp, i64, vp, vp, i64, vp]
     lib.ttemb_cache_populate.argtypes = [shp, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp]
-    lib.ttemb_preprocess.argtypes = [vp, vp, i64, i64, i32, vp, vp, i64, vp, vp, vp, vp, vp, i64, vp]
+    lib.ttemb_preprocess.argtypes = [vp, vp, i64, i64, i32, vp, vp, i64, vp, vp, vp, vp, vp, i32, vp, i64, vp]
     lib.ttemb_cache_forward.argtypes = [vp, vp, vp, i64, vp, i64, vp, i64, vp, vp]
-    lib.ttemb_cache_backward_sgd.argtypes = [vp, vp, i64, vp, i64, vp, i64, f32, vp, vp]
-    lib.ttemb_cache_backward_dense.argtypes = [vp, vp, i64, vp, i64, vp, i64, i64, vp, vp]
+    lib.ttemb_cache_backward_sgd.argtypes = [vp, vp, i64, vp, i64, vp, i64, f32, vp, vp, vp]
+    lib.ttemb_cache_backward_dense.argtypes = [vp, vp, i64, vp, i64, vp, i64, i64, vp, vp, vp]
     lib.ttemb_cache_backward_rowwise_adagrad.argtypes = [vp, vp, i64, vp, i64, vp, i64, f32, f32, vp, vp, vp]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
@@ -305,7 +305,9 @@ def cache_populate(shape: Shape, cores, hashtbl, cache_freq, cache_state, cache_
 
 
 def preprocess(indices, offsets, B: int, warmup: bool, hashtbl, cache_state, indices_out, rowidx_out,
-               cache_loc_out, nnz_tt_dev, ws: Workspace) -> None:
+               cache_loc_out, nnz_tt_dev, ws: Workspace, dup_stamp=None, epoch: int = 0) -> None:
+    """``dup_stamp`` (int32[C], zeros at first) + a non-zero ``epoch``: ``nnz_tt_dev`` must hold two int32 and its
+    second word tells the cache backward whether a cache row occurs twice in this call."""
     dev = indices.device
     nnz = indices.numel()
     H = 0 if hashtbl is None else hashtbl.numel()
@@ -314,7 +316,7 @@ def preprocess(indices, offsets, B: int, warmup: bool, hashtbl, cache_state, ind
     with _on_device(dev):
         _check(LIB.ttemb_preprocess(_ptr(indices), _ptr(offsets), nnz, B, 1 if warmup else 0, _ptr(hashtbl),
                                     _ptr(cache_state), H, _ptr(indices_out), _ptr(rowidx_out),
-                                    _ptr(cache_loc_out), _ptr(nnz_tt_dev), _ptr(w), w.numel(),
+                                    _ptr(cache_loc_out), _ptr(nnz_tt_dev), _ptr(dup_stamp), epoch, _ptr(w), w.numel(),
                                     _stream(indices)))
 
 
@@ -327,20 +329,20 @@ def cache_forward(cache_loc, rowidx, start: int, start_dev, nnz: int, cache_weig
 
 
 def cache_backward_sgd(cache_loc, rowidx, start: int, start_dev, nnz: int, d_output, lr: float,
-                       cache_weight) -> None:
+                       cache_weight, dup_dev=None) -> None:
     with _on_device(d_output.device):
         _check(LIB.ttemb_cache_backward_sgd(_ptr(cache_loc), _ptr(rowidx), start, _ptr(start_dev), nnz,
                                             _ptr(d_output), cache_weight.shape[1], lr, _ptr(cache_weight),
-                                            _stream(d_output)))
+                                            _ptr(dup_dev), _stream(d_output)))
 
 
 def cache_backward_dense(cache_loc, rowidx, start: int, start_dev, nnz: int, d_output,
-                         d_cache_weight) -> None:
+                         d_cache_weight, dup_dev=None) -> None:
     with _on_device(d_output.device):
         _check(LIB.ttemb_cache_backward_dense(_ptr(cache_loc), _ptr(rowidx), start, _ptr(start_dev), nnz,
                                               _ptr(d_output), d_cache_weight.shape[1],
                                               d_cache_weight.shape[0], _ptr(d_cache_weight),
-                                              _stream(d_output)))
+                                              _ptr(dup_dev), _stream(d_output)))
 
 
 def cache_backward_rowwise_adagrad(cache_loc, rowidx, start: int, start_dev, nnz: int, d_output, lr: float,

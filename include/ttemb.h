@@ -191,11 +191,15 @@ int ttemb_cache_populate(const ttemb_shape_t* shape, const float* const* cores,
  * cache_loc) are partitioned: TT ids first in input order, cached ids from the end
  * backwards (the CUB DevicePartition::Flagged order); *nnz_tt_dev = #TT ids.
  * Does NOT synchronise: the count stays on the device (pass it to the other entry
- * points as nnz_dev, or copy it back yourself). */
+ * points as nnz_dev, or copy it back yourself).
+ * `dup_stamp` (nullable; int32[C], zero-filled once by the caller and then owned by these calls) and `epoch`
+ * (non-zero, different from the epochs of the caller's recent calls) turn on duplicate detection among the
+ * cached ids: nnz_tt_dev must then hold TWO int32 and nnz_tt_dev[1] becomes 1 when some cache row is met more
+ * than once in this call, else 0 -- the word ttemb_cache_backward_sgd / _dense take as `dup_dev`. */
 int ttemb_preprocess(const int64_t* indices, const int64_t* offsets, int64_t nnz, int64_t B,
                      int32_t warmup, const int64_t* hashtbl, const int32_t* cache_state,
                      int64_t H, int64_t* indices_out, int64_t* rowidx_out,
-                     int32_t* cache_loc_out, int32_t* nnz_tt_dev,
+                     int32_t* cache_loc_out, int32_t* nnz_tt_dev, int32_t* dup_stamp, int32_t epoch,
                      void* workspace, int64_t workspace_bytes, void* stream);
 
 /* cache_forward (tt_embeddings.cpp:151, tt_embeddings_cuda.cu:1509-1583):
@@ -208,16 +212,19 @@ int ttemb_cache_forward(const int32_t* cache_loc, const int64_t* rowidx, const i
                         int64_t D, float* output, void* stream);
 
 /* cache_backward_sgd (tt_embeddings.cpp:152, tt_embeddings_cuda.cu:1585-1668):
- * cache_weight[loc] -= lr * d_output[row]. */
+ * cache_weight[loc] -= lr * d_output[row].  The adds are float atomics (an id may occur twice, as in the
+ * reference) unless `dup_dev` (nullable) points at a device int32 that is 0: the word ttemb_preprocess wrote
+ * when no cache row occurs twice in the call -- every row then has one writer and is updated by a plain
+ * read-modify-write. */
 int ttemb_cache_backward_sgd(const int32_t* cache_loc, const int64_t* rowidx, int64_t start,
                              const int32_t* start_dev, int64_t nnz, const float* d_output,
-                             int64_t D, float lr, float* cache_weight, void* stream);
+                             int64_t D, float lr, float* cache_weight, const int32_t* dup_dev, void* stream);
 
 /* cache_backward_dense (tt_embeddings.cpp:153-156, tt_embeddings_cuda.cu:1670-1744):
  * d_cache_weight[C][D] is zero-filled, then d_cache_weight[loc] += d_output[row]. */
 int ttemb_cache_backward_dense(const int32_t* cache_loc, const int64_t* rowidx, int64_t start,
                                const int32_t* start_dev, int64_t nnz, const float* d_output,
-                               int64_t D, int64_t C, float* d_cache_weight, void* stream);
+                               int64_t D, int64_t C, float* d_cache_weight, const int32_t* dup_dev, void* stream);
 
 /* cache_backward_rowwise_adagrad_approx (tt_embeddings.cpp:157-160,
  * tt_embeddings_cuda.cu:1746-1846): per id, g2 = mean(d_output[row]^2);

@@ -281,6 +281,59 @@ def test_cache_lifecycle_keeps_forward_and_trains(ops, orc, sparse):
             np.testing.assert_allclose(c.grad[0].cpu().numpy(), g, rtol=1e-3, atol=1e-4 * np.abs(g).max())
 
 
+@pytest.mark.parametrize("sparse", [False, True])
+def test_cache_backward_with_unique_cache_rows(ops, orc, sparse):
+    """A batch in which no cached id repeats: ttemb_preprocess reports it (second word of the device count) and the
+    cache backward updates every row with a plain read-modify-write instead of float atomics; a batch with a repeat
+    flips the flag and takes the atomic path.  Both against the oracle."""
+    import ttemb_native as nat
+    torch.manual_seed(11)
+    rng = np.random.default_rng(11)
+    p, q, r = [20, 25, 30], [4, 5, 5], [16, 16]
+    n, D, lr = int(np.prod(p)), 100, 0.1
+    emb = ops.TTEmbeddingBag(n, D, r, p, q, sparse=sparse, use_cache=True, cache_size=300, hashtbl_size=n,
+                             weight_dist="normal", learning_rate=lr)
+    for c in emb.tt_cores:
+        c.data.mul_(40.0)
+    hot = rng.choice(n, size=250, replace=False)
+    for _ in range(4):
+        idx = torch.tensor(np.concatenate([rng.choice(hot, size=400), rng.integers(0, n, size=100)])).cuda()
+        emb(idx, torch.arange(idx.numel() + 1).cuda())
+    emb.cache_populate()
+    keys, state = emb.hashtbl.cpu().numpy(), emb.cache_state.cpu().numpy()
+    for repeat in (False, True):
+        batch = np.concatenate([rng.choice(hot, size=180, replace=False),
+                                rng.choice(np.setdiff1d(np.arange(n), hot), size=220, replace=False)])
+        if repeat:   # one cached id a second time, in the place of an uncached one
+            is_tt0, _ = orc.cache_lookup(batch, keys, state)
+            batch[np.flatnonzero(is_tt0)[0]] = batch[np.flatnonzero(~is_tt0)[0]]
+        rng.shuffle(batch)
+        idx = torch.tensor(batch).cuda()
+        offs = torch.arange(batch.shape[0] + 1).cuda()
+        # the flag itself, through the C ABI
+        nnz_tt = torch.full((2,), -7, dtype=torch.int32).cuda()
+        stamp = torch.zeros(300, dtype=torch.int32).cuda()
+        nat.preprocess(idx, offs, batch.shape[0], False, emb.hashtbl, emb.cache_state, torch.empty_like(idx),
+                       torch.empty_like(idx), torch.empty(batch.shape[0], dtype=torch.int32).cuda(), nnz_tt,
+                       nat.Workspace(), stamp, 3)
+        is_tt, loc = orc.cache_lookup(batch, keys, state)
+        assert nnz_tt.cpu().tolist() == [int(is_tt.sum()), 1 if repeat else 0]
+        assert (~is_tt).sum() > 100
+        # one training step through the module
+        cache_before = emb.cache_weight.detach().clone().cpu().numpy()
+        if emb.cache_weight.grad is not None:
+            emb.cache_weight.grad = None
+        out = emb(idx, offs)
+        d_out = (torch.rand_like(out) - 0.5) * 0.1
+        out.backward(d_out)
+        g_cache = orc.cache_backward_dense(d_out.cpu().numpy(), loc[~is_tt], np.arange(batch.shape[0])[~is_tt], 300, D)
+        if sparse:
+            np.testing.assert_allclose(emb.cache_weight.detach().cpu().numpy(), cache_before - lr * g_cache,
+                                       rtol=0, atol=1e-5)
+        else:
+            np.testing.assert_allclose(emb.cache_weight.grad.cpu().numpy(), g_cache, rtol=1e-4, atol=1e-6)
+
+
 def test_lfu_update_after_populate_keeps_cached_ids(ops, orc):
     """After cache_populate's evictions the update must find a displaced cached key instead of
     inserting it again in front of itself (see oracle.update_cache_state, find_first=True)."""
