@@ -213,6 +213,39 @@ def main():
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t1) / 20
             local = {"ids": N, "ms_per_step": round(dt * 1e3, 4), "lookups_per_s": round(N / dt, 1)}
+        # BASELINE.json configs[2]: the same step with the LFU row cache live (10 % of the rows cached, frontiers of
+        # 200-id windows whose starts follow a Zipf law so that hot regions recur -- SURVEY.md §8d cfg-C), after a
+        # counting epoch and cache_populate(); the hit rate is reported next to the step time
+        cached = None
+        if world == 1 and not args.no_extras:
+            n_win = N_EMB // 200
+            zp = 1.0 / np.arange(1, n_win + 1) ** 1.05
+            zp /= zp.sum()
+            perm = rng.permutation(n_win)
+
+            def frontier():
+                st = perm[rng.choice(n_win, size=N // 200, replace=False, p=zp)] * 200
+                return torch.from_numpy((st[:, None] + np.arange(200)[None, :]).reshape(-1).astype(np.int64)).cuda()
+
+            cemb = TTEmbeddingBag(N_EMB, D, RANKS, P, Q, sparse=True, use_cache=True, cache_size=int(0.1 * N_EMB),
+                                  hashtbl_size=N_EMB, weight_dist="normal", learning_rate=0.01, batch_count=N)
+            for _ in range(96):
+                cemb.update_cache(frontier())
+            cemb.cache_populate()
+            test = [frontier() for _ in range(24)]
+            keys = cemb.hashtbl[cemb.cache_state >= 0]
+            hit = float(np.mean([float(torch.isin(b, keys).float().mean()) for b in test[:4]]))
+            for b in test[:4]:
+                cemb(b, offsets).backward(d_out)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for b in test:
+                cemb(b, offsets).backward(d_out)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / len(test)
+            cached = {"ids": N, "ms_per_step": round(dt * 1e3, 4), "lookups_per_s": round(N / dt, 1),
+                      "cache_rows": int(cemb.cache_weight.shape[0]), "hit_rate": round(hit, 3)}
+            del cemb
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             from oracle import cpu_einsum
@@ -232,6 +265,7 @@ def main():
                        "p": P, "q": Q, "tt_ranks": RANKS, "num_embeddings": N_EMB, "ids_per_gpu_step": N,
                        "parallelism": f"dp{world}", "kernel_path": args.path},
             "roofline": roofline, "cpu_baseline": cpu, "batch2048_step": small, "metis_like_step": local,
+            "cache_on_step": cached,
         }
     if world > 1:
         dist.barrier()
