@@ -1038,9 +1038,9 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(const float* __rest
 // in registers and stores one (r2 q2)-float row per i2 into the tile's slab of partial sums
 // (plain stores: atomics from every tile onto the 45 KB of dG2 ran at ~0.1 TB/s).  E rows are
 // read exactly once, 16 bytes per lane.  fast3_finalize_kernel adds the slabs up.
-template <int ROW2, int kRowsB, int NWB>
-__global__ __launch_bounds__(NWB * 64) void fast3_dg2_reduce_kernel(GroupPlan plan, int G, uint32_t p2) {
-  extern __shared__ uint32_t lds_u[];   // [p2 + 1] bucket starts | [p2] cursors | [kRowsB] row list (uint16)
+template <int ROW2, int kRowsMax, int NWB>
+__global__ __launch_bounds__(NWB * 64) void fast3_dg2_reduce_kernel(GroupPlan plan, int G, uint32_t p2, uint32_t kRowsB) {
+  extern __shared__ uint32_t lds_u[];   // [p2 + 1] bucket starts | [p2] cursors | [kRowsMax] row list (uint16)
   uint32_t* bstart = lds_u;
   uint32_t* cursor = lds_u + p2 + 1;
   unsigned short* rows = reinterpret_cast<unsigned short*>(cursor + p2);
@@ -1054,9 +1054,9 @@ __global__ __launch_bounds__(NWB * 64) void fast3_dg2_reduce_kernel(GroupPlan pl
   for (uint32_t e = tid; e <= p2; e += NWB * 64) bstart[e] = 0;
   __syncthreads();
   // histogram of i2 over the tile (integer LDS atomics; 8 ids per thread)
-  uint32_t my_i2[kRowsB / (NWB * 64)], my_rank[kRowsB / (NWB * 64)];
+  uint32_t my_i2[kRowsMax / (NWB * 64)], my_rank[kRowsMax / (NWB * 64)];
 #pragma unroll
-  for (int k = 0; k < kRowsB / (NWB * 64); ++k) {
+  for (int k = 0; k < kRowsMax / (NWB * 64); ++k) {
     const uint32_t r = k * NWB * 64 + tid;
     my_i2[k] = 0xffffffffu;
     if (r < n_rows) {
@@ -1082,7 +1082,7 @@ __global__ __launch_bounds__(NWB * 64) void fast3_dg2_reduce_kernel(GroupPlan pl
   }
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < kRowsB / (NWB * 64); ++k)
+  for (int k = 0; k < kRowsMax / (NWB * 64); ++k)
     if (my_i2[k] != 0xffffffffu) rows[bstart[my_i2[k]] + my_rank[k]] = (unsigned short)(k * NWB * 64 + tid);
   __syncthreads();
   // wave w sums the buckets i2 = w, w + NWB, ...
@@ -1429,9 +1429,16 @@ bool fast3_fits(const DevShape& s, int64_t nnz, int64_t B) {
 #ifndef TTEMB_ROWS_B
 #define TTEMB_ROWS_B 2048
 #endif
-constexpr int kRowsB = TTEMB_ROWS_B;  // E rows per workgroup of the dG2 reduce
+constexpr int kRowsB = TTEMB_ROWS_B;  // E rows per workgroup of the dG2 reduce, at most
+// One round of workgroups when the batch allows it: the kernel is as long as its longest workgroup, so 409 600 rows
+// go as 256 tiles of 1 600 (every CU busy) rather than 200 tiles of 2 048; small batches keep >= 512 rows per tile
+// (the finalize kernel reads one p2 x row slab per tile).
+static int reduce_rows(int64_t nnz) {
+  int64_t r = ((nnz + 255) / 256 + 63) / 64 * 64;
+  return (int)(r < 512 ? 512 : (r > kRowsB ? kRowsB : r));
+}
 constexpr int NWB = 16;
-static int64_t reduce_tiles(int64_t nnz) { return (nnz + kRowsB - 1) / kRowsB; }
+static int64_t reduce_tiles(int64_t nnz) { const int r = reduce_rows(nnz); return (nnz + r - 1) / r; }
 // the epilogue cuts the i0 range of every i1 into ~kEpiSlices slices of `gpw` groups (one wavefront each)
 static int epi_groups_per_wave(const DevShape& s) {
   int gpw = (s.p[0] + kEpiSlices - 1) / kEpiSlices;
@@ -1673,7 +1680,7 @@ static int run_backward(const DevShape& s, const CorePtrs& cores, const GroupPla
   if (rc) return rc;
   const int tiles = (int)reduce_tiles(nnz);
   hipLaunchKernelGGL((fast3_dg2_reduce_kernel<C::ROW2, kRowsB, NWB>), dim3((unsigned)tiles), dim3(NWB * 64),
-                     (size_t)(2 * s.p[2] + 1) * 4 + kRowsB * 2, st, plan, (int)G, (uint32_t)s.p[2]);
+                     (size_t)(2 * s.p[2] + 1) * 4 + kRowsB * 2, st, plan, (int)G, (uint32_t)s.p[2], (uint32_t)reduce_rows(nnz));
   rc = check_hip(hipGetLastError(), "fast3_dg2_reduce_kernel");
   if (rc) return rc;
   const int gpw = epi_groups_per_wave(s), slices = epi_slices(s);
