@@ -1434,6 +1434,9 @@ constexpr int kRowsB = TTEMB_ROWS_B;  // E rows per workgroup of the dG2 reduce,
 // go as 256 tiles of 1 600 (every CU busy) rather than 200 tiles of 2 048; small batches keep >= 512 rows per tile
 // (the finalize kernel reads one p2 x row slab per tile).
 static int reduce_rows(int64_t nnz) {
+#ifdef TTEMB_REDUCE_FIXED
+  return kRowsB;
+#endif
   int64_t r = ((nnz + 255) / 256 + 63) / 64 * 64;
   return (int)(r < 512 ? 512 : (r > kRowsB ? kRowsB : r));
 }
