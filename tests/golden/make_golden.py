@@ -241,6 +241,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "windows":
         window_case("rows_products_b3", [125, 140, 140], [4, 5, 5], [16, 16], 22, 2449029, 6, 40)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "scripts":   # the (q, rank) shapes of the reference's run scripts
+        script_shape_cases()
+        return
     torch.manual_seed(0)
     tiny_case("tt_tiny_T2", [6, 7], [4, 3], [5], seed=11)
     tiny_case("tt_tiny_T3", [3, 4, 5], [2, 3, 2], [4, 3], seed=12)
@@ -255,6 +258,16 @@ def main():
     window_case("rows_products_b3", [125, 140, 140], [4, 5, 5], [16, 16], 22, 2449029, 6, 40)
     murmur_vectors()
     suggested_shape_vectors()
+    script_shape_cases()
+
+
+def script_shape_cases():
+    """q = 4,4,8 / 8,4,4 at rank 16 (run_ogbn-arxiv*.sh and friends) and the rank-32 variants of the fast path."""
+    tiny_case("tt_small_q448r16", [5, 4, 6], [4, 4, 8], [16, 16], seed=17)
+    tiny_case("tt_small_q844r16", [4, 5, 3], [8, 4, 4], [16, 16], seed=18)
+    tiny_case("tt_small_q455r32", [3, 4, 5], [4, 5, 5], [32, 32], seed=19)
+    tiny_case("tt_small_q448r32", [4, 3, 4], [4, 4, 8], [32, 32], seed=20)
+    window_case("rows_q448r16_b3", [125, 140, 140], [4, 4, 8], [16, 16], 24, 2449029, 6, 40)
 
 
 if __name__ == "__main__":
