@@ -160,6 +160,7 @@ CONFIGS = {
     "arxiv": ([56, 60, 51], [4, 4, 8], [1, 8, 8, 1], 169343),
     "products": ([125, 140, 140], [4, 5, 5], [1, 16, 16, 1], 2449029),
     "papers": ([500, 560, 400], [8, 4, 4], [1, 32, 32, 1], 111059956),
+    "arxiv_r16": ([125, 140, 140], [4, 4, 8], [1, 16, 16, 1], 2449029),   # the run scripts' ogbn-arxiv shape (D = 128, rank 16)
     "two_core": ([300, 400], [8, 8], [1, 12, 1], 120000),
     "four_core": ([20, 25, 30, 10], [2, 4, 4, 2], [1, 6, 10, 4, 1], 150000),
 }
@@ -380,7 +381,7 @@ def test_random_tables_fast_path(nat, orc, shape, seed):
     assert_grads_close(grads, orc.tt_dense_backward(idx, offsets, d_out, cores, p, q, R), rel=2e-4)
 
 
-@pytest.mark.parametrize("cfg,N", [("products", 409600), ("arxiv", 169343), ("papers", 819200)])
+@pytest.mark.parametrize("cfg,N", [("products", 409600), ("arxiv", 169343), ("papers", 819200), ("arxiv_r16", 169343)])
 def test_full_size_properties(nat, orc, cfg, N):
     """BASELINE.json sizes (products: the frontier of a 2048-seed batch; arxiv: every node, the full-graph pattern of
     gcn_gat_partition.py; papers: ids beyond 2^24) through size-independent properties."""
