@@ -170,10 +170,10 @@ struct GroupPlan {           // device pointers into the caller's plan buffer / 
   uint32_t* rcount;          // [ranges] running / final id count of every range
   uint32_t* rstart;          // [ranges + 1] first position of every range in the range-ordered arrays
   uint64_t* lpre;            // [G] prefix of (ids | chunks << 32) inside the group's range
-  uint64_t* rtot;            // [ranges] (ids | chunks << 32) of every range
+  uint64_t* rtot;            // [2 * ranges] (ids | chunks << 32) of every range, then its number of non-empty groups
   uint32_t* i2s;             // [nnz] grouped: last index digit of the id
   uint32_t* vals;            // [nnz] grouped: output row | kMultiBit
-  uint32_t* counts;          // [G+1] ids per group
+  uint32_t* counts;          // [G+1] ids per group; entry G = number of groups that hold an id
   uint64_t* gpre;            // [G+1] low word: first grouped position of the group; high word: its first chunk.
                              //       entry G = (live ids, chunks)
   uint4* ctab;               // [max_chunks] chunk descriptors
@@ -183,6 +183,7 @@ struct GroupPlan {           // device pointers into the caller's plan buffer / 
   float* g2part;             // [tiles][p2][ROW2] per-tile partial dG2
   float* g0part;             // [G][ROW0] per-group contribution to dG0
   float* g1part;             // [slices][p1][ROW1] per-slice partial dG1
+  uint32_t* epi_live;        // [slices][p1] sparse form only: 1 when the slice of that i1 holds an id (its slab exists)
 };
 
 __device__ __forceinline__ uint64_t pack_count(uint32_t c) {   // ids in the low word, chunks of <= kChunk ids in the high word
@@ -362,6 +363,7 @@ __global__ __launch_bounds__(kRangeThreads) void fast3_count_kernel(uint32_t G, 
   }
   __syncthreads();
   uint64_t carry = 0;
+  uint32_t live_groups = 0;
   for (uint32_t base = 0; base < span; base += kRangeThreads) {
     const uint32_t i = base + threadIdx.x;
     const uint32_t c = i < span ? hist[i] : 0u;
@@ -372,8 +374,12 @@ __global__ __launch_bounds__(kRangeThreads) void fast3_count_kernel(uint32_t G, 
       plan.lpre[g0 + i] = carry + pre;
     }
     carry += total;
+    live_groups += (uint32_t)__syncthreads_count(c != 0u);
   }
-  if (threadIdx.x == 0) plan.rtot[blockIdx.x] = carry;
+  if (threadIdx.x == 0) {
+    plan.rtot[blockIdx.x] = carry;
+    plan.rtot[gridDim.x + blockIdx.x] = live_groups;   // second half of the array: non-empty groups of the range
+  }
 }
 
 __device__ __forceinline__ void place_range(const uint32_t range, const uint32_t ranges, uint32_t G, uint32_t shift,
@@ -387,13 +393,22 @@ __device__ __forceinline__ void place_range(const uint32_t range, const uint32_t
   uint32_t* gchunk = gcount + span;
   if (threadIdx.x < kWave) {   // (ids, chunks) of the ranges before this one
     uint64_t v = 0;
-    for (uint32_t r = threadIdx.x; r < range; r += kWave) v += plan.rtot[r];
+    uint32_t live_groups = 0;
+    for (uint32_t r = threadIdx.x; r < range; r += kWave) {
+      v += plan.rtot[r];
+      if (range == ranges - 1) live_groups += (uint32_t)plan.rtot[ranges + r];
+    }
 #pragma unroll
     for (int d = kWave / 2; d > 0; d >>= 1) {
       const uint32_t lo_w = __shfl_down((uint32_t)v, d, kWave), hi_w = __shfl_down((uint32_t)(v >> 32), d, kWave);
       v += (uint64_t)lo_w | ((uint64_t)hi_w << 32);
+      live_groups += __shfl_down(live_groups, d, kWave);
     }
-    if (threadIdx.x == 0) range_base = v;
+    if (threadIdx.x == 0) {
+      range_base = v;
+      // how many groups hold an id at all: the backward's epilogue / finalize pick their sparse or dense form by it
+      if (range == ranges - 1) plan.counts[G] = live_groups + (uint32_t)plan.rtot[ranges + range];
+    }
   }
   __syncthreads();
   const uint64_t base = range_base;
@@ -1136,9 +1151,18 @@ __global__ __launch_bounds__(NWB * 64) void fast3_dg2_reduce_kernel(GroupPlan pl
 #define TTEMB_EPI_SLICES 16
 #endif
 constexpr int kEpiSlices = TTEMB_EPI_SLICES;   // target number of i0 slices (dG1 slabs)
-template <int Q0, int Q1, int Q2, int R1, int R2>
-__global__ __launch_bounds__(64) void fast3_group_epilogue_kernel(
-    const float* __restrict__ G0, const float* __restrict__ G1, uint32_t p0, uint32_t p1, uint32_t gpw, GroupPlan plan) {
+// fewer than three quarters of the groups hold an id (count left in counts[G] by the grouping pass): wave-uniform
+__device__ __forceinline__ bool sparse_groups(const GroupPlan& plan, uint32_t G) {
+  return __builtin_amdgcn_readfirstlane(plan.counts[G]) * 4u < 3u * G;
+}
+
+// SKIP: walk only the batches that hold an id and leave the dG0 parts of the others unwritten (the finalize kernel
+// then skips them by their counts) -- the form for frontiers that touch a small share of the groups.  Without SKIP
+// the loop is the plain counted one, and every group gets a part (zeros for an empty one).
+template <int Q0, int Q1, int Q2, int R1, int R2, bool SKIP>
+__device__ __forceinline__ void epilogue_unit(
+    const float* __restrict__ G0, const float* __restrict__ G1, uint32_t p0, uint32_t p1, uint32_t gpw, const GroupPlan& plan,
+    float* dpbuf, float* g1buf) {
   using C = Cfg<Q0, Q1, Q2, R1, R2>;
   constexpr int GM = 16 / Q0;            // groups per batch: their q0 rows fill one 16-row MFMA tile
   constexpr int LDD = C::N1 + 4;         // row stride of the staged dP rows (16-byte aligned rows)
@@ -1147,8 +1171,6 @@ __global__ __launch_bounds__(64) void fast3_group_epilogue_kernel(
   constexpr int NLB = (BF4 + kWave - 1) / kWave;
   constexpr int KS3 = C::N1 / 4;
   static_assert(16 % Q0 == 0 && C::N1 % 4 == 0, "q0 must divide the MFMA tile height");
-  __shared__ __attribute__((aligned(16))) float dpbuf[16 * LDD];
-  __shared__ __attribute__((aligned(16))) float g1buf[R1 * C::LDG];
   const int lane = threadIdx.x;
   const int hi = lane >> 4, lo = lane & 15;
   const uint32_t i1 = blockIdx.y;
@@ -1191,7 +1213,20 @@ __global__ __launch_bounds__(64) void fast3_group_epilogue_kernel(
             r_g0, (on && 16 * t + lo < R1) ? (i0_begin + gi) * (uint32_t)(C::ROW0 * 4) + 4u * ((rho % Q0) * R1 + 16 * t + lo) : kOob));
     }
   };
-  request(0);
+  // only batches that hold an id are walked (a METIS-ordered frontier touches a few per cent of the groups; their
+  // dG0 parts are neither computed nor stored, and the finalize kernel skips them by their counts)
+  auto next_live = [&](uint32_t k) {   // first batch start >= k with a non-empty group, or past the slice
+    if constexpr (SKIP) {
+      while (k < gpw && !((live >> k) & ((1ull << GM) - 1ull))) k += GM;
+    }
+    return k;
+  };
+  if constexpr (SKIP) {   // a slice without ids leaves no slab and no parts: one flag says so
+    if (lane == 0) plan.epi_live[(size_t)blockIdx.x * p1 + i1] = live != 0ull ? 1u : 0u;
+    if (live == 0ull) return;
+  }
+  const uint32_t k_first = next_live(0);
+  request(k_first);
   {
     // G1[i1] -> LDS (also for a slice without ids: 0 x stale LDS could be NaN): all loads first -- a load / wait /
     // store per piece would serialise ~20 L2 round trips
@@ -1210,7 +1245,7 @@ __global__ __launch_bounds__(64) void fast3_group_epilogue_kernel(
     }
   }
   const uint32_t n_here = i0_end - i0_begin;
-  for (uint32_t k0 = 0; k0 < n_here; k0 += GM) {
+  for (uint32_t k0 = k_first; k0 < n_here;) {
     // the batch's stacked dP -> LDS [rho][n]
     float g0v[4][C::RT1];
 #pragma unroll
@@ -1223,7 +1258,8 @@ __global__ __launch_bounds__(64) void fast3_group_epilogue_kernel(
 #pragma unroll
       for (int t = 0; t < C::RT1; ++t) g0v[s][t] = nxt_g0[s][t];
     __builtin_amdgcn_sched_barrier(0);
-    request(k0 + GM);
+    const uint32_t k_next = next_live(k0 + GM);
+    request(k_next);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();  // one wavefront per workgroup: LDS hand-over only (a __syncthreads would also drain the prefetch)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1262,7 +1298,7 @@ __global__ __launch_bounds__(64) void fast3_group_epilogue_kernel(
 #pragma unroll
       for (int t = 0; t < C::RT1; ++t)
         g0part[s & 3][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[s], b3[s][t], g0part[s & 3][t], 0, 0, 0);
-    // every group's contribution to dG0 (zeros for an empty group): summed over i1 by fast3_finalize_kernel.
+    // the contribution of every group of this batch to dG0 (zeros for an empty group next to a live one): summed over i1 by fast3_finalize_kernel.
     // accumulator row 4 hi + r = rho = (group rho / q0, core row rho % q0), column c = 16 t + lo
 #pragma unroll
     for (int t = 0; t < C::RT1; ++t) {
@@ -1275,6 +1311,7 @@ __global__ __launch_bounds__(64) void fast3_group_epilogue_kernel(
         buf_store1(r_part, on ? (g_begin + gi) * (uint32_t)(C::ROW0 * 4) + 4u * ((rho % Q0) * R1 + 16 * t + lo) : kOob, sum[r]);
       }
     }
+    k0 = k_next;
   }
   // this slice's dG1[i1] slab: every element is written (zeros when the slice holds no id)
   float* dst = plan.g1part + ((size_t)blockIdx.x * p1 + i1) * C::ROW1;
@@ -1287,6 +1324,18 @@ __global__ __launch_bounds__(64) void fast3_group_epilogue_kernel(
         const int c = 16 * t + 4 * hi + r;
         if (c < R1) dst[c * C::N1 + 16 * nt + lo] = g1acc[t][nt][r];
       }
+}
+
+template <int Q0, int Q1, int Q2, int R1, int R2>
+__global__ __launch_bounds__(64) void fast3_group_epilogue_kernel(
+    const float* __restrict__ G0, const float* __restrict__ G1, uint32_t p0, uint32_t p1, uint32_t gpw, GroupPlan plan) {
+  using C = Cfg<Q0, Q1, Q2, R1, R2>;
+  __shared__ __attribute__((aligned(16))) float dpbuf[16 * (C::N1 + 4)];
+  __shared__ __attribute__((aligned(16))) float g1buf[R1 * C::LDG];
+  if (sparse_groups(plan, p0 * p1))
+    epilogue_unit<Q0, Q1, Q2, R1, R2, true>(G0, G1, p0, p1, gpw, plan, dpbuf, g1buf);
+  else
+    epilogue_unit<Q0, Q1, Q2, R1, R2, false>(G0, G1, p0, p1, gpw, plan, dpbuf, g1buf);
 }
 
 // D. finalize (and, in the fused modes, the optimiser step: every core element is produced exactly once here, so
@@ -1314,6 +1363,7 @@ __global__ __launch_bounds__(256) void fast3_finalize_kernel(GroupPlan plan, int
   const int x = threadIdx.x & 31, y = threadIdx.x >> 5;
   const int e = blockIdx.x * 32 + x;
   const int n0 = p0 * row0;
+  const bool sparse = sparse_groups(plan, (uint32_t)(p0 * p1));   // the form the epilogue kernel took
   float s = 0.f;
   // U independent partial sums per thread keep that many loads in flight (a single running sum issues them one by one)
   constexpr int U = 4;
@@ -1333,7 +1383,10 @@ __global__ __launch_bounds__(256) void fast3_finalize_kernel(GroupPlan plan, int
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int g = (i1 + 8 * u) * p0 + i0;
-        if (i1 + 8 * u < p1) a[u] += plan.g0part[(size_t)g * row0 + c];   // empty groups hold zeros
+        if (i1 + 8 * u < p1) {
+          if (!sparse) a[u] += plan.g0part[(size_t)g * row0 + c];   // every group has a part (zeros for an empty one)
+          else if (plan.counts[g] != 0u) a[u] += plan.g0part[(size_t)g * row0 + c];   // empty groups have none
+        }
       }
     }
     s = (a[0] + a[1]) + (a[2] + a[3]);
@@ -1343,7 +1396,11 @@ __global__ __launch_bounds__(256) void fast3_finalize_kernel(GroupPlan plan, int
     for (int t = y; t < slices; t += 8 * U) {
 #pragma unroll
       for (int u = 0; u < U; ++u)
-        if (t + 8 * u < slices) a[u] += plan.g1part[(size_t)(t + 8 * u) * g1_floats + o];
+        if (t + 8 * u < slices) {
+          if (!sparse) a[u] += plan.g1part[(size_t)(t + 8 * u) * g1_floats + o];
+          else if (plan.epi_live[(size_t)(t + 8 * u) * p1 + o / (g1_floats / p1)] != 0u)   // slices without ids wrote nothing
+            a[u] += plan.g1part[(size_t)(t + 8 * u) * g1_floats + o];
+        }
     }
     s = (a[0] + a[1]) + (a[2] + a[3]);
   }
@@ -1500,7 +1557,7 @@ static int64_t carve_workspace(const DevShape& s, int64_t nnz, bool bwd, bool pl
     uint32_t* rs = (uint32_t*)take((sort_ranges(G) + 1) * 4);
     uint32_t* rc = (uint32_t*)take(sort_ranges(G) * 4);
     uint64_t* lp = (uint64_t*)take(G * 8);
-    uint64_t* rt = (uint64_t*)take(sort_ranges(G) * 8);
+    uint64_t* rt = (uint64_t*)take(sort_ranges(G) * 16);
     if (pl) {
       pl->grp_in = in[0];
       pl->i2_in = in[1];
@@ -1521,8 +1578,10 @@ static int64_t carve_workspace(const DevShape& s, int64_t nnz, bool bwd, bool pl
     float* g2 = (float*)take(reduce_tiles(nnz) * (int64_t)s.p[2] * s.row_len[2] * 4);
     float* g0 = (float*)take(G * (int64_t)s.row_len[0] * 4);
     float* g1 = (float*)take((int64_t)epi_slices(s) * s.p[1] * s.row_len[1] * 4);
+    uint32_t* el = (uint32_t*)take((int64_t)epi_slices(s) * s.p[1] * 4);
     if (pl) {
       pl->g1part = g1;
+      pl->epi_live = el;
       pl->etab = e;
       pl->dptab = d;
       pl->g2part = g2;
