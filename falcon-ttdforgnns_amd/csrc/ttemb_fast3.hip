@@ -1361,48 +1361,63 @@ __global__ __launch_bounds__(256) void fast3_finalize_kernel(GroupPlan plan, int
                                                              float* __restrict__ dG2, FusedUpdate upd) {
   __shared__ float part[8][33];
   const int x = threadIdx.x & 31, y = threadIdx.x >> 5;
-  const int e = blockIdx.x * 32 + x;
   const int n0 = p0 * row0;
   const bool sparse = sparse_groups(plan, (uint32_t)(p0 * p1));   // the form the epilogue kernel took
+  // dG1 has few terms per output (one per slice): one thread per output, 256 outputs per workgroup, the workgroups
+  // after those of dG2 / dG0 (eight threads per output as below made 8x the workgroups for the largest of the cores)
+  const int wg_a = (g2_floats + n0 + 31) / 32;
+  if ((int)blockIdx.x >= wg_a) {
+    const int o = ((int)blockIdx.x - wg_a) * 256 + (int)threadIdx.x;
+    if (o >= g1_floats) return;
+    const int i1 = o / (g1_floats / p1);
+    float tot = 0.f;
+    for (int t = 0; t < slices; t += 8) {
+      bool on[8];
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)   // slices without ids wrote nothing (sparse form)
+        on[u] = t + u < slices && (!sparse || plan.epi_live[(size_t)(t + u) * p1 + i1] != 0u);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = on[u] ? plan.g1part[(size_t)(t + u) * g1_floats + o] : 0.f;
+      tot += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    finalize_emit(upd, 1, dG1, o, tot);
+    return;
+  }
+  const int e = blockIdx.x * 32 + x;
   float s = 0.f;
   // U independent partial sums per thread keep that many loads in flight (a single running sum issues them one by one)
   constexpr int U = 4;
   if (e < g2_floats) {
-    float a[U] = {0.f, 0.f, 0.f, 0.f};
-    for (int t = y; t < tiles; t += 8 * U) {
+    // the loads of a step go into registers first, then into the sum (accumulating load by load made every one of
+    // them wait for the one before: the slabs were written on other XCDs, each dependent step is a trip to memory;
+    // 8 per step measured best, 32 thrashes on shapes with hundreds of tiles)
+    constexpr int U2 = 8;
+    for (int t = y; t < tiles; t += 8 * U2) {
+      float v[U2];
 #pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (t + 8 * u < tiles) a[u] += plan.g2part[(size_t)(t + 8 * u) * g2_floats + e];
+      for (int u = 0; u < U2; ++u) v[u] = t + 8 * u < tiles ? plan.g2part[(size_t)(t + 8 * u) * g2_floats + e] : 0.f;
+#pragma unroll
+      for (int u = 0; u < U2; u += 4) s += (v[u] + v[u + 1]) + (v[u + 2] + v[u + 3]);
     }
-    s = (a[0] + a[1]) + (a[2] + a[3]);
   } else if (e < g2_floats + n0) {
     const int o = e - g2_floats;
     const int i0 = o / row0, c = o - i0 * row0;
-    float a[U] = {0.f, 0.f, 0.f, 0.f};
     for (int i1 = y; i1 < p1; i1 += 8 * U) {
+      bool on[U];
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {   // dense form: every group has a part (zeros for an empty one); sparse: empty groups have none
+        const int g = (i1 + 8 * u) * p0 + i0;
+        on[u] = i1 + 8 * u < p1 && (!sparse || plan.counts[g] != 0u);
+      }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int g = (i1 + 8 * u) * p0 + i0;
-        if (i1 + 8 * u < p1) {
-          if (!sparse) a[u] += plan.g0part[(size_t)g * row0 + c];   // every group has a part (zeros for an empty one)
-          else if (plan.counts[g] != 0u) a[u] += plan.g0part[(size_t)g * row0 + c];   // empty groups have none
-        }
+        v[u] = on[u] ? plan.g0part[(size_t)g * row0 + c] : 0.f;
       }
+      s += (v[0] + v[1]) + (v[2] + v[3]);
     }
-    s = (a[0] + a[1]) + (a[2] + a[3]);
-  } else if (e < g2_floats + n0 + g1_floats) {
-    const int o = e - g2_floats - n0;
-    float a[U] = {0.f, 0.f, 0.f, 0.f};
-    for (int t = y; t < slices; t += 8 * U) {
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (t + 8 * u < slices) {
-          if (!sparse) a[u] += plan.g1part[(size_t)(t + 8 * u) * g1_floats + o];
-          else if (plan.epi_live[(size_t)(t + 8 * u) * p1 + o / (g1_floats / p1)] != 0u)   // slices without ids wrote nothing
-            a[u] += plan.g1part[(size_t)(t + 8 * u) * g1_floats + o];
-        }
-    }
-    s = (a[0] + a[1]) + (a[2] + a[3]);
   }
   part[y][x] = s;
   __syncthreads();
@@ -1417,8 +1432,6 @@ __global__ __launch_bounds__(256) void fast3_finalize_kernel(GroupPlan plan, int
       finalize_emit(upd, 2, dG2, i2 * row2 + c2 * q2 + kk, tot);
     } else if (e < g2_floats + n0) {
       finalize_emit(upd, 0, dG0, e - g2_floats, tot);
-    } else if (e < g2_floats + n0 + g1_floats) {
-      finalize_emit(upd, 1, dG1, e - g2_floats - n0, tot);
     }
   }
 }
@@ -1752,8 +1765,8 @@ static int run_backward(const DevShape& s, const CorePtrs& cores, const GroupPla
   if (rc) return rc;
   {
     const int g2_floats = s.p[2] * C::ROW2, g1_floats = s.p[1] * C::ROW1;
-    const int outs = g2_floats + s.p[0] * C::ROW0 + g1_floats;
-    hipLaunchKernelGGL(fast3_finalize_kernel, dim3((unsigned)((outs + 31) / 32)), dim3(256), 0, st, plan, tiles, slices,
+    const int wgs = (g2_floats + s.p[0] * C::ROW0 + 31) / 32 + (g1_floats + 255) / 256;   // dG2 | dG0, then dG1
+    hipLaunchKernelGGL(fast3_finalize_kernel, dim3((unsigned)wgs), dim3(256), 0, st, plan, tiles, slices,
                        s.p[0], s.p[1], g2_floats, (int)C::ROW0, g1_floats, Q2, R2, d_cores.c[0], d_cores.c[1], d_cores.c[2], upd);
   }
   profile_end(1, st);

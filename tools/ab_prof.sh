@@ -5,6 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for lib in $R/falcon-ttdforgnns_amd/lib/libttemb_*.so; do
   tag=abp_$(basename $lib .so)
+  rm -rf $R/gpurun_out/$tag
   TTEMB_LIB=$lib rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$tag -- python3 $R/tools/kbench.py "$@" > $R/gpurun_out/$tag.log 2>&1
   echo "== $(basename $lib)"
   python3 - <<PY
