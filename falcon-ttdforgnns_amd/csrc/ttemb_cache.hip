@@ -249,10 +249,20 @@ __global__ __launch_bounds__(kPartThreads) void partition_scatter_kernel(int64_t
   if (wave == 0) {
     int64_t v = 0;
     int dups = 0;
-    for (int64_t b = lane; b < (int64_t)blockIdx.x + (last ? 1 : 0); b += kWave) {
-      const int32_t c = blockcnt[b];
-      if (b < (int64_t)blockIdx.x) v += c & 0x7fffffff;
-      dups |= c < 0;
+    const int64_t nb = (int64_t)blockIdx.x + (last ? 1 : 0);
+    for (int64_t b0 = 0; b0 < nb; b0 += 8 * kWave) {   // eight loads per lane in flight, then the sums
+      int32_t c[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int64_t b = b0 + k * kWave + lane;
+        c[k] = b < nb ? blockcnt[b] : 0;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int64_t b = b0 + k * kWave + lane;
+        if (b < (int64_t)blockIdx.x) v += c[k] & 0x7fffffff;
+        dups |= c[k] < 0;
+      }
     }
     if (last && nnz_tt != nullptr && write_dups) {
       const unsigned long long any = __ballot(dups != 0);

@@ -394,9 +394,19 @@ __device__ __forceinline__ void place_range(const uint32_t range, const uint32_t
   if (threadIdx.x < kWave) {   // (ids, chunks) of the ranges before this one
     uint64_t v = 0;
     uint32_t live_groups = 0;
-    for (uint32_t r = threadIdx.x; r < range; r += kWave) {
-      v += plan.rtot[r];
-      if (range == ranges - 1) live_groups += (uint32_t)plan.rtot[ranges + r];
+    // all loads of the lane first (ranges <= kMaxRanges = 8 * 64), then the sums: a running sum would wait for
+    // every load before issuing the next
+    uint64_t tv[kMaxRanges / kWave], lv[kMaxRanges / kWave];
+#pragma unroll
+    for (int k = 0; k < kMaxRanges / kWave; ++k) {
+      const uint32_t r = threadIdx.x + k * kWave;
+      tv[k] = r < range ? plan.rtot[r] : 0ull;
+      lv[k] = (range == ranges - 1 && r < range) ? plan.rtot[ranges + r] : 0ull;
+    }
+#pragma unroll
+    for (int k = 0; k < kMaxRanges / kWave; ++k) {
+      v += tv[k];
+      live_groups += (uint32_t)lv[k];
     }
 #pragma unroll
     for (int d = kWave / 2; d > 0; d >>= 1) {
