@@ -246,6 +246,19 @@ def main():
             cached = {"ids": N, "ms_per_step": round(dt * 1e3, 4), "lookups_per_s": round(N / dt, 1),
                       "cache_rows": int(cemb.cache_weight.shape[0]), "hit_rate": round(hit, 3)}
             del cemb
+        # second half of BASELINE.json's metric: SAGE epoch time on the products shapes.  DGL / OGB are not in the
+        # image, so the epoch is tools/sage_epoch.py's restatement of sage_dgl_partition.py:train() around the TT
+        # layer (synthetic 2.45 M-node graph, fan-out 5/10/15, batch 2048, 3 mean-SAGE layers in stock PyTorch,
+        # 196 615 train nodes = 97 steps); the second epoch is reported
+        epoch = None
+        if world == 1 and not args.no_extras:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import sage_epoch
+            ea = argparse.Namespace(nodes=N_EMB, avg_degree=25, locality=0.5, train_nodes=196615, batch=2048,
+                                    fan_out="5,10,15", hidden=256, classes=47, emb="tt", epochs=2, max_steps=0)
+            epoch = sage_epoch.run(ea, quiet=True)
+            epoch["what"] = ("synthetic graph + sampler + 3 mean-SAGE layers in stock PyTorch around TTEmbeddingBag "
+                             "(tools/sage_epoch.py), second epoch")
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             from oracle import cpu_einsum
@@ -265,7 +278,7 @@ def main():
                        "p": P, "q": Q, "tt_ranks": RANKS, "num_embeddings": N_EMB, "ids_per_gpu_step": N,
                        "parallelism": f"dp{world}", "kernel_path": args.path},
             "roofline": roofline, "cpu_baseline": cpu, "batch2048_step": small, "metis_like_step": local,
-            "cache_on_step": cached,
+            "cache_on_step": cached, "sage_epoch": epoch,
         }
     if world > 1:
         dist.barrier()

@@ -94,14 +94,19 @@ def main():
     ap.add_argument("--emb", default="tt", choices=["tt", "dense"])
     ap.add_argument("--epochs", type=int, default=2)
     ap.add_argument("--max-steps", type=int, default=0)
-    a = ap.parse_args()
-    dev = torch.device("cuda", 0)
+    run(ap.parse_args())
+
+
+def run(a, quiet=False):
+    """Runs the harness; returns the statistics of the last epoch (bench.py's `sage_epoch` leg calls this)."""
+    say = (lambda *x, **k: None) if quiet else print
+    dev = torch.device("cuda", torch.cuda.current_device())
     gen = torch.Generator(device=dev).manual_seed(0)
     fanouts = [int(x) for x in a.fan_out.split(",")]
     t0 = time.perf_counter()
     indptr, indices = build_graph(a.nodes, a.avg_degree, a.locality, dev, gen)
     torch.cuda.synchronize()
-    print(f"graph: {a.nodes} nodes, {indices.numel()} edges, built in {time.perf_counter() - t0:.1f} s", flush=True)
+    say(f"graph: {a.nodes} nodes, {indices.numel()} edges, built in {time.perf_counter() - t0:.1f} s", flush=True)
     train = torch.randperm(a.nodes, device=dev, generator=gen)[: a.train_nodes]
     labels = torch.randint(0, a.classes, (a.nodes,), device=dev, generator=gen)
     D = 100
@@ -160,8 +165,12 @@ def main():
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
         msg = ", ".join(f"{k} {v / steps:.2f} ms" for k, v in split.items())
-        print(f"epoch {epoch}: {steps} steps in {wall:.2f} s ({wall / steps * 1e3:.1f} ms/step, "
-              f"{frontier / steps:.0f} frontier ids/step, loss {loss.item():.3f}); per step: {msg}", flush=True)
+        say(f"epoch {epoch}: {steps} steps in {wall:.2f} s ({wall / steps * 1e3:.1f} ms/step, "
+            f"{frontier / steps:.0f} frontier ids/step, loss {loss.item():.3f}); per step: {msg}", flush=True)
+        stats = {"epoch_s": round(wall, 3), "steps": steps, "ms_per_step": round(wall / steps * 1e3, 3),
+                 "frontier_ids_per_step": int(frontier / steps),
+                 "split_ms": {k: round(v / steps, 3) for k, v in split.items()}}
+    return stats
 
 
 if __name__ == "__main__":
