@@ -18,7 +18,10 @@ CFG = {"products": ([125, 140, 140], [4, 5, 5], [1, 16, 16, 1], 2449029),
        # the reference's run scripts: ogbn-arxiv / D = 128 at rank 16 on the products factorisation
        "arxiv_r16": ([125, 140, 140], [4, 4, 8], [1, 16, 16, 1], 2449029),
        "q844_r16": ([125, 140, 140], [8, 4, 4], [1, 16, 16, 1], 2449029),
-       "products_r32": ([125, 140, 140], [4, 5, 5], [1, 32, 32, 1], 2449029)}
+       "products_r32": ([125, 140, 140], [4, 5, 5], [1, 32, 32, 1], 2449029),
+       # 4-core shapes of the run scripts (generic kernels only)
+       "arxiv_4core": ([50, 60, 60, 60], [2, 4, 4, 4], [1, 16, 16, 16, 1], 10800000),
+       "products_4core": ([50, 60, 60, 60], [5, 5, 2, 2], [1, 16, 16, 16, 1], 10800000)}
 
 
 def main():
@@ -36,7 +39,7 @@ def main():
     shape = nat.make_shape(p, q, R)
     rng = np.random.default_rng(0)
     cores = [torch.tensor((rng.standard_normal((p[t], R[t] * q[t] * R[t + 1])) * 0.3).astype(np.float32)).cuda()
-             for t in range(3)]
+             for t in range(len(p))]
     ws = nat.Workspace()
     nat.profile_enable(True)
     for N in a.n:
