@@ -222,6 +222,46 @@ def test_hash_table_matches_oracle_bit_exactly(ops, orc):
     assert np.array_equal(out_loc.cpu().numpy()[ntt:], ploc[ntt:])
 
 
+@pytest.mark.parametrize("n_ids,bags", [(70000, "single"), (50003, "ragged"), (257, "ragged"), (256, "single")])
+def test_partition_of_many_blocks_is_bit_exact(ops, orc, n_ids, bags):
+    """ttemb_preprocess on batches that span hundreds of 256-id blocks (per-block counts, prefix over the blocks
+    before, ballot ranks inside a block): partitioned ids / bags / cache rows in exactly the order the oracle's
+    restatement of cub::DevicePartition::Flagged gives, and the duplicate flag."""
+    import ttemb_native as nat
+    rng = np.random.default_rng(n_ids)
+    H, C = 40000, 6000
+    keys = np.full(H, -1, dtype=np.int64)
+    freq = np.zeros(H, dtype=np.int64)
+    universe = rng.choice(10 ** 7, size=12000, replace=False).astype(np.int64)
+    orc.update_cache_state(np.repeat(universe, rng.integers(1, 4, size=universe.shape[0])), keys, freq)
+    state = np.full(H, -1, dtype=np.int32)
+    orc.cache_populate(keys, freq, state, C)
+    cached_ids = keys[state >= 0]
+    ids = np.where(rng.random(n_ids) < 0.4, rng.choice(cached_ids, size=n_ids), rng.integers(0, 10 ** 7, size=n_ids))
+    unique_cached = len(set(ids[np.isin(ids, cached_ids)].tolist())) == int(np.isin(ids, cached_ids).sum())
+    if bags == "single":
+        offs = np.arange(n_ids + 1, dtype=np.int64)
+    else:
+        lens = rng.integers(0, 5, size=n_ids)
+        lens = lens[np.cumsum(lens) <= n_ids]
+        lens[-1] += n_ids - lens.sum()
+        offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    B = offs.shape[0] - 1
+    t_ids, t_offs = torch.tensor(ids).cuda(), torch.tensor(offs).cuda()
+    out_idx, out_row = torch.empty_like(t_ids), torch.empty_like(t_ids)
+    out_loc = torch.empty(n_ids, dtype=torch.int32, device="cuda")
+    count = torch.full((2,), -5, dtype=torch.int32, device="cuda")
+    stamp = torch.zeros(C, dtype=torch.int32, device="cuda")
+    nat.preprocess(t_ids, t_offs, B, False, torch.tensor(keys).cuda(), torch.tensor(state).cuda(), out_idx, out_row,
+                   out_loc, count, nat.Workspace(), stamp, 9)
+    pi, pr, ntt, ploc = orc.preprocess_indices(ids, offs, False, keys, state)
+    assert count.cpu().tolist() == [ntt, 0 if unique_cached else 1]
+    assert 0 < ntt < n_ids
+    assert np.array_equal(out_idx.cpu().numpy(), pi)
+    assert np.array_equal(out_row.cpu().numpy(), pr)
+    assert np.array_equal(out_loc.cpu().numpy()[ntt:], ploc[ntt:])
+
+
 @pytest.mark.parametrize("sparse", [False, True])
 def test_cache_lifecycle_keeps_forward_and_trains(ops, orc, sparse):
     torch.manual_seed(7)
