@@ -224,3 +224,17 @@ def test_prefix_locality_metric():
     assert u["ids"] == 40960 and w["ids"] == 41000
     assert w["distinct_prefixes"] <= 3 * 205 and w["ids_per_prefix"] > 20 * u["ids_per_prefix"]
     assert ttemb_init.prefix_locality(torch.empty(0, dtype=torch.long), p)["distinct_prefixes"] == 0
+
+
+def test_product_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under the package (Python or HIP sources) may import, call or even
+    name it; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do."""
+    import pathlib
+    root = pathlib.Path(__file__).resolve().parents[1]
+    offenders = []
+    for path in (root / "falcon-ttdforgnns_amd").rglob("*"):
+        if path.suffix in (".py", ".hip", ".h", ".cpp") and "oracle" in path.read_text(errors="ignore"):
+            offenders.append(str(path.relative_to(root)))
+    assert offenders == []
+    bench = (root / "bench.py").read_text()
+    assert bench.count("from oracle import") == 1 and "cpu_einsum" in bench   # the cpu_baseline leg only
