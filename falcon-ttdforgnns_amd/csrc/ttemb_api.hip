@@ -113,6 +113,31 @@ __global__ void zero_words_kernel(uint32_t* __restrict__ p, size_t n) {
   }
 }
 
+struct ZeroSegs {
+  uint32_t* p[TTEMB_MAX_CORES];
+  size_t n[TTEMB_MAX_CORES];   // words
+};
+
+__global__ void zero_segments_kernel(ZeroSegs z, int T) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (int t = 0; t < T; ++t)
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < z.n[t]; i += stride) z.p[t][i] = 0u;
+}
+
+int launch_zero_cores(const DevShape& s, const CorePtrsMut& d_cores, hipStream_t st) {
+  ZeroSegs z;
+  size_t most = 0;
+  for (int t = 0; t < TTEMB_MAX_CORES; ++t) {
+    z.p[t] = t < s.T ? reinterpret_cast<uint32_t*>(d_cores.c[t]) : nullptr;
+    z.n[t] = t < s.T ? (size_t)s.p[t] * s.row_len[t] : 0;
+    most = z.n[t] > most ? z.n[t] : most;
+  }
+  if (most == 0) return TTEMB_OK;
+  const size_t blocks = (most + 255) / 256;
+  hipLaunchKernelGGL(zero_segments_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, st, z, s.T);
+  return check_hip(hipGetLastError(), "zero d_cores");
+}
+
 int launch_zero(void* p, size_t bytes, hipStream_t st, const char* what) {
   if (bytes == 0) return TTEMB_OK;
   const size_t n = bytes / 4;
@@ -237,10 +262,7 @@ static int resolve_rowidx(const int64_t** rowidx, const int64_t* offsets, int64_
   }
   if (*rowidx != nullptr || nnz == 0) return TTEMB_OK;
   if (offsets == nullptr) return fail(TTEMB_E_BADARG, "rowidx and offsets are both null");
-  if (rows_in_plan) return TTEMB_OK;  // the fast path derives rows from `offsets` while it groups the ids
-  int rc = launch_rowidx(offsets, B, nnz, reinterpret_cast<int64_t*>(base), st);
-  *rowidx = reinterpret_cast<const int64_t*>(base);
-  return rc;
+  return TTEMB_OK;   // both kernel families derive the rows from `offsets` themselves (no expansion launch, no array)
 }
 
 // shared body of the three backward entry points: gradient of the live ids into `dst`
@@ -252,11 +274,9 @@ static int backward_into(const DevShape& ds, const CorePtrs& cp, const int64_t* 
     return launch_backward_fast3(ds, cp, indices, rowidx, offsets, nnz, nnz_dev, B, d_output, dst, ws, ws_bytes, plan,
                                  plan_bytes, st, update);
   if (current_path() == TTEMB_PATH_FAST3) return fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
-  for (int t = 0; t < ds.T; ++t) {
-    int rc = launch_zero(dst.c[t], (size_t)ds.p[t] * ds.row_len[t] * 4, st, "zero d_core");
-    if (rc) return rc;
-  }
-  return launch_backward_generic(ds, cp, indices, rowidx, nnz, nnz_dev, d_output, dst, st);
+  int rc = launch_zero_cores(ds, dst, st);
+  if (rc) return rc;
+  return launch_backward_generic(ds, cp, indices, rowidx, offsets, B, nnz, nnz_dev, d_output, dst, st);
 }
 
 }  // namespace ttemb
@@ -362,7 +382,7 @@ static int forward_phase(int phase, const ttemb_shape_t* shape, const float* con
     return launch_forward_fast3(ds, cp, indices, rowidx, offsets, nnz, nnz_dev, B, output, offsets != nullptr, workspace,
                                 workspace_bytes, plan, plan_bytes, phase, st);
   if (current_path() == TTEMB_PATH_FAST3) return fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
-  return launch_forward_generic(ds, cp, indices, rowidx, offsets, nnz, nnz_dev, output, st);
+  return launch_forward_generic(ds, cp, indices, rowidx, offsets, B, nnz, nnz_dev, output, st);
 }
 
 extern "C" {
@@ -544,7 +564,7 @@ int ttemb_cache_populate(const ttemb_shape_t* shape, const float* const* cores, 
   CorePtrs cp;
   for (int t = 0; t < TTEMB_MAX_CORES; ++t) cp.c[t] = t < ds.T ? cores[t] : nullptr;
   // rows of the C hottest ids straight into cache_weight (reference: prefetch in chunks of 200)
-  return launch_forward_generic(ds, cp, sorted_keys, nullptr, nullptr, C, nullptr, cache_weight, st);
+  return launch_forward_generic(ds, cp, sorted_keys, nullptr, nullptr, C, C, nullptr, cache_weight, st);
 }
 
 int ttemb_preprocess(const int64_t* indices, const int64_t* offsets, int64_t nnz, int64_t B,

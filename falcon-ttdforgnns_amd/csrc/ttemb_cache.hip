@@ -208,20 +208,6 @@ __global__ __launch_bounds__(kPartThreads) void cache_lookup_kernel(const int64_
   if (threadIdx.x == 0) blockcnt[blockIdx.x] = c | (d ? (int32_t)0x80000000 : 0);   // bit 31: a duplicate in this block
 }
 
-// bag of position n: the last b with offsets[b] <= n  (tt_embeddings_cuda.cu:1349-1365 expands the same map)
-__device__ __forceinline__ int64_t bag_of_position(const int64_t* __restrict__ offsets, int64_t B, int64_t n) {
-  if (n < B) {   // the usual case: every bag holds one id
-    const int64_t o0 = offsets[n], o1 = offsets[n + 1];
-    if (o0 <= n && n < o1) return n;
-  }
-  int64_t lo = 0, hi = B;  // invariant: offsets[lo] <= n < offsets[hi]
-  while (hi - lo > 1) {
-    const int64_t mid = (lo + hi) >> 1;
-    if (offsets[mid] <= n) lo = mid; else hi = mid;
-  }
-  return lo;
-}
-
 // selected (TT) items keep input order at the front; rejected (cached) items fill the
 // tail from the end backwards -- the order cub::DevicePartition::Flagged produces and
 // the reference's cache kernels therefore see (tt_embeddings_cuda.cu:1448-1490).

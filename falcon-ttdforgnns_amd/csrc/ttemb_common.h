@@ -45,11 +45,13 @@ void profile_end(int which, hipStream_t st);
 int64_t generic_fwd_lds_bytes(const DevShape& s);
 int64_t generic_bwd_lds_bytes(const DevShape& s);
 int launch_forward_generic(const DevShape& s, const CorePtrs& cores, const int64_t* indices,
-                           const int64_t* rowidx, const int64_t* offsets, int64_t nnz,
+                           const int64_t* rowidx, const int64_t* offsets, int64_t B, int64_t nnz,
                            const int32_t* nnz_dev, float* output, hipStream_t st);
 int launch_backward_generic(const DevShape& s, const CorePtrs& cores, const int64_t* indices,
-                            const int64_t* rowidx, int64_t nnz, const int32_t* nnz_dev,
-                            const float* d_output, const CorePtrsMut& d_cores, hipStream_t st);
+                            const int64_t* rowidx, const int64_t* offsets, int64_t B, int64_t nnz,
+                            const int32_t* nnz_dev, const float* d_output, const CorePtrsMut& d_cores, hipStream_t st);
+// zero-fills the T gradient cores in one launch
+int launch_zero_cores(const DevShape& s, const CorePtrsMut& d_cores, hipStream_t st);
 
 // fast 3-core path (ttemb_fast3.hip)
 bool fast3_supported(const DevShape& s);
@@ -90,6 +92,20 @@ __device__ __forceinline__ bool bag_is_single(const int64_t* __restrict__ rowidx
                                               int64_t row) {
   if (offsets != nullptr) return offsets[row + 1] - offsets[row] == 1;
   return (n == 0 || rowidx[n - 1] != row) && (n + 1 >= cnt || rowidx[n + 1] != row);
+}
+
+// bag of position n: the last b with offsets[b] <= n  (tt_embeddings_cuda.cu:1349-1365 expands the same map)
+__device__ __forceinline__ int64_t bag_of_position(const int64_t* __restrict__ offsets, int64_t B, int64_t n) {
+  if (n < B) {   // the usual case: every bag holds one id
+    const int64_t o0 = offsets[n], o1 = offsets[n + 1];
+    if (o0 <= n && n < o1) return n;
+  }
+  int64_t lo = 0, hi = B;  // invariant: offsets[lo] <= n < offsets[hi]
+  while (hi - lo > 1) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (offsets[mid] <= n) lo = mid; else hi = mid;
+  }
+  return lo;
 }
 
 __device__ __forceinline__ int64_t live_count(int64_t nnz, const int32_t* nnz_dev) {

@@ -31,7 +31,7 @@ int64_t generic_bwd_lds_bytes(const DevShape& s) {
 __global__ __launch_bounds__(64) void fwd_generic_kernel(DevShape s, CorePtrs cores,
                                                          const int64_t* __restrict__ indices,
                                                          const int64_t* __restrict__ rowidx,
-                                                         const int64_t* __restrict__ offsets,
+                                                         const int64_t* __restrict__ offsets, int64_t B,
                                                          int64_t nnz,
                                                          const int32_t* __restrict__ nnz_dev,
                                                          float* __restrict__ output) {
@@ -49,6 +49,9 @@ __global__ __launch_bounds__(64) void fwd_generic_kernel(DevShape s, CorePtrs co
     if (rowidx != nullptr) {
       row = rowidx[n];
       single = bag_is_single(rowidx, offsets, n, cnt, row);
+    } else if (offsets != nullptr) {   // rows straight from the bag boundaries: no rowidx launch, no rowidx array
+      row = bag_of_position(offsets, B, n);
+      single = offsets[row + 1] - offsets[row] == 1;
     }
     const float* g0 = cores.c[0] + (int64_t)it[0] * s.row_len[0];
     for (int e = lane; e < s.row_len[0]; e += kWave) buf0[e] = g0[e];
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(64) void fwd_generic_kernel(DevShape s, CorePtrs co
 }
 
 int launch_forward_generic(const DevShape& s, const CorePtrs& cores, const int64_t* indices,
-                           const int64_t* rowidx, const int64_t* offsets, int64_t nnz,
+                           const int64_t* rowidx, const int64_t* offsets, int64_t B, int64_t nnz,
                            const int32_t* nnz_dev, float* output, hipStream_t st) {
   if (nnz <= 0) return TTEMB_OK;
   const int64_t lds = generic_fwd_lds_bytes(s);
@@ -92,7 +95,7 @@ int launch_forward_generic(const DevShape& s, const CorePtrs& cores, const int64
   const int64_t grid = nnz < 262144 ? nnz : 262144;
   profile_begin(0, st);
   hipLaunchKernelGGL(fwd_generic_kernel, dim3((unsigned)grid), dim3(kWave), (size_t)lds, st, s,
-                     cores, indices, rowidx, offsets, nnz, nnz_dev, output);
+                     cores, indices, rowidx, offsets, B, nnz, nnz_dev, output);
   profile_end(0, st);
   return check_hip(hipGetLastError(), "fwd_generic_kernel");
 }
@@ -106,6 +109,7 @@ int launch_forward_generic(const DevShape& s, const CorePtrs& cores, const int64
 __global__ __launch_bounds__(64) void bwd_generic_kernel(DevShape s, CorePtrs cores,
                                                          const int64_t* __restrict__ indices,
                                                          const int64_t* __restrict__ rowidx,
+                                                         const int64_t* __restrict__ offsets, int64_t B,
                                                          int64_t nnz,
                                                          const int32_t* __restrict__ nnz_dev,
                                                          const float* __restrict__ d_output,
@@ -125,7 +129,7 @@ __global__ __launch_bounds__(64) void bwd_generic_kernel(DevShape s, CorePtrs co
   for (int64_t n = blockIdx.x; n < cnt; n += gridDim.x) {
     int it[TTEMB_MAX_CORES];
     split_index(s, indices[n], it);
-    const int64_t row = rowidx != nullptr ? rowidx[n] : n;
+    const int64_t row = rowidx != nullptr ? rowidx[n] : (offsets != nullptr ? bag_of_position(offsets, B, n) : n);
     // recompute the forward partials v[0..T-2]
     const float* g0 = cores.c[0] + (int64_t)it[0] * s.row_len[0];
     for (int e = lane; e < s.row_len[0]; e += kWave) v[0][e] = g0[e];
@@ -183,8 +187,8 @@ __global__ __launch_bounds__(64) void bwd_generic_kernel(DevShape s, CorePtrs co
 }
 
 int launch_backward_generic(const DevShape& s, const CorePtrs& cores, const int64_t* indices,
-                            const int64_t* rowidx, int64_t nnz, const int32_t* nnz_dev,
-                            const float* d_output, const CorePtrsMut& d_cores, hipStream_t st) {
+                            const int64_t* rowidx, const int64_t* offsets, int64_t B, int64_t nnz,
+                            const int32_t* nnz_dev, const float* d_output, const CorePtrsMut& d_cores, hipStream_t st) {
   if (nnz <= 0) return TTEMB_OK;
   const int64_t lds = generic_bwd_lds_bytes(s);
   if (lds > 64 * 1024) return fail(TTEMB_E_UNSUPPORTED, "backward partials of %lld bytes exceed the LDS budget", (long long)lds);
@@ -192,7 +196,7 @@ int launch_backward_generic(const DevShape& s, const CorePtrs& cores, const int6
   profile_begin(1, st);
   profile_begin(2, st);
   hipLaunchKernelGGL(bwd_generic_kernel, dim3((unsigned)grid), dim3(kWave), (size_t)lds, st, s,
-                     cores, indices, rowidx, nnz, nnz_dev, d_output, d_cores);
+                     cores, indices, rowidx, offsets, B, nnz, nnz_dev, d_output, d_cores);
   profile_end(2, st);
   profile_end(1, st);
   return check_hip(hipGetLastError(), "bwd_generic_kernel");
