@@ -485,8 +485,7 @@ template <int Q0, int Q1, int Q2, int R1, int R2>
 __device__ __forceinline__ void prefix_unit(const float* __restrict__ G0, const float* __restrict__ G1, uint32_t p0,
                                             const GroupPlan& plan, uint32_t i0_block, uint32_t i1, int lane) {
   using C = Cfg<Q0, Q1, Q2, R1, R2>;
-  constexpr int GM = 16 / Q0;  // groups per MFMA tile
-  static_assert(16 % Q0 == 0, "q0 must divide the MFMA tile height");
+  constexpr int GM = 16 / Q0;  // whole groups per 16-row MFMA tile (q0 = 5: three groups, the last tile row idles)
   const int hi = lane >> 4, lo = lane & 15;
   const uint32_t i0_begin = i0_block * kPrefixGroups;
   const uint32_t i0_end = i0_begin + kPrefixGroups < p0 ? i0_begin + kPrefixGroups : p0;
@@ -521,7 +520,7 @@ __device__ __forceinline__ void prefix_unit(const float* __restrict__ G0, const 
       const int row = 4 * hi + r;
       const uint32_t gi = base + row / Q0;
       const int a = row % Q0;
-      if (!((live >> gi) & 1ull)) continue;
+      if (row / Q0 >= GM || !((live >> gi) & 1ull)) continue;
       float* dst = plan.ptab + (size_t)(i1 * p0 + i0_begin + gi) * (C::M2 * R2);
 #pragma unroll
       for (int nt = 0; nt < C::NT1; ++nt) {
@@ -1180,7 +1179,7 @@ __device__ __forceinline__ void epilogue_unit(
   constexpr int BF4 = 16 * C::N1 / 4;    // float4 pieces of a batch's stacked dP
   constexpr int NLB = (BF4 + kWave - 1) / kWave;
   constexpr int KS3 = C::N1 / 4;
-  static_assert(16 % Q0 == 0 && C::N1 % 4 == 0, "q0 must divide the MFMA tile height");
+  static_assert(C::N1 % 4 == 0, "dP rows move as float4");
   const int lane = threadIdx.x;
   const int hi = lane >> 4, lo = lane & 15;
   const uint32_t i1 = blockIdx.y;
@@ -1208,15 +1207,15 @@ __device__ __forceinline__ void epilogue_unit(
     for (int it = 0; it < NLB; ++it) {
       const int e = it * kWave + lane;                  // float4 number e of the stacked [16][N1] block
       const uint32_t gi = k0 + (uint32_t)(4 * e / PF);  // the group it belongs to
-      const bool on = (BF4 % kWave == 0 || e < BF4) && gi < gpw && ((live >> gi) & 1ull);
-      nxt[it] = buf_load4(r_dp, on ? (g_begin + k0) * (uint32_t)(PF * 4) + 16u * e : kOob);
+      const bool on = (BF4 % kWave == 0 || e < BF4) && 4 * e / PF < GM && gi < gpw && ((live >> gi) & 1ull);   // tile rows past the
+      nxt[it] = buf_load4(r_dp, on ? (g_begin + k0) * (uint32_t)(PF * 4) + 16u * e : kOob);                    // GM whole groups stay zero
     }
     // A operand of the dG1 product: row c = 16 t + lo of G0^T, column rho = 4 s + hi = (group rho / q0, core row rho % q0)
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int rho = 4 * s + hi;
       const uint32_t gi = k0 + (uint32_t)(rho / Q0);
-      const bool on = gi < gpw && ((live >> gi) & 1ull);
+      const bool on = rho / Q0 < GM && gi < gpw && ((live >> gi) & 1ull);
 #pragma unroll
       for (int t = 0; t < C::RT1; ++t)
         nxt_g0[s][t] = __uint_as_float(buf_load1u(
@@ -1317,7 +1316,7 @@ __device__ __forceinline__ void epilogue_unit(
       for (int r = 0; r < 4; ++r) {
         const int rho = 4 * hi + r;
         const uint32_t gi = k0 + (uint32_t)(rho / Q0);
-        const bool on = gi < n_here && 16 * t + lo < R1;
+        const bool on = rho / Q0 < GM && gi < n_here && 16 * t + lo < R1;
         buf_store1(r_part, on ? (g_begin + gi) * (uint32_t)(C::ROW0 * 4) + 4u * ((rho % Q0) * R1 + 16 * t + lo) : kOob, sum[r]);
       }
     }
@@ -1451,7 +1450,8 @@ __global__ __launch_bounds__(256) void fast3_finalize_kernel(GroupPlan plan, int
 // ---------------------------------------------------------------------------------
 // The (q, ranks) shapes with an instantiated chain: the three BASELINE.json configurations first, then the other
 // 3-core shapes the reference's run scripts train with (q = 4,4,8 / 4,5,5 / 8,4,4 at rank 16; the rank sweep of
-// the products shape).  q0 has to divide the MFMA tile height, so q = 5,5,4 and 5,4,5 stay on the generic path.
+// the products shape).  q0 q1 has to be a multiple of the MFMA K and q1 r2 has to tile by 16, so q = 5,5,4 (and 4,5,5 at rank 8) stay on
+// the generic path.
 #define TTEMB_FAST3_SHAPES(X) \
   X(4, 5, 5, 16, 16)          \
   X(4, 4, 8, 8, 8)            \
@@ -1459,7 +1459,8 @@ __global__ __launch_bounds__(256) void fast3_finalize_kernel(GroupPlan plan, int
   X(4, 4, 8, 16, 16)          \
   X(8, 4, 4, 16, 16)          \
   X(4, 5, 5, 32, 32)          \
-  X(4, 4, 8, 32, 32)
+  X(4, 4, 8, 32, 32)          \
+  X(5, 4, 5, 16, 16)
 
 static bool shape_is(const DevShape& s, int q0, int q1, int q2, int r1, int r2) {
   return s.q[0] == q0 && s.q[1] == q1 && s.q[2] == q2 && s.R[1] == r1 && s.R[2] == r2;
