@@ -73,7 +73,7 @@ struct Cfg {
   static constexpr int BB_FLOATS = B_FLOATS > P_FLOATS ? B_FLOATS : P_FLOATS;
   static constexpr int DB_FLOATS = ((O_FLOATS > R1 * LDG ? O_FLOATS : R1 * LDG) + 3) / 4 * 4;
   static constexpr int BWD_WAVE_FLOATS = P_FLOATS + BB_FLOATS + DB_FLOATS;
-  static_assert(M2 % 4 == 0, "q0*q1 must be a multiple of the MFMA K");
+  static_assert(LDOB >= (M2 + 3) / 4 * 4 * Q2, "the padded K-step of the E product reads inside the staged row");
   static_assert(Q0 <= 16, "stage 1 pads q0 to one 16-row tile");
   static_assert(R1 % 4 == 0 && R2 % 4 == 0, "ranks must be multiples of the MFMA K");
   static_assert(N1 % 16 == 0, "q1*r2 must tile by 16");
@@ -698,14 +698,15 @@ __global__ __launch_bounds__(64) void fast3_forward_kernel(const float* __restri
         for (int nt = 0; nt < C::NT2; ++nt)
           acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[s][nt], s == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[nt], 0, 0, 0);
       }
-      // rows -> LDS, id-major.  q0 q1 is a multiple of 4, so a lane's four rows 16 mt + 4 hi + r are in or out together
-      if (16 * mt + 4 * hi + 3 < C::M2) {
+      // rows -> LDS, id-major.  When q0 q1 is a multiple of 4 a lane's four rows 16 mt + 4 hi + r are in or out together
+      if (16 * mt + 4 * hi + (C::M2 % 4 == 0 ? 3 : 0) < C::M2) {
 #pragma unroll
         for (int nt = 0; nt < C::NT2; ++nt) {
           const int n = 16 * nt + lo;
           const int b = n / Q2, kk = n % Q2;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) obuf[b * C::LDO + (16 * mt + 4 * hi + r) * Q2 + kk] = acc[nt][r];
+          for (int r = 0; r < 4; ++r)
+            if (C::M2 % 4 == 0 || 16 * mt + 4 * hi + r < C::M2) obuf[b * C::LDO + (16 * mt + 4 * hi + r) * Q2 + kk] = acc[nt][r];
         }
       }
     }
@@ -984,16 +985,19 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(const float* __rest
       for (int nt = 0; nt < C::NT2; ++nt) e[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #if !(defined(TTEMB_ABL) && (TTEMB_ABL & 8))
 #pragma unroll
-    for (int s = 0; s < C::M2 / 4; ++s) {
+    for (int s = 0; s < (C::M2 + 3) / 4; ++s) {
+      // q0 q1 not a multiple of the MFMA K: the last step's rows past M2 are read (inside the buffers) and zeroed
+      const bool k_ok = 4 * s + 3 < C::M2 || 4 * s + hi < C::M2;
       float av[C::RT2];
 #pragma unroll
       for (int t = 0; t < C::RT2; ++t) {
         av[t] = pbuf[(4 * s + hi) * C::LDPB + (16 * t + lo) % R2];
-        if (16 * t + lo >= R2) av[t] = 0.f;
+        if (16 * t + lo >= R2 || !k_ok) av[t] = 0.f;
       }
 #pragma unroll
       for (int nt = 0; nt < C::NT2; ++nt) {
-        const float bv = dbuf[offE[nt] + 4 * s * Q2];
+        float bv = dbuf[offE[nt] + 4 * s * Q2];
+        if (!k_ok) bv = 0.f;
 #pragma unroll
         for (int t = 0; t < C::RT2; ++t)
           e[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv, e[t][nt], 0, 0, 0);
@@ -1450,8 +1454,7 @@ __global__ __launch_bounds__(256) void fast3_finalize_kernel(GroupPlan plan, int
 // ---------------------------------------------------------------------------------
 // The (q, ranks) shapes with an instantiated chain: the three BASELINE.json configurations first, then the other
 // 3-core shapes the reference's run scripts train with (q = 4,4,8 / 4,5,5 / 8,4,4 at rank 16; the rank sweep of
-// the products shape).  q0 q1 has to be a multiple of the MFMA K and q1 r2 has to tile by 16, so q = 5,5,4 (and 4,5,5 at rank 8) stay on
-// the generic path.
+// the products shape).  q1 r2 has to tile by 16, so 4,5,5 at rank 8 stays on the generic path.
 #define TTEMB_FAST3_SHAPES(X) \
   X(4, 5, 5, 16, 16)          \
   X(4, 4, 8, 8, 8)            \
@@ -1460,7 +1463,8 @@ __global__ __launch_bounds__(256) void fast3_finalize_kernel(GroupPlan plan, int
   X(8, 4, 4, 16, 16)          \
   X(4, 5, 5, 32, 32)          \
   X(4, 4, 8, 32, 32)          \
-  X(5, 4, 5, 16, 16)
+  X(5, 4, 5, 16, 16)          \
+  X(5, 5, 4, 16, 16)
 
 static bool shape_is(const DevShape& s, int q0, int q1, int q2, int r1, int r2) {
   return s.q[0] == q0 && s.q[1] == q1 && s.q[2] == q2 && s.R[1] == r1 && s.R[2] == r2;

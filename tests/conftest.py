@@ -14,7 +14,7 @@ for p in (ROOT, PKG):
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 TINY_CASES = ["tt_tiny_T2", "tt_tiny_T3", "tt_tiny_T4", "tt_small_prodshape", "tt_small_arxivshape",
-              "tt_small_papershape", "tt_small_q448r16", "tt_small_q844r16", "tt_small_q455r32", "tt_small_q448r32", "tt_small_q545r16"]
+              "tt_small_papershape", "tt_small_q448r16", "tt_small_q844r16", "tt_small_q455r32", "tt_small_q448r32", "tt_small_q545r16", "tt_small_q554r16"]
 ROW_CASES = ["rows_arxiv", "rows_products", "rows_papers", "rows_products_b3", "rows_q448r16_b3"]
 
 

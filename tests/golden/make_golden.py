@@ -268,6 +268,7 @@ def script_shape_cases():
     tiny_case("tt_small_q455r32", [3, 4, 5], [4, 5, 5], [32, 32], seed=19)
     tiny_case("tt_small_q448r32", [4, 3, 4], [4, 4, 8], [32, 32], seed=20)
     tiny_case("tt_small_q545r16", [7, 5, 4], [5, 4, 5], [16, 16], seed=21)   # q0 does not divide the MFMA tile height
+    tiny_case("tt_small_q554r16", [4, 7, 5], [5, 5, 4], [16, 16], seed=22)   # q0 q1 = 25 is not a multiple of the MFMA K
     window_case("rows_q448r16_b3", [125, 140, 140], [4, 4, 8], [16, 16], 24, 2449029, 6, 40)
 
 

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 PATHS = ["generic", "auto", "fast3"]
 # (q0, q1, q2, r1, r2) of the MFMA path: the BASELINE.json shapes, then the other 3-core shapes of the reference's scripts
 FAST3_SHAPES = {(4, 5, 5, 16, 16), (4, 4, 8, 8, 8), (8, 4, 4, 32, 32), (4, 4, 8, 16, 16), (8, 4, 4, 16, 16),
-                (4, 5, 5, 32, 32), (4, 4, 8, 32, 32), (5, 4, 5, 16, 16)}
+                (4, 5, 5, 32, 32), (4, 4, 8, 32, 32), (5, 4, 5, 16, 16), (5, 5, 4, 16, 16)}
 
 
 @pytest.fixture(scope="module")
@@ -304,6 +304,8 @@ def test_fast_path_huge_groups_and_bags(nat, orc, p, q, R):
     ([7, 300, 900], [4, 4, 8], [1, 16, 16, 1], 20000),      # p2 near the reduce kernel's bucket limit
     ([50, 80, 100], [5, 4, 5], [1, 16, 16, 1], 40000),      # q0 = 5: three groups per MFMA tile in prefix / epilogue
     ([9, 7, 30], [5, 4, 5], [1, 16, 16, 1], 9000),
+    ([60, 50, 60], [5, 5, 4], [1, 16, 16, 1], 40000),       # q0 q1 = 25: the E product's last K-step is padded
+    ([4, 9, 11], [5, 5, 4], [1, 16, 16, 1], 7000),
 ])
 def test_fast_path_script_shapes(nat, orc, p, q, R, n_ids):
     """The other (q, rank) shapes the reference's run scripts train with, on the grouped MFMA path: uniform ids plus

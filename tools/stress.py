@@ -11,7 +11,7 @@ import ttemb_native as nat
 from oracle import tt_oracle as orc
 
 SHAPES = [(4, 5, 5, 16, 16), (4, 4, 8, 8, 8), (8, 4, 4, 32, 32), (4, 4, 8, 16, 16), (8, 4, 4, 16, 16), (4, 5, 5, 32, 32),
-          (4, 4, 8, 32, 32), (5, 4, 5, 16, 16)]
+          (4, 4, 8, 32, 32), (5, 4, 5, 16, 16), (5, 5, 4, 16, 16)]
 seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 nat.set_path(nat.PATH_FAST3)
