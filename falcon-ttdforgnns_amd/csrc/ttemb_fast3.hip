@@ -1508,7 +1508,8 @@ bool fast3_pays(const DevShape& s, int64_t nnz) {
 bool fast3_fits(const DevShape& s, int64_t nnz, int64_t B) {
   const int64_t lim = int64_t(1) << 32;
   return B * s.D * 4 < lim && nnz * (int64_t)s.row_len[2] * 4 < lim &&
-         num_groups(s) * (int64_t)s.q[0] * s.q[1] * s.R[2] * 4 < lim && s.p[2] <= 4096 && s.p[1] < 65536;
+         num_groups(s) * (int64_t)s.q[0] * s.q[1] * s.R[2] * 4 < lim && s.p[2] <= 4096 && s.p[1] < 65536 &&
+         num_groups(s) <= (int64_t)kMaxRanges * 4096;   // the grouping pass: <= 512 ranges of <= 4096 groups (64 KB of LDS)
 }
 
 #ifndef TTEMB_ROWS_B
