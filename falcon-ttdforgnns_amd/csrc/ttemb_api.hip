@@ -102,6 +102,155 @@ static bool use_fast3(const DevShape& s, int64_t nnz, int64_t B) {
   return path == TTEMB_PATH_FAST3 || fast3_pays(s, nnz);
 }
 
+// ---------------------------------------------------------------------------------
+// 4-core tables on the grouped path.  row = G0[i0].G1[i1].G2[i2].G3[i3] is a 3-core row over the table
+// (p0 p1, p2, p3) with the VIRTUAL first core V[(i0, i1)] = G0[i0].G1[i1]  (q0 q1 x r2) -- or over (p0, p1, p2 p3)
+// with the virtual last core V[(i2, i3)] = G2[i2].G3[i3]: the id digits are the same (i0 p1 + i1 is the leading,
+// i2 p3 + i3 the trailing digit of the 3-core split), so the grouped kernels run unchanged on (V, G2, G3) /
+// (G0, G1, V) when the merged (q, ranks) is one of their shapes.  V is rebuilt from the cores per call (a few
+// thousand small GEMMs), its gradient is split back:  dA[ia] = sum_ib dV[ia,ib].B[ib]^T, dB[ib] = sum_ia A[ia]^T.dV[ia,ib]
+// -- two tiny kernels around the 3-core path.
+// ---------------------------------------------------------------------------------
+struct Merged4 {
+  bool on;
+  int a;                // the merged pair: cores a and a + 1 (0: the first two, 2: the last two)
+  DevShape s3;          // the 3-core view
+  int64_t v_bytes;      // bytes of V (and of dV), 256-aligned
+  // V[(ia, ib)] = A[ia] (rows x K) . Bm[ib] (K x n): the two cores as plain matrices
+  int pa, pb, rows, K, n;
+};
+
+static bool view3(const DevShape& s, int a, DevShape* out) {   // the 3-core shape with cores a, a + 1 merged
+  const long long pp = (long long)s.p[a] * s.p[a + 1], qq = (long long)s.q[a] * s.q[a + 1];
+  if (pp > 0x7fffffffll || qq > 1024) return false;
+  DevShape d;
+  memset(&d, 0, sizeof(d));
+  d.T = 3;
+  int k = 0;
+  for (int t = 0; t < 4; ++t) {
+    if (t == a + 1) continue;
+    d.p[k] = t == a ? (int)pp : s.p[t];
+    d.q[k] = t == a ? (int)qq : s.q[t];
+    d.R[k] = s.R[t];
+    ++k;
+  }
+  d.R[3] = 1;
+  d.D = s.D;
+  d.L[2] = 1; d.L[1] = d.p[2]; d.L[0] = (long long)d.p[1] * d.p[2];
+  long long Q = 1;
+  int pm = 0;
+  for (int t = 0; t < 3; ++t) {
+    Q *= d.q[t];
+    const long long rl = (long long)d.R[t] * d.q[t] * d.R[t + 1], pl = Q * d.R[t + 1];
+    if (rl > (1 << 24) || pl > (1 << 24)) return false;
+    d.row_len[t] = (int)rl;
+    d.part_len[t] = (int)pl;
+    if (t < 2 && d.part_len[t] > pm) pm = d.part_len[t];
+  }
+  d.part_max = pm;
+  *out = d;
+  return true;
+}
+
+// first choice: merge the first two cores (small virtual core, the per-id operand stays the last core); else the
+// last two (q = 5,5,2,2: the virtual last core has p2 p3 rows of r2 q2 q3 floats, its dG slabs grow with it)
+static Merged4 merge_first_two(const DevShape& s, int64_t nnz, int64_t B) {
+  Merged4 m;
+  memset(&m, 0, sizeof(m));
+  if (s.T != 4 || current_path() == TTEMB_PATH_GENERIC) return m;
+  for (int a = 0; a <= 2; a += 2) {
+    DevShape d;
+    if (!view3(s, a, &d) || !use_fast3(d, nnz, B)) continue;
+    if (a == 2 && (long long)d.p[2] * d.row_len[2] * 4 > (4ll << 20)) continue;   // virtual last core: at most 4 MB (its slabs)
+    m.on = true;
+    m.a = a;
+    m.s3 = d;
+    m.pa = s.p[a]; m.pb = s.p[a + 1];
+    m.rows = s.R[a] * s.q[a];          // A[ia] is (R_a q_a) x R_{a+1}
+    m.K = s.R[a + 1];
+    m.n = s.q[a + 1] * s.R[a + 2];     // Bm[ib] is R_{a+1} x (q_{a+1} R_{a+2})
+    m.v_bytes = align256((long long)m.pa * m.pb * m.rows * m.n * 4);
+    return m;
+  }
+  return m;
+}
+
+// V[(ia, ib)] = A[ia] (rows x K) . Bm[ib] (K x n): one workgroup per pair
+__global__ __launch_bounds__(256) void merge_pair_kernel(const float* __restrict__ A, const float* __restrict__ Bm, int pb, int rows,
+                                                         int K, int n, float* __restrict__ V) {
+  const int pair = blockIdx.x, ia = pair / pb, ib = pair - ia * pb;
+  const float* a = A + (size_t)ia * rows * K;
+  const float* b = Bm + (size_t)ib * K * n;
+  float* v = V + (size_t)pair * rows * n;
+  for (int e = threadIdx.x; e < rows * n; e += 256) {
+    const int r = e / n, c = e - r * n;
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) acc = fmaf(a[r * K + k], b[k * n + c], acc);
+    v[e] = acc;
+  }
+}
+
+// sum of `terms` products per output, `outs` outputs: a thread per output when there are many outputs, else the
+// terms of one output spread over the workgroup
+template <typename F>
+__device__ __forceinline__ void sum_terms(int outs, int terms, float* __restrict__ dst, float* red, F term) {
+  const int tid = threadIdx.x;
+  if (outs >= 128) {
+    for (int o = tid; o < outs; o += 256) {
+      float acc = 0.f;
+      for (int k = 0; k < terms; ++k) acc += term(o, k);
+      dst[o] = acc;
+    }
+    return;
+  }
+  for (int o = 0; o < outs; ++o) {
+    float acc = 0.f;
+    for (int k = tid; k < terms; k += 256) acc += term(o, k);
+    red[tid] = acc;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if (tid < w) red[tid] += red[tid + w];
+      __syncthreads();
+    }
+    if (tid == 0) dst[o] = red[0];
+    __syncthreads();
+  }
+}
+
+// workgroups [0, pa): dA[ia] (rows x K) = sum over ib of dV[ia,ib] . Bm[ib]^T;  [pa, pa + pb): dBm[ib] (K x n) = sum over ia of
+// A[ia]^T . dV[ia,ib]
+__global__ __launch_bounds__(256) void split_pair_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                         const float* __restrict__ dV, int pa, int pb, int rows, int K, int n,
+                                                         float* __restrict__ dA, float* __restrict__ dBm) {
+  __shared__ float red[256];
+  if ((int)blockIdx.x < pa) {
+    const int ia = blockIdx.x;
+    sum_terms(rows * K, pb * n, dA + (size_t)ia * rows * K, red, [&](int o, int t) {
+      const int r = o / K, k = o - r * K, ib = t / n, c = t - ib * n;
+      return dV[((size_t)ia * pb + ib) * rows * n + r * n + c] * Bm[((size_t)ib * K + k) * n + c];
+    });
+  } else {
+    const int ib = blockIdx.x - pa;
+    sum_terms(K * n, pa * rows, dBm + (size_t)ib * K * n, red, [&](int o, int t) {
+      const int k = o / n, c = o - k * n, ia = t / rows, r = t - ia * rows;
+      return A[((size_t)ia * rows + r) * K + k] * dV[((size_t)ia * pb + ib) * rows * n + r * n + c];
+    });
+  }
+}
+
+static int build_merged_core(const Merged4& m, const CorePtrs& cp, float* V, hipStream_t st) {
+  hipLaunchKernelGGL(merge_pair_kernel, dim3((unsigned)(m.pa * m.pb)), dim3(256), 0, st, cp.c[m.a], cp.c[m.a + 1], m.pb, m.rows,
+                     m.K, m.n, V);
+  return check_hip(hipGetLastError(), "merge_pair_kernel");
+}
+
+// the 3-core operand lists of a merged table: V in the place of the pair
+static void merged_cores(const Merged4& m, const CorePtrs& cp, const float* V, CorePtrs* c3) {
+  memset(c3, 0, sizeof(*c3));
+  if (m.a == 0) { c3->c[0] = V; c3->c[1] = cp.c[2]; c3->c[2] = cp.c[3]; }
+  else          { c3->c[0] = cp.c[0]; c3->c[1] = cp.c[1]; c3->c[2] = V; }
+}
+
 __global__ void zero_words_kernel(uint32_t* __restrict__ p, size_t n) {
   const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
   for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
@@ -273,6 +422,26 @@ static int backward_into(const DevShape& ds, const CorePtrs& cp, const int64_t* 
   if (use_fast3(ds, nnz, B))
     return launch_backward_fast3(ds, cp, indices, rowidx, offsets, nnz, nnz_dev, B, d_output, dst, ws, ws_bytes, plan,
                                  plan_bytes, st, update);
+  const Merged4 m4 = merge_first_two(ds, nnz, B);
+  if (m4.on) {   // 4 cores: the grouped 3-core backward on (V, G2, G3), then dV back onto G0 and G1
+    if (ws == nullptr || ws_bytes < 2 * m4.v_bytes) return fail(TTEMB_E_WORKSPACE, "backward needs room for the merged core");
+    float* V = reinterpret_cast<float*>(ws);
+    float* dV = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + m4.v_bytes);
+    int rc = build_merged_core(m4, cp, V, st);
+    if (rc) return rc;
+    CorePtrs c3;
+    CorePtrsMut d3;
+    merged_cores(m4, cp, V, &c3);
+    memset(&d3, 0, sizeof(d3));
+    if (m4.a == 0) { d3.c[0] = dV; d3.c[1] = dst.c[2]; d3.c[2] = dst.c[3]; }
+    else           { d3.c[0] = dst.c[0]; d3.c[1] = dst.c[1]; d3.c[2] = dV; }
+    rc = launch_backward_fast3(m4.s3, c3, indices, rowidx, offsets, nnz, nnz_dev, B, d_output, d3,
+                               reinterpret_cast<char*>(ws) + 2 * m4.v_bytes, ws_bytes - 2 * m4.v_bytes, plan, plan_bytes, st, nullptr);
+    if (rc) return rc;
+    hipLaunchKernelGGL(split_pair_kernel, dim3((unsigned)(m4.pa + m4.pb)), dim3(256), 0, st, cp.c[m4.a], cp.c[m4.a + 1], dV, m4.pa,
+                       m4.pb, m4.rows, m4.K, m4.n, dst.c[m4.a], dst.c[m4.a + 1]);
+    return check_hip(hipGetLastError(), "split_pair_kernel");
+  }
   if (current_path() == TTEMB_PATH_FAST3) return fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
   int rc = launch_zero_cores(ds, dst, st);
   if (rc) return rc;
@@ -315,10 +484,13 @@ int64_t ttemb_workspace_bytes(const ttemb_shape_t* shape, int32_t op, int64_t nn
   int rc = make_dev_shape(shape, &ds);
   if (rc) return rc;
   const bool f3 = use_fast3(ds, op == TTEMB_OP_CACHE_POPULATE ? B : nnz, B);
+  const Merged4 m4 = op == TTEMB_OP_CACHE_POPULATE ? Merged4{} : merge_first_two(ds, nnz, B);
   switch (op) {
     case TTEMB_OP_FORWARD:
+      if (m4.on) return align256(nnz * 8) + m4.v_bytes + fast3_workspace_bytes(m4.s3, op, nnz, B);
       return align256(nnz * 8) + (f3 ? fast3_workspace_bytes(ds, op, nnz, B) : 0);
     case TTEMB_OP_BACKWARD:
+      if (m4.on) return grad_scratch_bytes(ds) + align256(nnz * 8) + 2 * m4.v_bytes + fast3_workspace_bytes(m4.s3, op, nnz, B);
       return grad_scratch_bytes(ds) + align256(nnz * 8) + (f3 ? fast3_workspace_bytes(ds, op, nnz, B) : 0);
     case TTEMB_OP_CACHE_POPULATE: {
       const int64_t sort = populate_workspace_bytes(nnz);
@@ -335,7 +507,9 @@ int64_t ttemb_plan_bytes(const ttemb_shape_t* shape, int64_t nnz) {
   int rc = make_dev_shape(shape, &ds);
   if (rc) return rc;
   if (nnz < 0) return fail(TTEMB_E_BADARG, "negative size");
-  return use_fast3(ds, nnz, 0) ? fast3_plan_bytes(ds, nnz) : 0;
+  if (use_fast3(ds, nnz, 0)) return fast3_plan_bytes(ds, nnz);
+  const Merged4 m4 = merge_first_two(ds, nnz, 0);
+  return m4.on ? fast3_plan_bytes(m4.s3, nnz) : 0;
 }
 
 }  // extern "C"
@@ -356,6 +530,26 @@ static int forward_phase(int phase, const ttemb_shape_t* shape, const float* con
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   CorePtrs cp;
   for (int t = 0; t < TTEMB_MAX_CORES; ++t) cp.c[t] = t < ds.T ? cores[t] : nullptr;
+  const Merged4 m4 = nnz > 0 ? merge_first_two(ds, nnz, B) : Merged4{};
+  if (m4.on) {   // 4 cores through the grouped 3-core kernels on (V = G0.G1, G2, G3); workspace: [row slot | V | 3-core]
+    char* w4 = reinterpret_cast<char*>(workspace);
+    const int64_t head = align256(nnz * 8);
+    if (w4 == nullptr || workspace_bytes < head + m4.v_bytes) return fail(TTEMB_E_WORKSPACE, "forward needs room for the merged core");
+    if (rowidx == nullptr && offsets == nullptr) return fail(TTEMB_E_BADARG, "rowidx and offsets are both null");
+    float* V = reinterpret_cast<float*>(w4 + head);
+    CorePtrs c3;
+    merged_cores(m4, cp, V, &c3);
+    if (phase != 1) {
+      rc = build_merged_core(m4, cp, V, st);
+      if (rc) return rc;
+    }
+    if (phase != 2 && offsets == nullptr) {
+      rc = launch_zero(output, (size_t)B * ds.D * 4, st, "zero output");
+      if (rc) return rc;
+    }
+    return launch_forward_fast3(m4.s3, c3, indices, rowidx, offsets, nnz, nnz_dev, B, output, offsets != nullptr,
+                                w4 + head + m4.v_bytes, workspace_bytes - head - m4.v_bytes, plan, plan_bytes, phase, st);
+  }
   const bool f3 = nnz > 0 && use_fast3(ds, nnz, B);
   if (phase == 1 && !f3) return TTEMB_OK;   // the generic kernels have no id-only half: phase 2 is their whole forward
   if (phase == 2 && f3) {

@@ -385,6 +385,53 @@ def test_random_tables_fast_path(nat, orc, shape, seed):
     assert_grads_close(grads, orc.tt_dense_backward(idx, offsets, d_out, cores, p, q, R), rel=2e-4)
 
 
+@pytest.mark.parametrize("p,q,R,n_ids,path", [
+    ([10, 12, 30, 40], [2, 4, 4, 4], [1, 16, 16, 16, 1], 30000, "fast3"),   # run scripts: q = 2,4,4,4 -> (8, 4, 4) at rank 16
+    ([50, 60, 60, 60], [2, 4, 4, 4], [1, 16, 16, 16, 1], 60000, "auto"),    # the scripts' own table (10.8 M rows)
+    ([9, 7, 20, 30], [2, 2, 5, 5], [1, 8, 16, 16, 1], 20000, "fast3"),      # (4, 5, 5) at rank 16, r1 = 8
+    ([6, 5, 25, 33], [4, 2, 4, 4], [1, 16, 16, 16, 1], 9000, "fast3"),
+    ([12, 9, 14, 11], [5, 5, 2, 2], [1, 16, 16, 16, 1], 30000, "fast3"),    # q0 q1 = 25: the LAST two cores merge -> (5, 5, 4)
+    ([50, 60, 60, 60], [5, 5, 2, 2], [1, 16, 16, 16, 1], 50000, "auto"),    # the scripts' own products 4-core table
+    ([7, 8, 9, 13], [5, 5, 2, 2], [1, 16, 16, 8, 1], 8000, "fast3"),        # r3 = 8 inside the merged pair
+])
+def test_four_core_tables_on_the_grouped_path(nat, orc, p, q, R, n_ids, path):
+    """4-core tables whose first two cores merge into a virtual first core of a covered 3-core shape: the grouped
+    kernels on (G0.G1, G2, G3), the gradient of the virtual core split back onto G0 and G1.  Against the oracle's
+    4-core forward / backward (dense and fused SGD), windows + duplicates + ragged bags."""
+    nat.set_path({"auto": nat.PATH_AUTO, "fast3": nat.PATH_FAST3}[path])
+    n_emb = int(np.prod(p))
+    rng = np.random.default_rng(5 + p[0] + n_ids)
+    cores = [(rng.standard_normal((p[t], R[t] * q[t] * R[t + 1])) * 0.35).astype(np.float32) for t in range(4)]
+    starts = rng.integers(0, n_emb - 300, size=60)
+    local = (starts[:, None] + rng.integers(0, 300, size=(60, n_ids // 120))).reshape(-1)
+    idx = np.concatenate([local, rng.integers(0, n_emb, size=n_ids - local.shape[0])]).astype(np.int64)
+    idx[:300] = idx[300:600]
+    rng.shuffle(idx)
+    lens = rng.integers(0, 4, size=n_ids)
+    lens = lens[np.cumsum(lens) <= n_ids]
+    idx = idx[: int(lens.sum())]
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    B, D = offsets.shape[0] - 1, int(np.prod(q))
+    shape = nat.make_shape(p, q, R)
+    assert nat.plan_bytes(shape, idx.shape[0]) > 0, "the 4-core table did not map onto the grouped path"
+    out, _ = run_forward(nat, p, q, R, cores, idx, offsets)
+    want = orc.tt_forward(idx, offsets, cores, p, q, R)
+    np.testing.assert_allclose(out, want, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(want).max())))
+    d_out = ((rng.random((B, D)) - 0.5) * 0.1).astype(np.float32)
+    grads = run_backward_dense(nat, p, q, R, cores, idx, offsets, d_out)
+    wg = orc.tt_dense_backward(idx, offsets, d_out, cores, p, q, R)
+    assert_grads_close(grads, wg, rel=3e-4)
+    # fused SGD through the same mapping (gradients into scratch, one step kernel over the four real cores)
+    c = [dev(x) for x in cores]
+    ws = nat.Workspace()
+    ti, to = dev(idx, torch.int64), dev(offsets, torch.int64)
+    nat.backward_sgd(shape, c, ti, None, idx.shape[0], None, B, dev(d_out), 0.05, ws, None, to)
+    torch.cuda.synchronize()
+    for t in range(4):
+        scale = max(float(np.abs(wg[t]).max()), 1e-6)
+        np.testing.assert_allclose(c[t].cpu().numpy(), cores[t] - np.float32(0.05) * wg[t], rtol=0, atol=0.05 * 3e-4 * scale + 2e-6)
+
+
 @pytest.mark.parametrize("cfg,N", [("products", 409600), ("arxiv", 169343), ("papers", 819200), ("arxiv_r16", 169343)])
 def test_full_size_properties(nat, orc, cfg, N):
     """BASELINE.json sizes (products: the frontier of a 2048-seed batch; arxiv: every node, the full-graph pattern of

@@ -21,7 +21,8 @@ CFG = {"products": ([125, 140, 140], [4, 5, 5], [1, 16, 16, 1], 2449029),
        "products_r32": ([125, 140, 140], [4, 5, 5], [1, 32, 32, 1], 2449029),
        # 4-core shapes of the run scripts (generic kernels only)
        "arxiv_4core": ([50, 60, 60, 60], [2, 4, 4, 4], [1, 16, 16, 16, 1], 10800000),
-       "products_4core": ([50, 60, 60, 60], [5, 5, 2, 2], [1, 16, 16, 16, 1], 10800000)}
+       "products_4core": ([50, 60, 60, 60], [5, 5, 2, 2], [1, 16, 16, 16, 1], 10800000),
+       "q2255_4core": ([50, 60, 60, 60], [2, 2, 5, 5], [1, 16, 16, 16, 1], 10800000)}
 
 
 def main():
