@@ -12,6 +12,8 @@ from oracle import tt_oracle as orc
 
 SHAPES = [(4, 5, 5, 16, 16), (4, 4, 8, 8, 8), (8, 4, 4, 32, 32), (4, 4, 8, 16, 16), (8, 4, 4, 16, 16), (4, 5, 5, 32, 32),
           (4, 4, 8, 32, 32), (5, 4, 5, 16, 16), (5, 5, 4, 16, 16)]
+FOUR = [([2, 4, 4, 4], [1, 16, 16, 16, 1]), ([4, 2, 4, 4], [1, 16, 16, 16, 1]), ([2, 2, 5, 5], [1, 8, 16, 16, 1]),
+        ([5, 5, 2, 2], [1, 16, 16, 16, 1]), ([5, 5, 2, 2], [1, 16, 16, 4, 1])]
 seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 nat.set_path(nat.PATH_FAST3)
@@ -24,6 +26,10 @@ while time.time() < t_end:
     sh = SHAPES[int(rng.integers(0, len(SHAPES)))]
     q, R = list(sh[:3]), [1, sh[3], sh[4], 1]
     p = [int(rng.integers(1, 80)), int(rng.integers(1, 80)), int(rng.integers(1, 400))]
+    if rng.random() < 0.25:   # a 4-core table that maps onto the grouped path through a merged pair of cores
+        q, R = FOUR[int(rng.integers(0, len(FOUR)))]
+        p = [int(rng.integers(1, 30)), int(rng.integers(1, 30)), int(rng.integers(1, 40)), int(rng.integers(1, 40))]
+        sh = tuple(q)
     n_emb = int(np.prod(p))
     nnz_target = int(rng.choice([1, 7, 200, 3000, 20000, 60000]))
     mode = int(rng.integers(0, 3))
@@ -46,7 +52,7 @@ while time.time() < t_end:
         idx[: nnz // 10] = idx[nnz // 10: 2 * (nnz // 10)]
     offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     B, D = offsets.shape[0] - 1, int(np.prod(q))
-    cores = [(rng.standard_normal((p[t], R[t] * q[t] * R[t + 1])) * 0.3).astype(np.float32) for t in range(3)]
+    cores = [(rng.standard_normal((p[t], R[t] * q[t] * R[t + 1])) * 0.3).astype(np.float32) for t in range(len(p))]
     d_out = ((rng.random((B, D)) - 0.5) * 0.2).astype(np.float32)
     shape = nat.make_shape(p, q, R)
     ws = nat.Workspace()
@@ -63,7 +69,7 @@ while time.time() < t_end:
     want = orc.tt_forward(idx, offsets, cores, p, q, R)
     wg = orc.tt_dense_backward(idx, offsets, d_out, cores, p, q, R)
     ok = np.allclose(out.cpu().numpy(), want, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(want).max())))
-    for t in range(3):
+    for t in range(len(p)):
         sc = max(float(np.abs(wg[t]).max()), 1e-6)
         ok &= float(np.abs(grads[t].cpu().numpy() - wg[t]).max()) <= 3e-4 * sc + 1e-6
         ok &= float(np.abs(c2[t].cpu().numpy() - (cores[t] - np.float32(0.05) * wg[t])).max()) <= 0.05 * (3e-4 * sc) + 2e-6
