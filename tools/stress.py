@@ -18,6 +18,7 @@ seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 nat.set_path(nat.PATH_FAST3)
 t_end = time.time() + seconds
+t_note = time.time() + 30.0
 n_cases = n_bad = 0
 case = seed0
 while time.time() < t_end:
@@ -74,6 +75,9 @@ while time.time() < t_end:
         ok &= float(np.abs(grads[t].cpu().numpy() - wg[t]).max()) <= 3e-4 * sc + 1e-6
         ok &= float(np.abs(c2[t].cpu().numpy() - (cores[t] - np.float32(0.05) * wg[t])).max()) <= 0.05 * (3e-4 * sc) + 2e-6
     n_cases += 1
+    if time.time() > t_note:   # a line every half minute: a silent GPU job looks hung to the runner
+        print(f"... {n_cases} cases, {n_bad} failures so far", flush=True)
+        t_note = time.time() + 30.0
     if not ok:
         n_bad += 1
         print(f"FAIL case {case}: shape {sh} p {p} nnz {nnz} B {B} mode {mode}", flush=True)
