@@ -190,51 +190,58 @@ __global__ __launch_bounds__(256) void merge_pair_kernel(const float* __restrict
   }
 }
 
-// sum of `terms` products per output, `outs` outputs: a thread per output when there are many outputs, else the
-// terms of one output spread over the workgroup
+// `outs` (< 128) outputs of `terms` products each: 256 / (outs rounded up to a power of two) threads share an output
 template <typename F>
-__device__ __forceinline__ void sum_terms(int outs, int terms, float* __restrict__ dst, float* red, F term) {
+__device__ __forceinline__ void sum_terms_few(int outs, int terms, float* dst, float* red, F term) {
   const int tid = threadIdx.x;
-  if (outs >= 128) {
-    for (int o = tid; o < outs; o += 256) {
-      float acc = 0.f;
-      for (int k = 0; k < terms; ++k) acc += term(o, k);
-      dst[o] = acc;
-    }
-    return;
-  }
-  for (int o = 0; o < outs; ++o) {
-    float acc = 0.f;
-    for (int k = tid; k < terms; k += 256) acc += term(o, k);
-    red[tid] = acc;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-      if (tid < w) red[tid] += red[tid + w];
-      __syncthreads();
-    }
-    if (tid == 0) dst[o] = red[0];
+  int lanes = 256;
+  for (int o2 = 1; o2 < outs; o2 <<= 1) lanes >>= 1;
+  const int o = tid / lanes, l = tid - o * lanes;
+  float acc = 0.f;
+  if (o < outs)
+    for (int k = l; k < terms; k += lanes) acc += term(o, k);
+  red[tid] = acc;
+  __syncthreads();
+  for (int w = lanes >> 1; w > 0; w >>= 1) {
+    if (l < w) red[tid] += red[tid + w];
     __syncthreads();
   }
+  if (l == 0 && o < outs) dst[o] = red[tid];
 }
 
-// workgroups [0, pa): dA[ia] (rows x K) = sum over ib of dV[ia,ib] . Bm[ib]^T;  [pa, pa + pb): dBm[ib] (K x n) = sum over ia of
-// A[ia]^T . dV[ia,ib]
+// grid (pa + pb, K): workgroup (ia, k) sums dA[ia][:, k] = sum over ib of dV[ia,ib] . Bm[ib][k, :]^T, workgroup (pa + ib, k)
+// sums dBm[ib][k, :] = sum over ia of A[ia][:, k]^T . dV[ia,ib]   (one column / row of K per workgroup: the sums are short
+// but there are only pa + pb of each kind, so they are spread over K times as many workgroups)
 __global__ __launch_bounds__(256) void split_pair_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
                                                          const float* __restrict__ dV, int pa, int pb, int rows, int K, int n,
                                                          float* __restrict__ dA, float* __restrict__ dBm) {
   __shared__ float red[256];
+  __shared__ float outv[256];
+  const int k = blockIdx.y;
   if ((int)blockIdx.x < pa) {
     const int ia = blockIdx.x;
-    sum_terms(rows * K, pb * n, dA + (size_t)ia * rows * K, red, [&](int o, int t) {
-      const int r = o / K, k = o - r * K, ib = t / n, c = t - ib * n;
-      return dV[((size_t)ia * pb + ib) * rows * n + r * n + c] * Bm[((size_t)ib * K + k) * n + c];
-    });
+    for (int r0 = 0; r0 < rows; r0 += 127) {   // outputs r, at most 127 per pass
+      const int nr = rows - r0 < 127 ? rows - r0 : 127;
+      sum_terms_few(nr, pb * n, outv, red, [&](int o, int t) {
+        const int r = r0 + o, ib = t / n, c = t - ib * n;
+        return dV[((size_t)ia * pb + ib) * rows * n + r * n + c] * Bm[((size_t)ib * K + k) * n + c];
+      });
+      __syncthreads();
+      for (int o = threadIdx.x; o < nr; o += 256) dA[((size_t)ia * rows + r0 + o) * K + k] = outv[o];
+      __syncthreads();
+    }
   } else {
     const int ib = blockIdx.x - pa;
-    sum_terms(K * n, pa * rows, dBm + (size_t)ib * K * n, red, [&](int o, int t) {
-      const int k = o / n, c = o - k * n, ia = t / rows, r = t - ia * rows;
-      return A[((size_t)ia * rows + r) * K + k] * dV[((size_t)ia * pb + ib) * rows * n + r * n + c];
-    });
+    for (int c0 = 0; c0 < n; c0 += 127) {
+      const int nc = n - c0 < 127 ? n - c0 : 127;
+      sum_terms_few(nc, pa * rows, outv, red, [&](int o, int t) {
+        const int c = c0 + o, ia = t / rows, r = t - ia * rows;
+        return A[((size_t)ia * rows + r) * K + k] * dV[((size_t)ia * pb + ib) * rows * n + r * n + c];
+      });
+      __syncthreads();
+      for (int o = threadIdx.x; o < nc; o += 256) dBm[((size_t)ib * K + k) * n + c0 + o] = outv[o];
+      __syncthreads();
+    }
   }
 }
 
@@ -438,7 +445,7 @@ static int backward_into(const DevShape& ds, const CorePtrs& cp, const int64_t* 
     rc = launch_backward_fast3(m4.s3, c3, indices, rowidx, offsets, nnz, nnz_dev, B, d_output, d3,
                                reinterpret_cast<char*>(ws) + 2 * m4.v_bytes, ws_bytes - 2 * m4.v_bytes, plan, plan_bytes, st, nullptr);
     if (rc) return rc;
-    hipLaunchKernelGGL(split_pair_kernel, dim3((unsigned)(m4.pa + m4.pb)), dim3(256), 0, st, cp.c[m4.a], cp.c[m4.a + 1], dV, m4.pa,
+    hipLaunchKernelGGL(split_pair_kernel, dim3((unsigned)(m4.pa + m4.pb), (unsigned)m4.K), dim3(256), 0, st, cp.c[m4.a], cp.c[m4.a + 1], dV, m4.pa,
                        m4.pb, m4.rows, m4.K, m4.n, dst.c[m4.a], dst.c[m4.a + 1]);
     return check_hip(hipGetLastError(), "split_pair_kernel");
   }

@@ -393,6 +393,7 @@ def test_random_tables_fast_path(nat, orc, shape, seed):
     ([12, 9, 14, 11], [5, 5, 2, 2], [1, 16, 16, 16, 1], 30000, "fast3"),    # q0 q1 = 25: the LAST two cores merge -> (5, 5, 4)
     ([50, 60, 60, 60], [5, 5, 2, 2], [1, 16, 16, 16, 1], 50000, "auto"),    # the scripts' own products 4-core table
     ([7, 8, 9, 13], [5, 5, 2, 2], [1, 16, 16, 8, 1], 8000, "fast3"),        # r3 = 8 inside the merged pair
+    ([6, 7, 9, 5], [4, 4, 8, 1], [1, 16, 16, 4, 1], 9000, "fast3"),         # last pair, 128 rows in the merged operand
 ])
 def test_four_core_tables_on_the_grouped_path(nat, orc, p, q, R, n_ids, path):
     """4-core tables whose first two cores merge into a virtual first core of a covered 3-core shape: the grouped
