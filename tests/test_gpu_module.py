@@ -73,6 +73,44 @@ def test_backward_dense_equals_autograd_through_full_weight(ops, p, q, r):
         torch.testing.assert_close(a.grad, b.grad, rtol=1e-3, atol=1e-4 * float(b.grad.abs().max()))
 
 
+@pytest.mark.parametrize("q,r", [([2, 4, 4, 4], [16, 16, 16]), ([5, 5, 2, 2], [16, 16, 16])])
+def test_four_core_module_trains_on_the_grouped_path(ops, q, r):
+    """The reference's 4-core run-script shapes through the class on a batch big enough for the grouped kernels:
+    forward against the dense table, dense gradients and the in-backward Adagrad step against autograd through
+    tt_matrix_to_full."""
+    import ttemb_native as nat
+    torch.manual_seed(3)
+    p = [8, 9, 20, 25]
+    n, D = int(np.prod(p)), int(np.prod(q))
+    rng = np.random.default_rng(3)
+    idx = torch.tensor(rng.integers(0, n, size=20000)).cuda()
+    offs = torch.arange(idx.numel() + 1).cuda()
+    assert nat.plan_bytes(nat.make_shape(p, q, r), idx.numel()) > 0   # AUTO takes the merged-pair mapping at this size
+    emb = ops.TTEmbeddingBag(n, D, r, p, q, sparse=False, use_cache=False, weight_dist="uniform")
+    for c in emb.tt_cores:
+        c.data.mul_(3.0)
+    clones = [c.detach().clone().requires_grad_(True) for c in emb.tt_cores]
+    full = ops.tt_matrix_to_full(p, q, r, clones, [1, 0, 2, 3])
+    out = emb(idx, offs)
+    torch.testing.assert_close(out, full.detach()[idx], rtol=1e-4, atol=1e-4)
+    d_out = torch.rand_like(out) * 0.1
+    out.backward(d_out)
+    full[idx].backward(d_out)
+    for a, b in zip(emb.tt_cores, clones):
+        torch.testing.assert_close(a.grad, b.grad, rtol=1e-3, atol=2e-4 * float(b.grad.abs().max()))
+    # sparse mode: the optimiser step happens inside backward
+    lr, eps = 0.05, 1e-8
+    emb2 = ops.TTEmbeddingBag(n, D, r, p, q, sparse=True, use_cache=False, weight_dist="uniform", learning_rate=lr,
+                              optimizer=ops.OptimType.EXACT_ADAGRAD, eps=eps)
+    for c, src in zip(emb2.tt_cores, clones):
+        c.data.copy_(src.detach())
+    emb2(idx, offs).backward(d_out)
+    for c, src in zip(emb2.tt_cores, clones):
+        g = src.grad
+        want = src.detach() - lr * g / (torch.sqrt(g * g) + eps)
+        torch.testing.assert_close(c.detach(), want, rtol=1e-3, atol=2e-4)
+
+
 @pytest.mark.parametrize("optimizer", ["SGD", "EXACT_ADAGRAD"])
 def test_sparse_mode_updates_in_backward(ops, optimizer):
     torch.manual_seed(3)
