@@ -1066,7 +1066,10 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(const float* __rest
 // in registers and stores one (r2 q2)-float row per i2 into the tile's slab of partial sums
 // (plain stores: atomics from every tile onto the 45 KB of dG2 ran at ~0.1 TB/s).  E rows are
 // read exactly once, 16 bytes per lane.  fast3_finalize_kernel adds the slabs up.
-template <int ROW2, int kRowsMax, int NWB>
+// SHARED: tables whose slab (p2 rows of r2 q2 floats) is large keep ONE zero-filled slab that every tile adds into
+// with float atomics, a whole row (contiguous floats) per non-empty bucket, instead of a slab per tile (a 4-core
+// table with a merged last pair has 0.9 MB slabs: 256 of them were 236 MB to write and read back).
+template <int ROW2, int kRowsMax, int NWB, bool SHARED>
 __global__ __launch_bounds__(NWB * 64) void fast3_dg2_reduce_kernel(GroupPlan plan, int G, uint32_t p2, uint32_t kRowsB) {
   extern __shared__ uint32_t lds_u[];   // [p2 + 1] bucket starts | [p2] cursors | [kRowsMax] row list (uint16)
   uint32_t* bstart = lds_u;
@@ -1078,7 +1081,7 @@ __global__ __launch_bounds__(NWB * 64) void fast3_dg2_reduce_kernel(GroupPlan pl
   const uint32_t total = (uint32_t)plan.gpre[G];
   const uint32_t s0 = blockIdx.x * kRowsB;
   const uint32_t n_rows = s0 >= total ? 0u : (s0 + kRowsB < total ? kRowsB : total - s0);
-  float* slab = plan.g2part + (size_t)blockIdx.x * p2 * ROW2;  // this tile's partial dG2, every row written
+  float* slab = plan.g2part + (SHARED ? (size_t)0 : (size_t)blockIdx.x * p2 * ROW2);  // this tile's partial dG2, every row written
   for (uint32_t e = tid; e <= p2; e += NWB * 64) bstart[e] = 0;
   __syncthreads();
   // histogram of i2 over the tile (integer LDS atomics; 8 ids per thread)
@@ -1117,6 +1120,7 @@ __global__ __launch_bounds__(NWB * 64) void fast3_dg2_reduce_kernel(GroupPlan pl
   const int sub = lane / F4, c4 = lane - sub * F4;
   for (uint32_t i2 = wave; i2 < p2; i2 += NWB) {
     const uint32_t b0 = bstart[i2], b1 = bstart[i2 + 1];
+    if (SHARED && b0 == b1) continue;   // nothing to add
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (sub < SUB) {
       // several independent row loads in flight per lane group (the loop is latency-bound otherwise)
@@ -1145,7 +1149,19 @@ __global__ __launch_bounds__(NWB * 64) void fast3_dg2_reduce_kernel(GroupPlan pl
       const float z = __shfl(acc.z, src, kWave), w = __shfl(acc.w, src, kWave);
       if (lane < F4) { acc.x += x; acc.y += y; acc.z += z; acc.w += w; }
     }
-    if (lane < F4) *reinterpret_cast<float4*>(slab + (size_t)i2 * ROW2 + 4 * lane) = acc;
+    if constexpr (SHARED) {
+      // element e of the row sits in lane e / 4, component e % 4: hand it to lane e so that an atomic instruction adds
+      // 64 consecutive floats (the shape the memory system takes at full rate; 16 lanes x 4 strided scalars did not)
+      for (int e0 = 0; e0 < ROW2; e0 += kWave) {
+        const int e = e0 + lane, src = (e >> 2) & 63;
+        const float x = __shfl(acc.x, src, kWave), y = __shfl(acc.y, src, kWave);
+        const float z = __shfl(acc.z, src, kWave), w = __shfl(acc.w, src, kWave);
+        const float v = (e & 3) == 0 ? x : ((e & 3) == 1 ? y : ((e & 3) == 2 ? z : w));
+        if (e < ROW2) atomicAdd(slab + (size_t)i2 * ROW2 + e, v);
+      }
+    } else {
+      if (lane < F4) *reinterpret_cast<float4*>(slab + (size_t)i2 * ROW2 + 4 * lane) = acc;
+    }
   }
 }
 
@@ -1528,6 +1544,9 @@ static int reduce_rows(int64_t nnz) {
 }
 constexpr int NWB = 16;
 static int64_t reduce_tiles(int64_t nnz) { const int r = reduce_rows(nnz); return (nnz + r - 1) / r; }
+// slabs of more than 256 KB are not replicated per tile: one shared slab, float atomics (see the reduce kernel)
+static bool shared_slab(const DevShape& s) { return (int64_t)s.p[2] * s.row_len[2] * 4 > (256 << 10); }
+static int64_t slab_count(const DevShape& s, int64_t nnz) { return shared_slab(s) ? 1 : reduce_tiles(nnz); }
 // the epilogue cuts the i0 range of every i1 into ~kEpiSlices slices of `gpw` groups (one wavefront each)
 static int epi_groups_per_wave(const DevShape& s) {
   int gpw = (s.p[0] + kEpiSlices - 1) / kEpiSlices;
@@ -1604,7 +1623,7 @@ static int64_t carve_workspace(const DevShape& s, int64_t nnz, bool bwd, bool pl
   if (bwd) {
     float* e = (float*)take(nnz * (int64_t)s.row_len[2] * 4);
     float* d = (float*)take(G * (int64_t)s.q[0] * s.q[1] * s.R[2] * 4);
-    float* g2 = (float*)take(reduce_tiles(nnz) * (int64_t)s.p[2] * s.row_len[2] * 4);
+    float* g2 = (float*)take(slab_count(s, nnz) * (int64_t)s.p[2] * s.row_len[2] * 4);
     float* g0 = (float*)take(G * (int64_t)s.row_len[0] * 4);
     float* g1 = (float*)take((int64_t)epi_slices(s) * s.p[1] * s.row_len[1] * 4);
     uint32_t* el = (uint32_t*)take((int64_t)epi_slices(s) * s.p[1] * 4);
@@ -1770,8 +1789,16 @@ static int run_backward(const DevShape& s, const CorePtrs& cores, const GroupPla
   rc = check_hip(hipGetLastError(), "fast3_bwd_chunk_kernel");
   if (rc) return rc;
   const int tiles = (int)reduce_tiles(nnz);
-  hipLaunchKernelGGL((fast3_dg2_reduce_kernel<C::ROW2, kRowsB, NWB>), dim3((unsigned)tiles), dim3(NWB * 64),
-                     (size_t)(2 * s.p[2] + 1) * 4 + kRowsB * 2, st, plan, (int)G, (uint32_t)s.p[2], (uint32_t)reduce_rows(nnz));
+  const size_t reduce_lds = (size_t)(2 * s.p[2] + 1) * 4 + kRowsB * 2;
+  if (shared_slab(s)) {
+    rc = launch_zero(plan.g2part, (size_t)s.p[2] * C::ROW2 * 4, st, "zero the shared dG2 slab");
+    if (rc) return rc;
+    hipLaunchKernelGGL((fast3_dg2_reduce_kernel<C::ROW2, kRowsB, NWB, true>), dim3((unsigned)tiles), dim3(NWB * 64), reduce_lds, st,
+                       plan, (int)G, (uint32_t)s.p[2], (uint32_t)reduce_rows(nnz));
+  } else {
+    hipLaunchKernelGGL((fast3_dg2_reduce_kernel<C::ROW2, kRowsB, NWB, false>), dim3((unsigned)tiles), dim3(NWB * 64), reduce_lds, st,
+                       plan, (int)G, (uint32_t)s.p[2], (uint32_t)reduce_rows(nnz));
+  }
   rc = check_hip(hipGetLastError(), "fast3_dg2_reduce_kernel");
   if (rc) return rc;
   const int gpw = epi_groups_per_wave(s), slices = epi_slices(s);
@@ -1782,7 +1809,7 @@ static int run_backward(const DevShape& s, const CorePtrs& cores, const GroupPla
   {
     const int g2_floats = s.p[2] * C::ROW2, g1_floats = s.p[1] * C::ROW1;
     const int wgs = (g2_floats + s.p[0] * C::ROW0 + 31) / 32 + (g1_floats + 255) / 256;   // dG2 | dG0, then dG1
-    hipLaunchKernelGGL(fast3_finalize_kernel, dim3((unsigned)wgs), dim3(256), 0, st, plan, tiles, slices,
+    hipLaunchKernelGGL(fast3_finalize_kernel, dim3((unsigned)wgs), dim3(256), 0, st, plan, (int)slab_count(s, nnz), slices,
                        s.p[0], s.p[1], g2_floats, (int)C::ROW0, g1_floats, Q2, R2, d_cores.c[0], d_cores.c[1], d_cores.c[2], upd);
   }
   profile_end(1, st);
