@@ -38,6 +38,21 @@ PEAK_F32_MFMA_TFLOPS = 157.3                        # MI355X_MICROARCH.md, chip-
 PEAK_HBM_GBS = 8000.0
 
 
+def _launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: run the same command line under torch.distributed.run."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -50,10 +65,17 @@ def main():
     ap.add_argument("--path", default="auto", choices=["auto", "generic", "fast3"])
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started plainly (`python bench.py --gpus N`): the ranks are fresh child processes, one per GPU, started
+        # through torch.distributed.run BEFORE this process has touched the GPU (no HIP call has been made yet; a
+        # process that has initialised the GPU must never be replaced or forked).  The launcher's rank 0 prints the
+        # JSON line; this parent only relays its exit code.
+        sys.exit(_launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a ROCm device (no CPU fallback)"
     # rehearsal of the N > 1 code path on a one-GPU box: TTEMB_BENCH_REHEARSAL=1 puts every rank on GPU 0 and
     # carries the all-reduce over gloo (RCCL needs one GPU per rank).  Never used for reported numbers.
@@ -110,10 +132,15 @@ def main():
         step(i)
     fence()
     elapsed = time.perf_counter() - t0
+    dist_info = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        elapsed = max(float(x.item()) for x in every)   # MAX over ranks
+        dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                     "ms_per_step_by_rank": [round(float(x.item()) / args.steps * 1e3, 4) for x in every],
+                     "devices": torch.cuda.device_count(), "rehearsal_on_one_gpu": rehearsal}
     value = world * N * args.steps / elapsed
 
     # roofline leg: kernels bracketed by HIP events on the stream they are launched on.
@@ -277,7 +304,7 @@ def main():
                                    "2048-seed batch = 409600 unique uniform ids per GPU, bag length 1",
                        "p": P, "q": Q, "tt_ranks": RANKS, "num_embeddings": N_EMB, "ids_per_gpu_step": N,
                        "parallelism": f"dp{world}", "kernel_path": args.path},
-            "roofline": roofline, "cpu_baseline": cpu, "batch2048_step": small, "metis_like_step": local,
+            "dist": dist_info, "roofline": roofline, "cpu_baseline": cpu, "batch2048_step": small, "metis_like_step": local,
             "cache_on_step": cached, "sage_epoch": epoch,
         }
     if world > 1:

@@ -260,9 +260,17 @@ class TTLookupFunction(torch.autograd.Function):
         # produced straight into it and nothing is handed back to autograd (no AccumulateGrad, no views)
         bucket = getattr(m, "_dense_grad_out", None)
         if bucket is not None and not ctx.live_cache:
-            _nat.backward_dense(m._shape, cores, indices, rowidx, nnz, nnz_dev, B, d_output, bucket, m._ws, ctx.plan,
-                                offsets)
-            m._bucket_filled = True
+            if m._bucket_filled:
+                # a second backward before dp.step() (micro-batches, two lookups through one module): the kernels
+                # overwrite their destination, so this one goes to scratch and is added -- what AccumulateGrad does
+                more = [torch.empty_like(b) for b in bucket]
+                _nat.backward_dense(m._shape, cores, indices, rowidx, nnz, nnz_dev, B, d_output, more, m._ws,
+                                    ctx.plan, offsets)
+                torch._foreach_add_(bucket, more)
+            else:
+                _nat.backward_dense(m._shape, cores, indices, rowidx, nnz, nnz_dev, B, d_output, bucket, m._ws,
+                                    ctx.plan, offsets)
+                m._bucket_filled = True
             return (None,) * (n_fixed + len(m.tt_cores))
         grads = bucket or [torch.empty_like(c[table] if c.dim() == 3 else c) for c in m.tt_cores]
         _nat.backward_dense(m._shape, cores, indices, rowidx, nnz, nnz_dev, B, d_output, grads, m._ws, ctx.plan,

@@ -335,6 +335,7 @@ __global__ __launch_bounds__(kSortThreads) void fast3_spread_kernel(uint32_t nnz
     for (int u = 0; u < kSortBatch; ++u) {
       if (g[u] == kNoGroup) continue;
       const uint32_t dst = atomicAdd(&cursor[g[u] >> shift], 1u);
+      if (dst >= nnz) continue;   // cannot happen with consistent counters; a stale counter must not become a wild store
       plan.grp_mid[dst] = g[u];
       plan.i2_mid[dst] = i2v[u];
       plan.vals_mid[dst] = vv[u];
@@ -383,7 +384,8 @@ __global__ __launch_bounds__(kRangeThreads) void fast3_count_kernel(uint32_t G, 
 }
 
 __device__ __forceinline__ void place_range(const uint32_t range, const uint32_t ranges, uint32_t G, uint32_t shift,
-                                            const GroupPlan& plan, uint32_t* lds_s, uint64_t& range_base) {
+                                            uint32_t nnz, uint32_t max_chunks, const GroupPlan& plan, uint32_t* lds_s,
+                                            uint64_t& range_base) {
   // lds_s: [span] cursor | [span] first position | [span] count | [span] first chunk
   const uint32_t span = 1u << shift;
   const uint32_t g0 = range << shift;
@@ -449,6 +451,7 @@ __device__ __forceinline__ void place_range(const uint32_t range, const uint32_t
     for (int u = 0; u < kSortBatch; ++u) {
       if (gl[u] == kNoGroup) continue;
       const uint32_t dst = atomicAdd(&cursor[gl[u]], 1u);
+      if (dst >= nnz) continue;   // as in the spread step: never trust a counter with an address
       plan.i2s[dst] = i2v[u];
       plan.vals[dst] = vv[u];
       const uint32_t rank = dst - gfirst[gl[u]];
@@ -456,17 +459,18 @@ __device__ __forceinline__ void place_range(const uint32_t range, const uint32_t
         const uint32_t c = gcount[gl[u]];
         const uint32_t chunks = (c + kChunk - 1) / kChunk, k = rank / kChunk;
         const uint32_t len = c - rank < (uint32_t)kChunk ? c - rank : (uint32_t)kChunk;
-        plan.ctab[gchunk[gl[u]] + k] = make_uint4(dst, g0 + gl[u], len | (k == 0 ? kFirstBit : 0u) | (k + 1 == chunks ? kLastBit : 0u),
+        if (gchunk[gl[u]] + k < max_chunks) plan.ctab[gchunk[gl[u]] + k] = make_uint4(dst, g0 + gl[u], len | (k == 0 ? kFirstBit : 0u) | (k + 1 == chunks ? kLastBit : 0u),
                                                   gchunk[gl[u]] + chunks);
       }
     }
   }
 }
 
-__global__ __launch_bounds__(kRangeThreads) void fast3_place_kernel(uint32_t nnz, uint32_t G, uint32_t shift, GroupPlan plan) {
+__global__ __launch_bounds__(kRangeThreads) void fast3_place_kernel(uint32_t nnz, uint32_t max_chunks, uint32_t G, uint32_t shift,
+                                                                    GroupPlan plan) {
   extern __shared__ uint32_t lds_s[];
   __shared__ uint64_t range_base;
-  place_range(blockIdx.x, gridDim.x, G, shift, plan, lds_s, range_base);
+  place_range(blockIdx.x, gridDim.x, G, shift, nnz, max_chunks, plan, lds_s, range_base);
 }
 
 // ---------------------------------------------------------------------------------
@@ -542,13 +546,14 @@ __global__ __launch_bounds__(64) void fast3_prefix_kernel(const float* __restric
 // share the machine instead of queueing.
 template <int Q0, int Q1, int Q2, int R1, int R2>
 __global__ __launch_bounds__(kRangeThreads) void fast3_place_prefix_kernel(uint32_t ranges, uint32_t G, uint32_t shift,
+                                                                          uint32_t nnz, uint32_t max_chunks,
                                                                           const float* __restrict__ G0,
                                                                           const float* __restrict__ G1, uint32_t p0,
                                                                           uint32_t p1, GroupPlan plan) {
   extern __shared__ uint32_t lds_s[];
   __shared__ uint64_t range_base;
   if (blockIdx.x < ranges) {
-    place_range(blockIdx.x, ranges, G, shift, plan, lds_s, range_base);
+    place_range(blockIdx.x, ranges, G, shift, nnz, max_chunks, plan, lds_s, range_base);
     return;
   }
   const uint32_t blocks0 = (p0 + kPrefixGroups - 1) / kPrefixGroups;
@@ -1646,7 +1651,8 @@ int64_t fast3_workspace_bytes(const DevShape& s, int32_t op, int64_t nnz, int64_
 
 // fill plan->{i2s, vals, counts, gpre, ctab} from the ids
 static int run_prefix(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, hipStream_t st);
-static int run_place_prefix(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int ranges, int shift, hipStream_t st);
+static int run_place_prefix(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int64_t nnz, int ranges, int shift,
+                            hipStream_t st);
 
 static int group_ids(const DevShape& s, const CorePtrs& cores, const int64_t* indices, const int64_t* rowidx,
                      const int64_t* offsets, int64_t nnz, const int32_t* nnz_dev, int64_t B, float* zero_out,
@@ -1672,9 +1678,9 @@ static int group_ids(const DevShape& s, const CorePtrs& cores, const int64_t* in
                      *plan);
   rc = check_hip(hipGetLastError(), "fast3_count_kernel");
   if (rc) return rc;
-  if (with_prefix) return run_place_prefix(s, cores, *plan, ranges, shift, st);
-  hipLaunchKernelGGL(fast3_place_kernel, dim3((unsigned)ranges), dim3(kRangeThreads), span * 16, st, (uint32_t)nnz, (uint32_t)G,
-                     (uint32_t)shift, *plan);
+  if (with_prefix) return run_place_prefix(s, cores, *plan, nnz, ranges, shift, st);
+  hipLaunchKernelGGL(fast3_place_kernel, dim3((unsigned)ranges), dim3(kRangeThreads), span * 16, st, (uint32_t)nnz,
+                     (uint32_t)max_chunks(s, nnz), (uint32_t)G, (uint32_t)shift, *plan);
   return check_hip(hipGetLastError(), "fast3_place_kernel");
 }
 
@@ -1722,19 +1728,20 @@ static int run_prefix(const DevShape& s, const CorePtrs& cores, const GroupPlan&
 }
 
 template <int Q0, int Q1, int Q2, int R1, int R2>
-static int run_place_prefix_t(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int ranges, int shift,
+static int run_place_prefix_t(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int64_t nnz, int ranges, int shift,
                               hipStream_t st) {
   const unsigned units = (unsigned)((s.p[0] + kPrefixGroups - 1) / kPrefixGroups) * (unsigned)s.p[1];
   const unsigned per_wg = kRangeThreads / kWave;
   hipLaunchKernelGGL((fast3_place_prefix_kernel<Q0, Q1, Q2, R1, R2>), dim3((unsigned)ranges + (units + per_wg - 1) / per_wg),
                      dim3(kRangeThreads), ((size_t)16 << shift), st, (uint32_t)ranges, (uint32_t)num_groups(s), (uint32_t)shift,
-                     cores.c[0], cores.c[1], (uint32_t)s.p[0], (uint32_t)s.p[1], plan);
+                     (uint32_t)nnz, (uint32_t)max_chunks(s, nnz), cores.c[0], cores.c[1], (uint32_t)s.p[0], (uint32_t)s.p[1], plan);
   return check_hip(hipGetLastError(), "fast3_place_prefix_kernel");
 }
 
-static int run_place_prefix(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int ranges, int shift, hipStream_t st) {
+static int run_place_prefix(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int64_t nnz, int ranges, int shift,
+                            hipStream_t st) {
   if (classify(s)) {
-#define TTEMB_X(a, b, c, d, e) if (shape_is(s, a, b, c, d, e)) return run_place_prefix_t<a, b, c, d, e>(s, cores, plan, ranges, shift, st);
+#define TTEMB_X(a, b, c, d, e) if (shape_is(s, a, b, c, d, e)) return run_place_prefix_t<a, b, c, d, e>(s, cores, plan, nnz, ranges, shift, st);
     TTEMB_FAST3_SHAPES(TTEMB_X)
 #undef TTEMB_X
   }

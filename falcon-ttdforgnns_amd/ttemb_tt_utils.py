@@ -1,4 +1,7 @@
-"""The two core initialisers of the reference's `tt_utils` module, on the MI355X.
+"""The two core initialisers of the reference's `tt_utils` module, on the MI355X.  Named `ttemb_tt_utils` so that this
+package directory can sit in front of the reference tree on sys.path without shadowing the reference's own `tt_utils`
+(every driver does `from tt_utils import *` for its argument parser): a driver that wants these versions imports
+`from ttemb_tt_utils import get_ortho, tt_matrix_decomp`.
 
 Only what feeds the TT layer is provided: `get_ortho` (tt_utils.py:117-157) and `tt_matrix_decomp`
 (tt_utils.py:159-201), with the reference's argument order and return types, so that

@@ -600,3 +600,31 @@ def test_data_parallel_step_two_ranks_on_gpu(orc, tmp_path, overlap):
         ids2 = r[k]["ids"][:50000].numpy()
         want_rows = orc.tt_rows(ids2, new_cores, p, q, R)
         np.testing.assert_allclose(r[k]["out2"].numpy(), want_rows, rtol=1e-4, atol=1e-4 * float(np.abs(want_rows).max()))
+
+
+def test_bucket_accumulates_over_two_backwards_before_the_step(ops, orc):
+    """Gradient accumulation with the data-parallel wrapper attached: two forward/backward passes before dp.step()
+    must sum into the flat bucket (the kernels overwrite their destination; the second pass goes through scratch),
+    as autograd accumulates into .grad."""
+    from ttemb_dist import TTDataParallel
+    torch.manual_seed(3)
+    p, q, r = [125, 140, 140], [4, 5, 5], [16, 16]
+    lr = 0.2
+    emb = ops.TTEmbeddingBag(2449029, 100, r, p, q, sparse=False, use_cache=False, weight_dist="normal", learning_rate=lr)
+    for c in emb.tt_cores:
+        c.data.mul_(300.0)
+    dp = TTDataParallel(emb)   # no process group: world size 1
+    cores = [c.detach()[0].cpu().numpy().copy() for c in emb.tt_cores]
+    rng = np.random.default_rng(5)
+    want = [np.zeros_like(c) for c in cores]
+    for n in (9000, 2000):   # grouped kernels, then the wave-per-id kernels
+        ids = rng.choice(2449029, size=n, replace=False).astype(np.int64)
+        d_out = ((rng.random((n, 100)) - 0.5) * 0.05).astype(np.float32)
+        emb(torch.tensor(ids).cuda(), torch.arange(n + 1).cuda()).backward(torch.tensor(d_out).cuda())
+        for w, g in zip(want, orc.tt_dense_backward(ids, np.arange(n + 1), d_out, cores, p, q, [1] + r + [1])):
+            w += g
+    dp.step()
+    torch.cuda.synchronize()
+    for c, c0, g in zip(emb.tt_cores, cores, want):
+        np.testing.assert_allclose(c.detach()[0].cpu().numpy(), c0 - np.float32(lr) * g, rtol=0,
+                                   atol=1e-6 + 2e-4 * float(np.abs(lr * g).max()))

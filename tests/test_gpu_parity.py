@@ -366,6 +366,25 @@ def test_random_shapes_generic(nat, orc, seed):
     assert_grads_close(grads, orc.tt_dense_backward(idx, offsets, d_out, cores, p, q, R), rel=2e-4)
 
 
+@pytest.mark.parametrize("q,r", [([5, 5, 4], 256), ([5, 5, 4], 128), ([4, 4, 8], 256), ([4, 5, 5], 8)])
+def test_generic_kernels_take_the_rank_sweep_of_the_run_scripts(nat, orc, q, r):
+    """run_script.sh:250-288 sweeps --tt-rank up to 256,256 with q = 5,5,4 / 4,4,8: the wave-per-id kernels need up to
+    80 KB of LDS per wavefront there (gfx950 has 160 KB per CU; the launch is allowed per kernel).  Forward and dense
+    backward against the oracle on a small table."""
+    nat.set_path(nat.PATH_GENERIC)
+    p, R = [6, 7, 9], [1, r, r, 1]
+    rng = np.random.default_rng(r + q[2])
+    cores = [(rng.standard_normal((p[t], R[t] * q[t] * R[t + 1])) * (0.3 if t == 0 else 0.3 / np.sqrt(r))).astype(np.float32)
+             for t in range(3)]
+    idx, offsets = _random_bags(rng, int(np.prod(p)), 600)
+    out, _ = run_forward(nat, p, q, R, cores, idx, offsets)
+    want = orc.tt_forward(idx, offsets, cores, p, q, R)
+    np.testing.assert_allclose(out, want, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(want).max())))
+    d_out = ((rng.random(want.shape) - 0.5) * 0.2).astype(np.float32)
+    grads = run_backward_dense(nat, p, q, R, cores, idx, offsets, d_out)
+    assert_grads_close(grads, orc.tt_dense_backward(idx, offsets, d_out, cores, p, q, R), rel=2e-4)
+
+
 @pytest.mark.parametrize("shape", sorted(FAST3_SHAPES))
 @pytest.mark.parametrize("seed", [0, 1])
 def test_random_tables_fast_path(nat, orc, shape, seed):

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import ROOT, load_golden
+from conftest import PKG, ROOT, load_golden
 
 import ttemb_native as nat
 from FBTT.tt_embeddings_ops import (BufferList, OptimType, TableBatchedTTEmbeddingBag, TTEmbeddingBag,
@@ -183,7 +183,7 @@ def test_tt_svd_recovers_a_tt_matrix(p, q, r):
 
 def test_tt_svd_truncation_is_monotone_and_shim_matches():
     import ttemb_init
-    import tt_utils
+    import ttemb_tt_utils as tt_utils
     p, q = [8, 6, 5], [2, 2, 3]
     table = torch.randn(240, 12, generator=torch.Generator().manual_seed(3))
     errs = []
@@ -198,7 +198,7 @@ def test_tt_svd_truncation_is_monotone_and_shim_matches():
 
 def test_ortho_cores_are_orthonormal_frames():
     import ttemb_init
-    import tt_utils
+    import ttemb_tt_utils as tt_utils
     p, q, r = [12, 14, 48], [4, 5, 5], [8, 8]
     R = [1] + r + [1]
     cores = ttemb_init.ortho_cores(r, p, q, generator=torch.Generator().manual_seed(1))
@@ -238,3 +238,33 @@ def test_product_never_touches_the_oracle():
     assert offenders == []
     bench = (root / "bench.py").read_text()
     assert bench.count("from oracle import") == 1 and "cpu_einsum" in bench   # the cpu_baseline leg only
+
+
+def test_import_resolution_next_to_a_reference_shaped_tree(tmp_path):
+    """the package directory goes in FRONT of the reference tree on sys.path.  The reference keeps
+    `FBTT/` as a namespace directory (no __init__.py) and has a top-level `tt_utils.py` that every driver star-imports
+    for its argument parser.  With a fake tree of that shape: `FBTT.tt_embeddings_ops` must resolve to this package,
+    `tt_utils` to the reference's file (this package ships its initialisers as `ttemb_tt_utils`)."""
+    import subprocess
+    import sys
+    ref = tmp_path / "reference"
+    (ref / "FBTT").mkdir(parents=True)
+    (ref / "FBTT" / "tt_embeddings_ops.py").write_text("WHO = 'reference'\n")
+    (ref / "tt_utils.py").write_text("WHO = 'reference'\ndef parse_args():\n    return 'reference parser'\n")
+    (ref / "driver.py").write_text(
+        "from tt_utils import *\n"
+        "import tt_utils, FBTT.tt_embeddings_ops as ops, ttemb_tt_utils\n"
+        "print(tt_utils.WHO, parse_args(), ops.__file__, hasattr(ops, 'TTEmbeddingBag'), ttemb_tt_utils.__file__)\n")
+    for how in ("pythonpath", "insert"):
+        env = dict(os.environ)
+        if how == "pythonpath":
+            env["PYTHONPATH"] = PKG + os.pathsep + env.get("PYTHONPATH", "")
+            cmd = [sys.executable, "driver.py"]
+        else:
+            cmd = [sys.executable, "-c", f"import sys; sys.path.insert(0, {str(ref)!r}); sys.path.insert(0, {PKG!r}); "
+                                         "exec(open('driver.py').read())"]
+        out = subprocess.run(cmd, cwd=ref, env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        who, parser, _, ops_file, has_class, shim = out.stdout.split()   # "reference parser" prints as two words
+        assert who == "reference" and parser == "reference"
+        assert ops_file.startswith(PKG) and has_class == "True" and shim.startswith(PKG)

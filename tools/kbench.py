@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--cfg", default="products")
     ap.add_argument("--n", type=int, nargs="+", default=[409600])
     ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--dist", default="uniform", choices=["uniform", "windows", "arange"])
+    ap.add_argument("--dist", default="uniform", choices=["uniform", "windows", "arange", "grouped"])
     ap.add_argument("--path", default="auto")
     ap.add_argument("--what", default="both", choices=["both", "fwd", "bwd"])
     a = ap.parse_args()
@@ -48,6 +48,10 @@ def main():
             ids = rng.choice(n_emb, size=N, replace=False)
         elif a.dist == "arange":
             ids = np.arange(N) % n_emb
+        elif a.dist == "grouped":   # uniform ids handed over in the order the grouping pass gives them: rows of the
+            ids = rng.choice(n_emb, size=N, replace=False)   # [N, D] tensors are then visited (almost) sequentially
+            i0, rem = ids // (p[1] * p[2]), ids % (p[1] * p[2])
+            ids = ids[np.argsort((rem // p[2]) * p[0] + i0, kind="stable")]
         else:  # METIS-like: windows of 200 consecutive ids
             starts = rng.choice(n_emb // 200 - 1, size=(N + 199) // 200, replace=False) * 200
             ids = (starts[:, None] + np.arange(200)[None, :]).reshape(-1)[:N]
