@@ -121,7 +121,7 @@ __device__ __forceinline__ void buf_store1(rsrc_t r, uint32_t voff, float x) {
 // (s_load_dwordx4), which are counted by lgkmcnt, not vmcnt, and so never sit in the queue of the row loads.
 typedef const __attribute__((address_space(4))) uint32_t* desc_ptr;
 __device__ __forceinline__ uint4 load_desc(desc_ptr tab, uint32_t c, uint32_t nchunks) {
-  const uint32_t at = 4u * (c < nchunks ? c : nchunks - 1);
+  const uint32_t at = 4u * (c < nchunks ? c : (nchunks ? nchunks - 1 : 0u));   // (the table always has an entry)
   const uint32_t keep = c < nchunks ? 0xffffffffu : 0u;   // past the table: an empty chunk
   return make_uint4(tab[at] & keep, tab[at + 1] & keep, tab[at + 2] & keep, tab[at + 3] & keep);
 }
@@ -565,79 +565,92 @@ __global__ __launch_bounds__(kRangeThreads) void fast3_place_prefix_kernel(uint3
 // ---------------------------------------------------------------------------------
 // forward
 //
-// One wavefront takes kCPWF consecutive chunk descriptors.  Everything it needs for a chunk is known two
+// One wavefront takes a contiguous share of the chunk descriptors.  Everything it needs for a chunk is known two
 // steps ahead, so the loop is a software pipeline with no data-dependent control flow: while chunk c is
 // multiplied, the G2 rows and the prefix product of chunk c+1 are in flight into registers and the (i2, row)
 // pairs of chunk c+2 are being fetched.  Lanes are tied to ids four by four (lane = 4 * id + piece): a lane
 // loads the pieces j, j+4, ... of "its" id's rows and later stores the same pieces of its output row, so no
 // lane ever needs another lane's index.
 // ---------------------------------------------------------------------------------
-#ifndef TTEMB_CPW_FWD
-#define TTEMB_CPW_FWD 3
+// The chain kernels are persistent: a workgroup is kChainWaves INDEPENDENT wavefronts (one per SIMD: they share
+// nothing and never meet at a barrier), the grid is sized to the machine and every wavefront takes an equal,
+// contiguous share of the chunk table.  On gfx950 an fp32 MFMA does not co-issue with other vector work of ANY
+// wavefront on its SIMD (tools/micro/mfma_valu.hip: an MFMA-only and a VALU-only partner wave take the SUM of their
+// times), so a SIMD's time is the sum of everything its waves issue.  The kernels are therefore built to issue
+// little besides MFMAs:
+//   * per-chunk tables (the (i2, row) pairs, E rows, P / dP of the group) are addressed through buffer descriptors
+//     re-based on the chunk in SCALAR registers: the per-lane offsets are kernel-lifetime constants, the descriptor's
+//     size does the clipping (rows past the chunk's length read zeros / are not stored), no vector instruction
+//     computes or predicates an address;
+//   * rows of the caller's tensors need one multiply-add per lane and chunk (row number -> byte offset), their
+//     pieces ride in the instructions' immediate offsets;
+//   * MFMA tiles / K-steps that hold no id of a short chunk are skipped (wave-uniform branches around MFMA-only code).
+#ifndef TTEMB_CHAIN_WAVES
+#define TTEMB_CHAIN_WAVES 4
 #endif
-#ifndef TTEMB_CPW_BWD
-#define TTEMB_CPW_BWD 2
-#endif
-constexpr int kCPWF = TTEMB_CPW_FWD, kCPWB = TTEMB_CPW_BWD;   // chunk descriptors per wavefront
-#ifdef TTEMB_NO_ALIGN_ROWS
-constexpr bool kAlignRows = false;
+constexpr int kChainWaves = TTEMB_CHAIN_WAVES;       // wavefronts per workgroup of the chain kernels
+constexpr uint32_t kOobBase = 0x80000000u;           // a byte offset past every table (fast3_fits keeps them < 2 GiB)
+
+__device__ __forceinline__ uint32_t uniform(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
+// A wavefront in its multiply phase streams MFMAs; its SIMD partner's loads, stores and LDS traffic then queue behind
+// them (the oldest wave wins the issue port).  Everything that is not an MFMA section runs at raised priority, so a
+// memory instruction waits for at most the MFMA in flight.
+#ifdef TTEMB_NO_PRIO
+#define TTEMB_PRIO(x)
 #else
-constexpr bool kAlignRows = true;   // rows of the caller's [B, D] tensors move as aligned 64-byte blocks
+#define TTEMB_PRIO(x) __builtin_amdgcn_s_setprio(x)
 #endif
 
 template <int Q0, int Q1, int Q2, int R1, int R2>
-__global__ __launch_bounds__(64) void fast3_forward_kernel(const float* __restrict__ G2, GroupPlan plan, uint32_t G,
-                                                           uint32_t p2, uint32_t nnz, float* __restrict__ out,
-                                                           uint32_t out_bytes) {
+__global__ __launch_bounds__(kChainWaves * 64) void fast3_forward_kernel(const float* __restrict__ G2, GroupPlan plan, uint32_t G,
+                                                                         uint32_t p2, uint32_t nnz, float* __restrict__ out,
+                                                                         uint32_t out_bytes) {
   using C = Cfg<Q0, Q1, Q2, R1, R2>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = uniform(threadIdx.x >> 6);
   const int hi = lane >> 4, lo = lane & 15;
   const int b_l = lane >> 2, j_l = lane & 3;   // this lane's id inside a chunk, and which pieces of its rows
-  float* pbuf = smem;
+  float* pbuf = smem + wave * C::WAVE_FLOATS;
   float* bbuf = pbuf + C::P_FLOATS;
   float* obuf = bbuf;
 
-  const uint32_t nchunks = (uint32_t)(plan.gpre[G] >> 32);
-  const uint32_t c0 = blockIdx.x * kCPWF;
+  const desc_ptr ctab = (desc_ptr)plan.ctab;
+  const uint32_t nchunks = ((desc_ptr)plan.gpre)[2u * G + 1u];
+  const uint32_t nwaves = gridDim.x * kChainWaves, gw = blockIdx.x * kChainWaves + wave;
+  const uint32_t per = (nchunks + nwaves - 1) / nwaves;
+  const uint32_t c0 = gw * per;
   if (c0 >= nchunks) return;
-  const uint32_t c1 = c0 + kCPWF < nchunks ? c0 + kCPWF : nchunks;
+  const uint32_t c1 = c0 + per < nchunks ? c0 + per : nchunks;
 
   constexpr int F4G = C::ROW2 / 4, NLG = (F4G + 3) / 4;     // float4 pieces of a G2 row / per lane
-  constexpr int D4 = C::D / 4, NLO = (D4 % 4 == 0 || !kAlignRows) ? (D4 + 3) / 4 : (D4 + 6) / 4;   // float4 pieces of an output row / per lane
+  constexpr int D4 = C::D / 4, NLO = (D4 + 3) / 4;          // float4 pieces of an output row / per lane
   constexpr int PF = C::M2 * R2, PF4 = PF / 4, NLP = (PF4 + kWave - 1) / kWave;
-  const desc_ptr ctab = (desc_ptr)plan.ctab;
-  const rsrc_t r_i2 = make_rsrc(plan.i2s, nnz * 4u), r_val = make_rsrc(plan.vals, nnz * 4u);
   const rsrc_t r_g2 = make_rsrc(G2, p2 * (uint32_t)C::ROW2 * 4u);
-  const rsrc_t r_p = make_rsrc(plan.ptab, G * (uint32_t)PF * 4u);
   const rsrc_t r_out = make_rsrc(out, out_bytes);
+  const uint32_t rowpiece = 16u * (uint32_t)j_l;
+  const uint32_t g_last = (F4G % 4 == 0 || j_l + 4 * (NLG - 1) < F4G) ? rowpiece + 64u * (NLG - 1) : kOobBase;
+  const bool o_has_last = D4 % 4 == 0 || j_l + 4 * (NLO - 1) < D4;
 
   // Pipeline of one wavefront (k = the chunk being multiplied):
   //     multiply chunk k out of LDS, rows -> LDS -> registers | G2 rows of k+1: registers -> LDS | offsets of k+2 from
   //     its (i2, row) pairs | store the rows of k | load the G2 rows (and P) of k+2 | load the pairs of k+3
   // Stores are issued only after everything the next steps wait for has been consumed, so no wait sits behind a store.
-  struct Offs {
-    uint32_t row, prow;   // byte offsets of this lane's pieces: G2 row, P (kOob = same group as before)
-  };
   auto fetch_meta = [&](const uint4& d, uint32_t& i2, uint32_t& val) {
-    const uint32_t voff = b_l < (int)(d.z & 0xffu) ? (d.x + (uint32_t)b_l) * 4u : kOob;
-    i2 = buf_load1u(r_i2, voff);   // unused slots read 0: row 0 stands in
-    val = buf_load1u(r_val, voff);
-  };
-  auto offsets = [&](const uint4& d, uint32_t i2, bool with_p) {
-    Offs o;
-    o.row = i2 * (uint32_t)(C::ROW2 * 4) + 16u * j_l;
-    o.prow = with_p ? d.y * (uint32_t)(PF * 4) + 16u * lane : kOob;
-    return o;
+    const uint32_t len = d.z & 0xffu;   // lanes past the chunk's length read 0: G2 row 0 stands in, nothing of theirs is stored
+    const uint32_t at = uniform(d.x), bytes = uniform(len * 4u);   // (loop-carried words may sit in vector registers)
+    i2 = buf_load1u(make_rsrc(plan.i2s + at, bytes), 4u * (uint32_t)b_l);
+    val = buf_load1u(make_rsrc(plan.vals + at, bytes), 4u * (uint32_t)b_l);
   };
   float4 pre_g[NLG], pre_p[NLP];
-  auto request = [&](const Offs& o) {
+  auto request = [&](uint32_t row, const uint4& d) {   // row: byte offset of the lane's G2 row
 #pragma unroll
     for (int k = 0; k < NLG; ++k)
-      pre_g[k] = buf_load4(r_g2, (F4G % 4 == 0 || j_l + 4 * k < F4G) ? o.row + 64u * k : kOob);
+      pre_g[k] = k + 1 < NLG ? buf_load4(r_g2, row + rowpiece + 64u * k) : buf_load4(r_g2, row + g_last);
+    // P of a new group: the descriptor is re-based on the group's slot, empty when the chunk continues a group
+    const rsrc_t r_p = make_rsrc(plan.ptab + (size_t)uniform(d.y) * PF, uniform((d.z & kFirstBit) ? (uint32_t)(PF * 4) : 0u));
 #pragma unroll
-    for (int it = 0; it < NLP; ++it)
-      pre_p[it] = buf_load4(r_p, (o.prow != kOob && (PF4 % kWave == 0 || it * kWave + lane < PF4)) ? o.prow + 1024u * it : kOob);
+    for (int it = 0; it < NLP; ++it) pre_p[it] = buf_load4(r_p, 16u * (uint32_t)lane + 1024u * it);
   };
   auto stage = [&](bool with_p) {   // registers -> LDS
     if (with_p) {   // the prefix product of a new group, as a (q0 q1) x r2 matrix (P rows are padded: b32 writes)
@@ -667,103 +680,105 @@ __global__ __launch_bounds__(64) void fast3_forward_kernel(const float* __restri
   uint32_t i2_a, val_cur, i2_b, val_nxt;
   fetch_meta(d_cur, i2_a, val_cur);
   fetch_meta(d_nxt, i2_b, val_nxt);
-  request(offsets(d_cur, i2_a, true));
+  {   // a share may begin inside a group: its first chunk needs P whatever its flags say
+    uint4 d0 = d_cur;
+    d0.z |= kFirstBit;
+    request(__umul24(i2_a, (uint32_t)(C::ROW2 * 4)), d0);   // i2 < p2 <= 4096
+  }
   stage(true);
   __builtin_amdgcn_sched_barrier(0);
-  request(offsets(d_nxt, i2_b, (d_nxt.z & kFirstBit) != 0u));
+  request(__umul24(i2_b, (uint32_t)(C::ROW2 * 4)), d_nxt);
   uint32_t i2_nn, val_nn;
   fetch_meta(d_nn, i2_nn, val_nn);
 
   for (uint32_t c = c0;; ++c) {
-    const int len = (int)(d_cur.z & 0xffu);
+    const uint32_t len = d_cur.z & 0xffu;
     const uint32_t val = val_cur;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- stage 2: (q0 q1 x r2) . (r2 x 16 q2), one 16-row tile of P at a time ----
-    float bv[C::KS2][C::NT2];
+    TTEMB_PRIO(0);
+    // ---- stage 2: (q0 q1 x r2) . (r2 x 16 q2): the A operand (P) is read once, then one column tile (16 of the
+    //      16 q2 columns = ids 16 nt / q2 ...) at a time; tiles past the chunk's last id are skipped ----
+    float av[C::MT2][C::KS2];
 #pragma unroll
-    for (int s = 0; s < C::KS2; ++s)
+    for (int mt = 0; mt < C::MT2; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < C::NT2; ++nt) {
+      for (int s = 0; s < C::KS2; ++s) av[mt][s] = pbuf[(16 * mt + lo) * C::LDA + 4 * s + hi];
+    float bv[C::NT2][C::KS2];
+#pragma unroll
+    for (int nt = 0; nt < C::NT2; ++nt) {
+      if ((uint32_t)(16 * nt) < len * Q2) {
         const int n = 16 * nt + lo;
-        bv[s][nt] = bbuf[(n / Q2) * C::LDB + (4 * s + hi) * Q2 + n % Q2];
+#pragma unroll
+        for (int s = 0; s < C::KS2; ++s) bv[nt][s] = bbuf[(n / Q2) * C::LDB + (4 * s + hi) * Q2 + n % Q2];
       }
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();  // every staged-G2 read is done: the region becomes the row buffer
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int mt = 0; mt < C::MT2; ++mt) {
-      f32x4 acc[C::NT2];
+    for (int nt = 0; nt < C::NT2; ++nt) {
+      if ((uint32_t)(16 * nt) < len * Q2) {
+        const int n = 16 * nt + lo;
+        const int b = n / Q2, kk = n % Q2;
+        f32x4 acc[C::MT2];   // the row tiles' accumulation chains alternate
 #pragma unroll
-      for (int s = 0; s < C::KS2; ++s) {
-        const float a = pbuf[(16 * mt + lo) * C::LDA + 4 * s + hi];
+        for (int s = 0; s < C::KS2; ++s)
 #pragma unroll
-        for (int nt = 0; nt < C::NT2; ++nt)
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[s][nt], s == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[nt], 0, 0, 0);
-      }
-      // rows -> LDS, id-major.  When q0 q1 is a multiple of 4 a lane's four rows 16 mt + 4 hi + r are in or out together
-      if (16 * mt + 4 * hi + (C::M2 % 4 == 0 ? 3 : 0) < C::M2) {
+          for (int mt = 0; mt < C::MT2; ++mt)
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][s], bv[nt][s], s == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[mt], 0, 0, 0);
+        // rows -> LDS, id-major.  When q0 q1 is a multiple of 4 a lane's four rows 16 mt + 4 hi + r are in or out together
 #pragma unroll
-        for (int nt = 0; nt < C::NT2; ++nt) {
-          const int n = 16 * nt + lo;
-          const int b = n / Q2, kk = n % Q2;
+        for (int mt = 0; mt < C::MT2; ++mt) {
+          if (16 * mt + 4 * hi + (C::M2 % 4 == 0 ? 3 : 0) < C::M2) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (C::M2 % 4 == 0 || 16 * mt + 4 * hi + r < C::M2) obuf[b * C::LDO + (16 * mt + 4 * hi + r) * Q2 + kk] = acc[nt][r];
+            for (int r = 0; r < 4; ++r)
+              if (C::M2 % 4 == 0 || 16 * mt + 4 * hi + r < C::M2) obuf[b * C::LDO + (16 * mt + 4 * hi + r) * Q2 + kk] = acc[mt][r];
+          }
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    TTEMB_PRIO(2);
     // ---- this lane's pieces of its output row: LDS -> registers ----
-    // Rows of D floats start on a 16-byte slot that is `sh` slots past a 64-byte boundary: the four lanes of an id
-    // take the pieces of one ALIGNED 64-byte block per instruction (piece 4k + j - sh), so a store instruction
-    // never straddles two 64-byte halves of a cache line (D a multiple of 16: sh = 0, nothing changes).
-    const int sh = kAlignRows && D4 % 4 != 0 ? (int)(((val & 3u) * (uint32_t)(D4 & 3)) & 3u) : 0;
     float4 x[NLO];
 #pragma unroll
     for (int k = 0; k < NLO; ++k) {
-      const int pc = 4 * k + j_l - sh;
-      const int idx = pc < 0 ? 0 : (pc < D4 ? pc : D4 - 1);
+      const int idx = 4 * k + j_l < D4 ? 4 * k + j_l : D4 - 1;
       x[k] = *reinterpret_cast<const float4*>(obuf + b_l * C::LDO + 4 * idx);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();  // the row buffer has been read: the next chunk's G2 rows may land in it
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- G2 rows (and P) of the next chunk: registers -> LDS; then the offsets of the chunk after ----
+    // ---- G2 rows (and P) of the next chunk: registers -> LDS; then the row offset of the chunk after (consumes its
+    //      pair here, in front of the stores: behind them its wait would cover every store as well) ----
     stage((d_nxt.z & kFirstBit) != 0u);
-    const Offs o_nn = offsets(d_nn, i2_nn, (d_nn.z & kFirstBit) != 0u);
+    const uint32_t row_nn = __umul24(i2_nn, (uint32_t)(C::ROW2 * 4));
+    asm volatile("" ::"v"(row_nn), "v"(val_nxt));
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- 16-byte global stores, four lanes per row: no load is waited for behind these stores ----
     {
-      const bool row_ok = b_l < len;
-      // B*D*4 < 2^32: checked on the host (the offset of a piece before the row wraps; those pieces are masked)
-      const uint32_t row_off = (val & ~kMultiBit) * (uint32_t)(C::D * 4) + 16u * (uint32_t)(j_l - sh);
-      auto piece_ok = [&](int k) {   // piece 4k + j - sh lies inside the row (only the first / last k can miss)
-        const int pc = 4 * k + j_l - sh;
-        return (k > 0 || pc >= 0) && (4 * k + 3 < D4 || pc < D4);
-      };
-      if (__ballot(row_ok && (val & kMultiBit)) == 0ull) {  // the usual case: every bag of the chunk holds one id
+      const bool row_ok = (uint32_t)b_l < len;
+      const bool multi = (val & kMultiBit) != 0u;
+      const uint32_t row_off = __umul24(val & 0x00ffffffu, (uint32_t)(C::D * 4)) + rowpiece;   // rows < 2^24 (fast3_fits)
+      const uint32_t off = row_ok && !multi ? row_off : kOobBase;   // bags with several ids accumulate below
 #pragma unroll
-        for (int k = 0; k < NLO; ++k)
-          buf_store4(r_out, (row_ok && piece_ok(k)) ? row_off + 64u * k : kOob, x[k]);
-      } else {  // bags with several ids accumulate with float atomics; the others keep the same seven stores
-        // (buffer atomics fault on an out-of-range offset instead of vanishing, so those sit in a branch)
-        const bool multi = (val & kMultiBit) != 0u;
-#pragma unroll
-        for (int k = 0; k < NLO; ++k)
-          buf_store4(r_out, (row_ok && !multi && piece_ok(k)) ? row_off + 64u * k : kOob, x[k]);
-        if (row_ok && multi) {
-          float* dst = out + (val & ~kMultiBit) * (uint32_t)C::D;
+      for (int k = 0; k < NLO; ++k) buf_store4(r_out, (k + 1 < NLO || o_has_last) ? off + 64u * k : kOobBase, x[k]);
+      if (__ballot(row_ok && multi) != 0ull) {  // rare: float atomics (buffer atomics fault on an out-of-range offset
+        if (row_ok && multi) {                  // instead of vanishing, so they sit in a branch)
+          float* dst = out + (size_t)(val & 0x00ffffffu) * (uint32_t)C::D;
 #pragma unroll
           for (int k = 0; k < NLO; ++k) {
-            const int idx = 4 * k + j_l - sh;
-            if (piece_ok(k)) {
+            const int idx = 4 * k + j_l;
+            if (k + 1 < NLO || o_has_last) {
               atomicAdd(dst + 4 * idx + 0, x[k].x);
               atomicAdd(dst + 4 * idx + 1, x[k].y);
               atomicAdd(dst + 4 * idx + 2, x[k].z);
@@ -775,7 +790,7 @@ __global__ __launch_bounds__(64) void fast3_forward_kernel(const float* __restri
     }
     if (c + 1 >= c1) break;
     // ---- loads of the chunk after next, pairs of the one after that ----
-    request(o_nn);
+    request(row_nn, d_nn);
     d_cur = d_nxt;
     d_nxt = d_nn;
     val_cur = val_nxt;
@@ -799,48 +814,81 @@ __global__ __launch_bounds__(64) void fast3_forward_kernel(const float* __restri
 // LDS float atomics cost ~160 LDS cycles per wave-instruction on gfx950 (measured), global
 // ones ~1.3 TB/s chip-wide; a store pass + per-destination sum pass is several times cheaper.
 // ---------------------------------------------------------------------------------
-template <int Q0, int Q1, int Q2, int R1, int R2>
-__global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(const float* __restrict__ G2, uint32_t G, uint32_t p2,
-                                                             uint32_t nnz, const float* __restrict__ d_out,
-                                                             uint32_t dout_bytes, GroupPlan plan) {
+// FUSE: the dG2 reduction happens inside this kernel and the E table never exists.  The workgroup is then kFuseWaves = 8
+// wavefronts that walk their shares in lock step: every round each wavefront multiplies one chunk and leaves its E rows
+// (16 x r2 q2 floats) in LDS, where its staged G2 rows were, and links every row into the list of its i2 (one LDS
+// exchange per row: head[i2] <- row, next[row] <- old head).  After a barrier wavefront w adds the rows whose
+// i2 = w (mod 8) into "its" rows of the workgroup's dG2 slab, which it keeps in REGISTERS for the whole kernel: row
+// i2 = 8 k + w sits in register quad k / GPW of lane group k % GPW (a row is r2 q2 / 4 lanes wide, GPW rows side by
+// side).  A lane group walks the lists of its own rows -- quad by quad, so every register index is static -- and adds
+// plain: no float atomics, no slab in LDS, no scalar dispatch, and a repeated id is simply a list of two rows.  At the
+// end every wavefront stores its rows of the workgroup's slab (what the reduce kernel writes per tile in the unfused
+// form); fast3_finalize_kernel adds the slabs as before.
+#ifndef TTEMB_FUSE_WAVES
+#define TTEMB_FUSE_WAVES 4
+#endif
+// Four wavefronts (one per SIMD) and two such workgroups per CU: the lock step then never binds two wavefronts of one
+// SIMD -- with eight in one workgroup both partners multiplied, waited for memory and reduced at the same moments and
+// the kernel took twice as long -- while the two workgroups drift into complementary phases as independent waves do.
+constexpr int kFuseWaves = TTEMB_FUSE_WAVES;   // a power of two
+constexpr int kFuseQuads = 48 / kFuseWaves;    // register quads of slab rows per wavefront: p2 <= kFuseWaves * GPW * kFuseQuads
+constexpr int kFuseBatch = 6;                  // quads whose list heads / first rows are read together
+static_assert(kFuseQuads % kFuseBatch == 0, "quads are handled in whole batches");
+
+template <int Q0, int Q1, int Q2, int R1, int R2, bool FUSE>
+__global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / kFuseWaves : 1) void fast3_bwd_chunk_kernel(
+    const float* __restrict__ G2, uint32_t G, uint32_t p2, uint32_t nnz, const float* __restrict__ d_out, uint32_t dout_bytes,
+    GroupPlan plan) {
   using C = Cfg<Q0, Q1, Q2, R1, R2>;
+  constexpr int NW = FUSE ? kFuseWaves : kChainWaves;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = uniform(threadIdx.x >> 6);
   const int hi = lane >> 4, lo = lane & 15;
   const int b_l = lane >> 2, j_l = lane & 3;   // this lane's id inside a chunk, and which pieces of its rows
-  float* pbuf = smem;
+  constexpr int WF = C::PB_FLOATS + C::BB2_FLOATS + C::OB_FLOATS;
+  float* pbuf = smem + wave * WF;
+  // FUSE: [kFuseWaves] "has a chunk after this one" | [kFuseWaves * 16] list entry of every row of the round: {byte offset
+  // of the row in LDS, byte offset of the next entry of its list} | [heads] byte offset of the first entry of every i2's
+  // list.  Lists are chased by LDS byte offsets (relative to smem), so walking one costs no address arithmetic.
+  // An empty list is the list of the NIL entry: {a row of zeros, NIL itself}.  Walking a list therefore needs no test at
+  // all -- lanes whose list is empty or has ended add zeros -- and a head is reset by storing NIL.
+  float* f_zero = smem + NW * WF;                                      // [ROW2] zeros
+  uint32_t* f_more = reinterpret_cast<uint32_t*>(f_zero + C::ROW2);
+  uint2* f_tab = reinterpret_cast<uint2*>(f_more + kFuseWaves);        // [kFuseWaves * 16 + 1]: the last one is NIL
+  uint32_t* f_head = reinterpret_cast<uint32_t*>(f_tab + kFuseWaves * 16 + 1);   // [heads + 1]: the last one is for idle lanes
+  char* const lds0 = reinterpret_cast<char*>(smem);
+  const uint32_t f_nil = (uint32_t)(reinterpret_cast<char*>(f_tab + kFuseWaves * 16) - lds0);
+  const uint32_t my_entry = (uint32_t)(reinterpret_cast<char*>(f_tab + wave * 16 + b_l) - lds0);            // this lane's row: its entry
+  const uint32_t my_row = (uint32_t)((wave * WF + C::PB_FLOATS + b_l * C::ROW2) * sizeof(float));              // ... and its place
   float* bbuf = pbuf + C::PB_FLOATS;   // staged G2 rows
   float* dbuf = bbuf + C::BB2_FLOATS;  // staged d_output rows
 
-  // A wavefront owns the groups whose FIRST chunk lies in its kCPWB descriptors: it skips the tail of a
-  // group that began earlier and follows its last group to the end, so every group is handled by exactly
-  // one wavefront and its dP needs no partial sums.
-  const uint32_t nchunks = (uint32_t)(plan.gpre[G] >> 32);
-  const uint32_t c0 = blockIdx.x * kCPWB;
-  if (c0 >= nchunks) return;
-  const uint32_t c1 = c0 + kCPWB < nchunks ? c0 + kCPWB : nchunks;
+  // This wavefront's share of the chunk table.  It owns the groups whose FIRST chunk lies in its share: it skips
+  // the tail of a group that began earlier and follows its last group to the end, so every group is handled by
+  // exactly one wavefront and its dP needs no partial sums.
+  const desc_ptr ctab = (desc_ptr)plan.ctab;
+  const uint32_t nchunks = ((desc_ptr)plan.gpre)[2u * G + 1u];
+  const uint32_t nwaves = gridDim.x * NW, gw = blockIdx.x * NW + wave;
+  const uint32_t per = (nchunks + nwaves - 1) / nwaves;
+  const uint32_t c0 = gw * per;
+  bool have = c0 < nchunks;   // a wavefront without work leaves (FUSE: keeps meeting the barriers with empty chunks)
+  const uint32_t c1 = c0 + per < nchunks ? c0 + per : nchunks;
   uint32_t c = c0;
-  {
-    const uint4 d = plan.ctab[c0];
-    if (!(d.z & kFirstBit)) {
-      c = d.w;  // first chunk of the next group
-      if (c >= c1) return;
-    }
+  if (have && !(ctab[4u * c0 + 2u] & kFirstBit)) {
+    c = ctab[4u * c0 + 3u];  // first chunk of the next group
+    have = c < c1;
   }
+  if (!FUSE && !have) return;
 
   constexpr int F4G = C::ROW2 / 4, NLG = (F4G + 3) / 4;   // float4 pieces of a G2 row / per lane (4 lanes per id)
-  constexpr int F4D = C::D / 4, NLD = (F4D % 4 == 0 || !kAlignRows) ? (F4D + 3) / 4 : (F4D + 6) / 4;      // float4 pieces of a d_output row / per lane
+  constexpr int F4D = C::D / 4, NLD = (F4D + 3) / 4;      // float4 pieces of a d_output row / per lane
   constexpr int PF = C::M2 * R2, PF4 = PF / 4, NLP = (PF4 + kWave - 1) / kWave;
-  const desc_ptr ctab = (desc_ptr)plan.ctab;
-  const rsrc_t r_i2 = make_rsrc(plan.i2s, nnz * 4u), r_val = make_rsrc(plan.vals, nnz * 4u);
   const rsrc_t r_g2 = make_rsrc(G2, p2 * (uint32_t)C::ROW2 * 4u);
-  const rsrc_t r_p = make_rsrc(plan.ptab, G * (uint32_t)PF * 4u);
   const rsrc_t r_do = make_rsrc(d_out, dout_bytes);
-  const rsrc_t r_e = make_rsrc(plan.etab, nnz * (uint32_t)C::ROW2 * 4u);
-  const rsrc_t r_dp = make_rsrc(plan.dptab, G * (uint32_t)PF * 4u);
 
-  // ---- lane-constant LDS offsets of the MFMA operands ----
-  // dP step (b4, kk): lane group `hi` contributes id b = 4 b4 + hi, column kk of that id
+  // ---- kernel-lifetime lane constants ----
+  // LDS offsets of the MFMA operands.  dP step (b4, kk): lane group `hi` contributes id b = 4 b4 + hi, column kk of it
   int offA[C::MT2], offB[C::RT2], offE[C::NT2];
 #pragma unroll
   for (int mt = 0; mt < C::MT2; ++mt) {
@@ -854,6 +902,44 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(const float* __rest
     const int col = 16 * nt + lo;
     offE[nt] = (col / Q2) * C::LDOB + col % Q2 + hi * Q2;
   }
+  // byte offsets inside a chunk's E rows ([id][kk][c2]: col * r2 + c2, 16-byte pieces) and inside a group's dP
+  // ([m][c2]); a lane that holds no element of the table gets an offset past it
+  uint32_t eoff[C::RT2], dpoff[C::MT2][C::RT2];
+#pragma unroll
+  for (int t = 0; t < C::RT2; ++t) eoff[t] = 16 * t + 4 * hi < R2 ? (uint32_t)(lo * R2 + 16 * t + 4 * hi) * 4u : kOobBase;
+#pragma unroll
+  for (int mt = 0; mt < C::MT2; ++mt)
+#pragma unroll
+    for (int t = 0; t < C::RT2; ++t)
+      dpoff[mt][t] = 16 * t + lo < R2 ? (uint32_t)((16 * mt + 4 * hi) * R2 + 16 * t + lo) * 4u : kOobBase;   // rows >= M2 fall off the group's slot
+  const uint32_t rowpiece = 16u * (uint32_t)j_l;
+  // the last piece round of a row whose float4 count is not a multiple of 4 exists for some lanes only
+  const uint32_t g_last = (F4G % 4 == 0 || j_l + 4 * (NLG - 1) < F4G) ? rowpiece + 64u * (NLG - 1) : kOobBase;
+  const bool d_has_last = F4D % 4 == 0 || j_l + 4 * (NLD - 1) < F4D;
+  // FUSE: an E row in LDS is [kk][c2] like a row of the E table, its 16-byte quads XOR-swizzled by kk (the accumulator
+  // layout would otherwise put four lanes of a write on one bank group).  Producer: where this lane's accumulators go;
+  // consumer: which quad of a row this lane adds (lane group = which of the GPW rows of a register quad)
+  constexpr int LPR = C::ROW2 / 4, GPW = kWave / LPR, QK = R2 / 4;   // lanes per row, rows side by side, quads per kk
+  int ewr[C::NT2][C::RT2];
+#pragma unroll
+  for (int nt = 0; nt < C::NT2; ++nt)
+#pragma unroll
+    for (int t = 0; t < C::RT2; ++t) {
+      const int col = 16 * nt + lo, kk = col % Q2, quad = 4 * t + hi;
+      ewr[nt][t] = quad < QK ? (col / Q2) * C::ROW2 + kk * R2 + 4 * (quad ^ (kk & (QK - 1))) : -1;
+    }
+  const int s_grp = lane / LPR, s_piece = lane % LPR;
+  const int s_kk = s_piece / QK;
+  const int rd_off = s_kk * R2 + 4 * ((s_piece % QK) ^ (s_kk & (QK - 1)));   // float offset of this lane's quad inside a row
+  f32x4 slab[kFuseQuads];
+  if constexpr (FUSE) {
+#pragma unroll
+    for (int q = 0; q < kFuseQuads; ++q) slab[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i <= kFuseWaves * GPW * kFuseQuads; i += kFuseWaves * kWave) f_head[i] = f_nil;
+    for (int i = threadIdx.x; i < C::ROW2; i += kFuseWaves * kWave) f_zero[i] = 0.f;
+    if (threadIdx.x == 0) f_tab[kFuseWaves * 16] = make_uint2((uint32_t)(reinterpret_cast<char*>(f_zero) - lds0), f_nil);
+    __syncthreads();
+  }
 
   // Pipeline of one wavefront (k = the chunk being multiplied):
   //     multiply chunk k out of LDS | rows of k+1: registers -> LDS | offsets of k+2 from its (i2, row) pairs |
@@ -861,45 +947,37 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(const float* __rest
   // Stores are issued only after everything the next steps wait for has been consumed, so no wait ever sits
   // behind a store; rows travel through registers and are in flight during one whole multiply.
   struct Offs {
-    uint32_t row, grow, prow;   // byte offsets of this lane's pieces: G2 row, d_output row (kOob = no id), P
-    int sh;                     // 16-byte slots between the last 64-byte boundary and the start of the d_output row
+    uint32_t row, grow;   // byte offsets of this lane's first pieces: G2 row, d_output row (past the table = no id)
   };
   auto fetch_meta = [&](const uint4& d, uint32_t& i2, uint32_t& val) {
-    const uint32_t voff = b_l < (int)(d.z & 0xffu) ? (d.x + (uint32_t)b_l) * 4u : kOob;
-    i2 = buf_load1u(r_i2, voff);   // unused slots read 0: G2 row 0 stands in (its gradient row is zero)
-    val = buf_load1u(r_val, voff);
+    const uint32_t len = d.z & 0xffu;   // lanes past the chunk's length read 0: G2 row 0 stands in, its d_output row is zeros
+    const uint32_t at = uniform(d.x), bytes = uniform(len * 4u);   // (loop-carried words may sit in vector registers)
+    i2 = buf_load1u(make_rsrc(plan.i2s + at, bytes), 4u * (uint32_t)b_l);
+    val = buf_load1u(make_rsrc(plan.vals + at, bytes), 4u * (uint32_t)b_l);
   };
   auto offsets = [&](const uint4& d, uint32_t i2, uint32_t val) {
     Offs o;
-    o.row = i2 * (uint32_t)(C::ROW2 * 4) + 16u * j_l;
+    o.row = __umul24(i2, (uint32_t)(C::ROW2 * 4)) + rowpiece;                                 // i2 < p2 <= 4096
+    const uint32_t g = __umul24(val & 0x00ffffffu, (uint32_t)(C::D * 4));                     // rows < 2^24 (fast3_fits); drops kMultiBit
 #if defined(TTEMB_ABL) && (TTEMB_ABL & 2)
-    o.sh = 0;
-    o.grow = b_l < (int)(d.z & 0xffu) ? (val & 1023u) * (uint32_t)(C::D * 4) + 16u * j_l : kOob;  // ablation: cache-resident rows
+    o.grow = (uint32_t)b_l < (d.z & 0xffu) ? __umul24(val & 1023u, (uint32_t)(C::D * 4)) : kOobBase;   // ablation: cache-resident rows
 #else
-    // the four lanes of an id load the pieces of one aligned 64-byte block per instruction (see the forward kernel)
-    o.sh = kAlignRows && F4D % 4 != 0 ? (int)(((val & 3u) * (uint32_t)(F4D & 3)) & 3u) : 0;
-    o.grow = b_l < (int)(d.z & 0xffu) ? (val & ~kMultiBit) * (uint32_t)(C::D * 4) + 16u * (uint32_t)(j_l - o.sh) : kOob;  // B*D*4 < 2^32 (host)
+    o.grow = (uint32_t)b_l < (d.z & 0xffu) ? g : kOobBase;
 #endif
-    o.prow = (d.z & kFirstBit) ? d.y * (uint32_t)(PF * 4) + 16u * lane : kOob;
     return o;
   };
   float4 pre_g[NLG], pre_d[NLD], pre_p[NLP];
-  int sh_pre = 0;   // the shift of the d_output rows now in pre_d
-  auto dpiece_ok = [&](int k, int sh) {   // piece 4k + j - sh lies inside the row (only the first / last k can miss)
-    const int pc = 4 * k + j_l - sh;
-    return (k > 0 || pc >= 0) && (4 * k + 3 < F4D || pc < F4D);
-  };
-  auto request = [&](const Offs& o) {
-    sh_pre = o.sh;
+  auto request = [&](const Offs& o, const uint4& d) {
 #pragma unroll
     for (int k = 0; k < NLG; ++k)
-      pre_g[k] = buf_load4(r_g2, (F4G % 4 == 0 || j_l + 4 * k < F4G) ? o.row + 64u * k : kOob);
+      pre_g[k] = k + 1 < NLG ? buf_load4(r_g2, o.row + 64u * k) : buf_load4(r_g2, o.row - rowpiece + g_last);
 #pragma unroll
     for (int k = 0; k < NLD; ++k)
-      pre_d[k] = buf_load4(r_do, (o.grow != kOob && dpiece_ok(k, o.sh)) ? o.grow + 64u * k : kOob);
+      pre_d[k] = buf_load4(r_do, (k + 1 < NLD || d_has_last) ? o.grow + rowpiece + 64u * k : kOobBase);   // o.grow may be kOobBase itself
+    // P of a new group: the descriptor is re-based on the group's slot, empty when the chunk continues a group
+    const rsrc_t r_p = make_rsrc(plan.ptab + (size_t)uniform(d.y) * PF, uniform((d.z & kFirstBit) ? (uint32_t)(PF * 4) : 0u));
 #pragma unroll
-    for (int it = 0; it < NLP; ++it)
-      pre_p[it] = buf_load4(r_p, (o.prow != kOob && (PF4 % kWave == 0 || it * kWave + lane < PF4)) ? o.prow + 1024u * it : kOob);
+    for (int it = 0; it < NLP; ++it) pre_p[it] = buf_load4(r_p, 16u * (uint32_t)lane + 1024u * it);
   };
   auto stage = [&](bool with_p) {   // registers -> LDS
     if (with_p) {
@@ -917,8 +995,8 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(const float* __rest
     }
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
-      const int idx = 4 * k + j_l - sh_pre;
-      if (dpiece_ok(k, sh_pre)) *reinterpret_cast<float4*>(dbuf + b_l * C::LDOB + 4 * idx) = pre_d[k];
+      const int idx = j_l + 4 * k;
+      if (F4D % 4 == 0 || idx < F4D) *reinterpret_cast<float4*>(dbuf + b_l * C::LDOB + 4 * idx) = pre_d[k];
     }
   };
 
@@ -929,7 +1007,8 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(const float* __rest
 
   // ---- prologue: chunk 0 into LDS, rows of chunk 1 and the pairs of chunk 2 in flight ----
   uint4 d_cur = load_desc(ctab, c, nchunks);
-  bool more1 = has_next(c, d_cur);
+  if (!have) d_cur = none;
+  bool more1 = have && has_next(c, d_cur);
   uint4 d_nxt = load_desc(ctab, c + 1, nchunks);
   if (!more1) d_nxt = none;
   bool more2 = more1 && has_next(c + 1, d_nxt);
@@ -938,21 +1017,32 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(const float* __rest
   uint32_t i2_a, val_a, i2_b, val_b;
   fetch_meta(d_cur, i2_a, val_a);
   fetch_meta(d_nxt, i2_b, val_b);
-  request(offsets(d_cur, i2_a, val_a));
+  request(offsets(d_cur, i2_a, val_a), d_cur);
   stage(true);
   __builtin_amdgcn_sched_barrier(0);
-  request(offsets(d_nxt, i2_b, val_b));
+  request(offsets(d_nxt, i2_b, val_b), d_nxt);
   uint32_t i2_nn, val_nn;
   fetch_meta(d_nn, i2_nn, val_nn);
+  uint32_t i2_cur = i2_a, i2_nxt = i2_b;   // FUSE: the i2 of the rows being multiplied travel with them
 
+#ifdef TTEMB_STAMPS
+  long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_n = 0, st_t[11];
+  for (int i = 0; i < 11; ++i) st_t[i] = 0;
+#define TTEMB_STAMP(i) st_t[i] = clock64(); __builtin_amdgcn_sched_barrier(0)
+  const long long st_begin = clock64();
+#else
+#define TTEMB_STAMP(i)
+#endif
   for (;;) {
-    const int len = (int)(d_cur.z & 0xffu);
-    const uint32_t here = d_cur.x;
+    const uint32_t len = d_cur.z & 0xffu;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_sched_barrier(0);
+    TTEMB_PRIO(0);
+    TTEMB_STAMP(0);
     if (d_cur.z & kFirstBit) {
+      asm volatile("; a group begins" ::: "memory");   // keeps this a branch (as selects it costs a vector op per register and chunk)
 #pragma unroll
       for (int mt = 0; mt < C::MT2; ++mt)
 #pragma unroll
@@ -960,52 +1050,60 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(const float* __rest
     }
 
 #if !(defined(TTEMB_ABL) && (TTEMB_ABL & 4))
-    // ---- dP += dO (q0q1 x 16 q2) . G2s^T (16 q2 x r2) ----
+    // ---- dP += dO (q0q1 x 16 q2) . G2s^T (16 q2 x r2); K-steps whose four ids lie past the chunk's length are skipped ----
 #pragma unroll
-    for (int b4 = 0; b4 < kChunk / 4; ++b4)
+    for (int b4 = 0; b4 < kChunk / 4; ++b4) {
+      if ((uint32_t)(4 * b4) < len) {
 #pragma unroll
-      for (int kk = 0; kk < Q2; ++kk) {
-        float av[C::MT2], bv[C::RT2];
+        for (int kk = 0; kk < Q2; ++kk) {
+          float av[C::MT2], bv[C::RT2];
 #pragma unroll
-        for (int mt = 0; mt < C::MT2; ++mt) av[mt] = dbuf[offA[mt] + b4 * 4 * C::LDOB + kk];
+          for (int mt = 0; mt < C::MT2; ++mt) av[mt] = dbuf[offA[mt] + b4 * 4 * C::LDOB + kk];
 #pragma unroll
-        for (int t = 0; t < C::RT2; ++t) {
-          bv[t] = bbuf[offB[t] + b4 * 4 * C::LDBB + kk];
-          if (16 * t + lo >= R2) bv[t] = 0.f;
+          for (int t = 0; t < C::RT2; ++t) {
+            bv[t] = bbuf[offB[t] + b4 * 4 * C::LDBB + kk];
+            if (16 * t + lo >= R2) bv[t] = 0.f;
+          }
+#pragma unroll
+          for (int mt = 0; mt < C::MT2; ++mt)
+#pragma unroll
+            for (int t = 0; t < C::RT2; ++t)
+              dp[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv[t], dp[mt][t], 0, 0, 0);
         }
-#pragma unroll
-        for (int mt = 0; mt < C::MT2; ++mt)
-#pragma unroll
-          for (int t = 0; t < C::RT2; ++t)
-            dp[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv[t], dp[mt][t], 0, 0, 0);
-        if (kk == Q2 - 1) __builtin_amdgcn_sched_barrier(0);  // keeps operand loads from piling up in registers
       }
-
+      __builtin_amdgcn_sched_barrier(0);  // keeps operand loads from piling up in registers
+    }
 #endif
-    // ---- E = P^T (r2 x q0q1) . dO (q0q1 x 16 q2) ----
+    TTEMB_STAMP(1);
+    // ---- E = P^T (r2 x q0q1) . dO (q0q1 x 16 q2): the A operand (P^T) is read once, column tiles without an id are skipped ----
     f32x4 e[C::RT2][C::NT2];
-#pragma unroll
-    for (int t = 0; t < C::RT2; ++t)
-#pragma unroll
-      for (int nt = 0; nt < C::NT2; ++nt) e[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #if !(defined(TTEMB_ABL) && (TTEMB_ABL & 8))
+    constexpr int KS = (C::M2 + 3) / 4;
+    float ap[KS][C::RT2];
 #pragma unroll
-    for (int s = 0; s < (C::M2 + 3) / 4; ++s) {
+    for (int s = 0; s < KS; ++s) {
       // q0 q1 not a multiple of the MFMA K: the last step's rows past M2 are read (inside the buffers) and zeroed
       const bool k_ok = 4 * s + 3 < C::M2 || 4 * s + hi < C::M2;
-      float av[C::RT2];
 #pragma unroll
       for (int t = 0; t < C::RT2; ++t) {
-        av[t] = pbuf[(4 * s + hi) * C::LDPB + (16 * t + lo) % R2];
-        if (16 * t + lo >= R2 || !k_ok) av[t] = 0.f;
+        ap[s][t] = pbuf[(4 * s + hi) * C::LDPB + (16 * t + lo) % R2];
+        if (16 * t + lo >= R2 || !k_ok) ap[s][t] = 0.f;
       }
+    }
 #pragma unroll
-      for (int nt = 0; nt < C::NT2; ++nt) {
-        float bv = dbuf[offE[nt] + 4 * s * Q2];
-        if (!k_ok) bv = 0.f;
+    for (int nt = 0; nt < C::NT2; ++nt) {
+      if ((uint32_t)(16 * nt) < len * Q2) {
 #pragma unroll
-        for (int t = 0; t < C::RT2; ++t)
-          e[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv, e[t][nt], 0, 0, 0);
+        for (int t = 0; t < C::RT2; ++t) e[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          const bool k_ok = 4 * s + 3 < C::M2 || 4 * s + hi < C::M2;
+          float bv = dbuf[offE[nt] + 4 * s * Q2];
+          if (!k_ok) bv = 0.f;
+#pragma unroll
+          for (int t = 0; t < C::RT2; ++t)
+            e[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[s][t], bv, e[t][nt], 0, 0, 0);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1013,49 +1111,119 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(const float* __rest
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();  // every LDS read of this chunk is done: the next chunk's rows may land
     __builtin_amdgcn_sched_barrier(0);
+    TTEMB_PRIO(2);
+    TTEMB_STAMP(2);
 
     // ---- rows of the next chunk: registers -> LDS; then the offsets of the chunk after (consumes its pairs) ----
-    stage((d_nxt.z & kFirstBit) != 0u);
-    const Offs o_nn = offsets(d_nn, i2_nn, val_nn);
+    Offs o_nn;
+    if constexpr (!FUSE) {
+      stage((d_nxt.z & kFirstBit) != 0u);
+      o_nn = offsets(d_nn, i2_nn, val_nn);
+      // the offsets are needed only after the stores; computed there, their wait for the (i2, row) pairs would become a
+      // wait for every store in front of it as well (vmcnt counts in order): ~3 000 cycles per chunk.  Pin them here.
+      asm volatile("" ::"v"(o_nn.row), "v"(o_nn.grow));
+    }
     __builtin_amdgcn_sched_barrier(0);
+    TTEMB_STAMP(3);
 
     // ---- this chunk's results leave now: no load is waited for behind these stores ----
     // Lane (hi, lo) holds E[c2 = 16 t + 4 hi + r][col = 16 nt + lo] with col = id * q2 + kk, and the E table keeps
     // an id's row as [kk][c2] (the reduce kernel sums rows element by element, the finalize kernel puts dG2 back
-    // into [c2][kk]): the chunk's rows are one contiguous block indexed col * r2 + c2, written in 16-byte pieces.
+    // into [c2][kk]): the chunk's rows are one contiguous block indexed col * r2 + c2, written in 16-byte pieces
+    // through a descriptor that covers exactly this chunk's rows.
+    if constexpr (FUSE) {
+      // (the wave barrier above: every staged-G2 read of this chunk is done, the region takes the E rows)
 #pragma unroll
-    for (int nt = 0; nt < C::NT2; ++nt) {
-      const int col = 16 * nt + lo;
+      for (int nt = 0; nt < C::NT2; ++nt) {
+        if ((uint32_t)(16 * nt) < len * Q2) {
 #pragma unroll
-      for (int t = 0; t < C::RT2; ++t) {
-        const int c2 = 16 * t + 4 * hi;
-        const uint32_t off = (here * (uint32_t)C::ROW2 + (uint32_t)(col * R2 + c2)) * 4u;
-#if defined(TTEMB_ABL) && (TTEMB_ABL & 1)
-        buf_store4(r_e, kOob, make_float4(   // ablation: no E traffic
-#else
-        buf_store4(r_e, (col < len * Q2 && c2 < R2) ? off : kOob, make_float4(
-#endif
-            e[t][nt][0], e[t][nt][1], e[t][nt][2], e[t][nt][3]));
+          for (int t = 0; t < C::RT2; ++t)
+            if (ewr[nt][t] >= 0) *reinterpret_cast<f32x4*>(bbuf + ewr[nt][t]) = e[t][nt];
+        }
+      }
+      if (j_l == 0 && (uint32_t)b_l < len)   // the row joins the list of its i2
+        f_tab[wave * 16 + b_l] = make_uint2(my_row, atomicExch(&f_head[i2_cur], my_entry));
+      if (lane == 0) f_more[wave] = more1 ? 1u : 0u;
+    }
+#if !(defined(TTEMB_ABL) && (TTEMB_ABL & 1))
+    if constexpr (!FUSE) {
+      const rsrc_t r_e = make_rsrc(plan.etab + (size_t)uniform(d_cur.x) * C::ROW2, uniform(len) * (uint32_t)(C::ROW2 * 4));
+#pragma unroll
+      for (int nt = 0; nt < C::NT2; ++nt) {
+        if ((uint32_t)(16 * nt) < len * Q2) {
+#pragma unroll
+          for (int t = 0; t < C::RT2; ++t)
+            buf_store4(r_e, eoff[t] + (uint32_t)(16 * nt * R2 * 4), make_float4(e[t][nt][0], e[t][nt][1], e[t][nt][2], e[t][nt][3]));
+        }
       }
     }
-    {  // dP of a finished group (for the other chunks the stores fall off the end of the buffer)
-      const bool closing = (d_cur.z & kLastBit) != 0u;
-      const uint32_t base = d_cur.y * (uint32_t)(PF * 4);
+#endif
+    if (d_cur.z & kLastBit) {  // dP of a finished group, into its own slot
+      const rsrc_t r_dp = make_rsrc(plan.dptab + (size_t)uniform(d_cur.y) * PF, (uint32_t)(PF * 4));
 #pragma unroll
       for (int mt = 0; mt < C::MT2; ++mt)
 #pragma unroll
         for (int t = 0; t < C::RT2; ++t)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int m = 16 * mt + 4 * hi + r;
-            const int c2 = 16 * t + lo;
-            buf_store1(r_dp, (closing && m < C::M2 && c2 < R2) ? base + (uint32_t)(m * R2 + c2) * 4u : kOob, dp[mt][t][r]);
-          }
+          for (int r = 0; r < 4; ++r) buf_store1(r_dp, dpoff[mt][t] + (uint32_t)(r * R2 * 4), dp[mt][t][r]);
     }
-    if (!more1) break;
+    TTEMB_STAMP(4);
+    if constexpr (FUSE) {
+      __syncthreads();   // the round's E rows and their lists are in LDS
+      TTEMB_STAMP(5);
+      {
+        // slab row of this lane in quad q: i2 = 8 (q GPW + lane group) + wave.  First the heads of all quads, then the
+        // first row of every list (reads in flight together), then whatever is left of longer lists
+        // head of this lane's slab row in quad q: f_head[(q GPW + lane group) kFuseWaves + wave]; idle lanes use the spare word
+        uint32_t* const my_head = s_grp < GPW ? f_head + ((uint32_t)s_grp * kFuseWaves + wave) : f_head + kFuseWaves * GPW * kFuseQuads;
+        const int qstep = s_grp < GPW ? GPW * kFuseWaves : 0;
+        const char* const rows = lds0 + (uint32_t)rd_off * 4u;
+#pragma unroll
+        for (int q0 = 0; q0 < kFuseQuads; q0 += kFuseBatch) {
+          if ((uint32_t)(q0 * GPW * kFuseWaves) >= p2) break;   // wave-uniform: no slab row in the remaining quads
+          uint32_t en[kFuseBatch];   // entry being visited
+#pragma unroll
+          for (int u = 0; u < kFuseBatch; ++u) en[u] = my_head[(q0 + u) * qstep];   // heads past p2 hold NIL for ever
+#pragma unroll
+          for (int u = 0; u < kFuseBatch; ++u) my_head[(q0 + u) * qstep] = f_nil;   // (every lane of the group stores the same word)
+          // first row of every list: entries, then rows, in flight together
+          uint2 ent[kFuseBatch];
+#pragma unroll
+          for (int u = 0; u < kFuseBatch; ++u) ent[u] = *reinterpret_cast<const uint2*>(lds0 + en[u]);
+          f32x4 x[kFuseBatch];
+#pragma unroll
+          for (int u = 0; u < kFuseBatch; ++u) x[u] = *reinterpret_cast<const f32x4*>(rows + ent[u].x);
+#pragma unroll
+          for (int u = 0; u < kFuseBatch; ++u) slab[q0 + u] += x[u];
+          // what is left of longer lists (128 rows over ~140 values of i2: a third of the rows share their i2 with another)
+#pragma unroll
+          for (int u = 0; u < kFuseBatch; ++u) {
+            uint32_t e = ent[u].y;
+            while (__ballot(e != f_nil) != 0ull) {
+              const uint2 e2 = *reinterpret_cast<const uint2*>(lds0 + e);
+              slab[q0 + u] += *reinterpret_cast<const f32x4*>(rows + e2.x);
+              e = e2.y;
+            }
+          }
+        }
+      }
+      const bool any = __ballot(lane < kFuseWaves && f_more[lane & (kFuseWaves - 1)] != 0u) != 0ull;
+      TTEMB_STAMP(6);
+      __syncthreads();   // every E row has been added: the regions take the next chunks' rows
+      TTEMB_STAMP(7);
+      stage((d_nxt.z & kFirstBit) != 0u);
+      o_nn = offsets(d_nn, i2_nn, val_nn);
+      asm volatile("" ::"v"(o_nn.row), "v"(o_nn.grow));
+      TTEMB_STAMP(8);
+      if (!any) break;
+    } else {
+      if (!more1) break;
+    }
     // ---- loads of the chunk after next, pairs of the one after that ----
-    request(o_nn);
+    request(o_nn, d_nn);
     ++c;
+    i2_cur = i2_nxt;
+    i2_nxt = i2_nn;
     d_cur = d_nxt;
     d_nxt = d_nn;
     more1 = more2;
@@ -1063,7 +1231,29 @@ __global__ __launch_bounds__(64) void fast3_bwd_chunk_kernel(const float* __rest
     d_nn = load_desc(ctab, c + 2, nchunks);
     if (!more2) d_nn = none;
     fetch_meta(d_nn, i2_nn, val_nn);
+#ifdef TTEMB_STAMPS
+    __builtin_amdgcn_sched_barrier(0);
+    st_t[FUSE ? 9 : 5] = clock64();
+    for (int i = 0; i < (FUSE ? 9 : 5); ++i) st_acc[i] += st_t[i + 1] - st_t[i];
+    ++st_n;
+#endif
   }
+  if constexpr (FUSE) {
+    // this wavefront's rows of the workgroup's slab: i2 = 8 (q GPW + lane group) + wave, every row of the slab is written by
+    // one wavefront (zeros where no id came by); the lane's quad goes back to its place in the [kk][c2] row
+    float* tile = plan.g2part + (size_t)blockIdx.x * p2 * C::ROW2;
+#pragma unroll
+    for (int q = 0; q < kFuseQuads; ++q) {
+      const uint32_t i2 = (uint32_t)(q * GPW + s_grp) * kFuseWaves + wave;
+      if (s_grp < GPW && i2 < p2) *reinterpret_cast<f32x4*>(tile + (size_t)i2 * C::ROW2 + 4 * s_piece) = slab[q];
+    }
+  }
+#ifdef TTEMB_STAMPS
+  if (lane == 0 && wave == 0 && (blockIdx.x % 97) == 0 && st_n > 0)
+    printf("chunk kernel wg %u: %lld iterations, total %lld cycles; per iteration: dP %lld | E %lld | stage(+wait) %lld | stores %lld | request/B1 %lld | reduce %lld | B2 %lld | stage %lld | request %lld\n",
+           blockIdx.x, st_n, (long long)(clock64() - st_begin), st_acc[0] / st_n, st_acc[1] / st_n, st_acc[2] / st_n, st_acc[3] / st_n,
+           st_acc[4] / st_n, st_acc[5] / st_n, st_acc[6] / st_n, st_acc[7] / st_n, st_acc[8] / st_n);
+#endif
 }
 
 // B. dG2 reduce.  A workgroup takes kRowsB consecutive E rows, buckets them by i2 inside LDS
@@ -1527,8 +1717,8 @@ bool fast3_pays(const DevShape& s, int64_t nnz) {
 // the chain kernels address every table through 32-bit byte offsets (buffer descriptors): 4 GiB each; the dG2
 // reduce keeps two counters per i2 in LDS (p2 <= 4096: 36 KB); p1 is a grid.y extent
 bool fast3_fits(const DevShape& s, int64_t nnz, int64_t B) {
-  const int64_t lim = int64_t(1) << 32;
-  return B * s.D * 4 < lim && nnz * (int64_t)s.row_len[2] * 4 < lim &&
+  const int64_t lim = int64_t(1) << 31;   // an offset of 2 GiB marks "no row" in the chain kernels (kOobBase)
+  return B * s.D * 4 < lim && B < (int64_t(1) << 24) && nnz * (int64_t)s.row_len[2] * 4 < lim &&
          num_groups(s) * (int64_t)s.q[0] * s.q[1] * s.R[2] * 4 < lim && s.p[2] <= 4096 && s.p[1] < 65536 &&
          num_groups(s) <= (int64_t)kMaxRanges * 4096;   // the grouping pass: <= 512 ranges of <= 4096 groups (64 KB of LDS)
 }
@@ -1551,7 +1741,74 @@ constexpr int NWB = 16;
 static int64_t reduce_tiles(int64_t nnz) { const int r = reduce_rows(nnz); return (nnz + r - 1) / r; }
 // slabs of more than 256 KB are not replicated per tile: one shared slab, float atomics (see the reduce kernel)
 static bool shared_slab(const DevShape& s) { return (int64_t)s.p[2] * s.row_len[2] * 4 > (256 << 10); }
-static int64_t slab_count(const DevShape& s, int64_t nnz) { return shared_slab(s) ? 1 : reduce_tiles(nnz); }
+// Persistent launch of a chain kernel: `wgs_per_cu` workgroups of kChainWaves independent wavefronts per CU (fewer
+// when their LDS does not fit 160 KB that often), every wavefront takes an equal share of the chunk table.
+#ifndef TTEMB_BWD_WGS
+#define TTEMB_BWD_WGS 2
+#endif
+#ifndef TTEMB_FWD_WGS
+#define TTEMB_FWD_WGS 3
+#endif
+constexpr int kBwdWgsPerCu = TTEMB_BWD_WGS, kFwdWgsPerCu = TTEMB_FWD_WGS;
+constexpr size_t kCuLds = 160 * 1024;
+static int chain_cus() {   // CUs of the current device (256 on MI355X; also the answer when no device can be asked)
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+      cus = n;
+    else
+      cus = 256;
+  }
+  return cus;
+}
+static int allow_lds(const void* kernel, size_t lds, bool* lds_allowed) {
+  if (lds > kCuLds) return fail(TTEMB_E_UNSUPPORTED, "chain kernel needs %lld bytes of LDS per workgroup", (long long)lds);
+  if (lds > 64 * 1024 && !*lds_allowed) {
+    int rc = check_hip(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCuLds), "hipFuncSetAttribute");
+    if (rc) return rc;
+    *lds_allowed = true;
+  }
+  return TTEMB_OK;
+}
+static int chain_grid(const void* kernel, size_t lds, int wgs_per_cu, bool* lds_allowed, unsigned* grid) {
+  int rc = allow_lds(kernel, lds, lds_allowed);
+  if (rc) return rc;
+  int fit = (int)(kCuLds / (lds ? lds : 1));
+  if (fit > wgs_per_cu) fit = wgs_per_cu;
+  *grid = (unsigned)(chain_cus() * (fit < 1 ? 1 : fit));
+  return TTEMB_OK;
+}
+
+
+// The fused form of the backward chunk kernel (dG2 reduced inside it, no E table): a row of the slab must fit a
+// wavefront's lanes, the slab's rows the register quads of eight wavefronts, and eight wavefronts' staging the CU's LDS
+static int64_t max_chunks(const DevShape& s, int64_t nnz);
+static size_t bwd_wave_lds_floats(const DevShape& s) {   // = Cfg::PB_FLOATS + BB2_FLOATS + OB_FLOATS of the shape
+  const int M2 = s.q[0] * s.q[1], R2 = s.R[2], Q2 = s.q[2], ROW2 = R2 * Q2, D = s.D;
+  const int LDPB = (R2 % 32 == 0) ? R2 + 16 : R2;
+  const int LDBB = (Q2 % 2 == 1 && ROW2 % 32 == 16) ? ROW2 : ROW2 + 4;
+  const int LDOB = ((D + 15) / 32) * 32 + 16;
+  return (size_t)((M2 * LDPB + 3) / 4 * 4) + (size_t)kChunk * LDBB + (size_t)kChunk * LDOB;
+}
+static bool fused_dg2(const DevShape& s) {
+#ifdef TTEMB_NO_FUSE
+  return false;
+#endif
+  const int lpr = s.row_len[2] / 4;
+  if (lpr < 1 || lpr > kWave) return false;
+  const int gpw = kWave / lpr;
+  if (s.p[2] > kFuseWaves * gpw * kFuseQuads) return false;
+  return (size_t)kFuseWaves * bwd_wave_lds_floats(s) * 4 + (size_t)(s.row_len[2] + kFuseWaves * 33 + 3 + kFuseWaves * gpw * kFuseQuads) * 4 <= kCuLds;
+}
+static int64_t fused_tiles(const DevShape& s, int64_t nnz) {   // workgroups: at least ~2 chunks per wavefront, at most one per CU
+  const int64_t t = (max_chunks(s, nnz) + 2 * kFuseWaves - 1) / (2 * kFuseWaves);
+  const int64_t most = (int64_t)chain_cus() * (8 / kFuseWaves);
+  return t < 1 ? 1 : (t > most ? most : t);
+}
+static int64_t slab_count(const DevShape& s, int64_t nnz) {
+  return fused_dg2(s) ? fused_tiles(s, nnz) : (shared_slab(s) ? 1 : reduce_tiles(nnz));
+}
 // the epilogue cuts the i0 range of every i1 into ~kEpiSlices slices of `gpw` groups (one wavefront each)
 static int epi_groups_per_wave(const DevShape& s) {
   int gpw = (s.p[0] + kEpiSlices - 1) / kEpiSlices;
@@ -1626,7 +1883,7 @@ static int64_t carve_workspace(const DevShape& s, int64_t nnz, bool bwd, bool pl
     }
   }
   if (bwd) {
-    float* e = (float*)take(nnz * (int64_t)s.row_len[2] * 4);
+    float* e = (float*)take(fused_dg2(s) ? 0 : nnz * (int64_t)s.row_len[2] * 4);   // no E table in the fused form
     float* d = (float*)take(G * (int64_t)s.q[0] * s.q[1] * s.R[2] * 4);
     float* g2 = (float*)take(slab_count(s, nnz) * (int64_t)s.p[2] * s.row_len[2] * 4);
     float* g0 = (float*)take(G * (int64_t)s.row_len[0] * 4);
@@ -1748,17 +2005,17 @@ static int run_place_prefix(const DevShape& s, const CorePtrs& cores, const Grou
   return fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
 }
 
-static unsigned chunk_waves(const DevShape& s, int64_t nnz, int per_wave) {
-  return (unsigned)((max_chunks(s, nnz) + per_wave - 1) / per_wave);
-}
-
 template <int Q0, int Q1, int Q2, int R1, int R2>
 static int run_forward(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int64_t nnz, int64_t B,
                        float* output, hipStream_t st) {
   using C = Cfg<Q0, Q1, Q2, R1, R2>;
-  const size_t lds = C::WAVE_FLOATS * sizeof(float);
+  const size_t lds = (size_t)kChainWaves * C::WAVE_FLOATS * sizeof(float);
+  static bool lds_ok = false;
+  unsigned grid = 0;
+  int rc = chain_grid(reinterpret_cast<const void*>(fast3_forward_kernel<Q0, Q1, Q2, R1, R2>), lds, kFwdWgsPerCu, &lds_ok, &grid);
+  if (rc) return rc;
   profile_begin(0, st);
-  hipLaunchKernelGGL((fast3_forward_kernel<Q0, Q1, Q2, R1, R2>), dim3(chunk_waves(s, nnz, kCPWF)), dim3(64), lds, st, cores.c[2],
+  hipLaunchKernelGGL((fast3_forward_kernel<Q0, Q1, Q2, R1, R2>), dim3(grid), dim3(kChainWaves * 64), lds, st, cores.c[2],
                      plan, (uint32_t)num_groups(s), (uint32_t)s.p[2], (uint32_t)nnz, output, (uint32_t)(B * s.D * 4));
   profile_end(0, st);
   return check_hip(hipGetLastError(), "fast3_forward_kernel");
@@ -1788,16 +2045,38 @@ static int run_backward(const DevShape& s, const CorePtrs& cores, const GroupPla
   const int64_t G = num_groups(s);
   profile_begin(1, st);
   int rc;
-  const size_t lds = (size_t)(C::PB_FLOATS + C::BB2_FLOATS + C::OB_FLOATS) * sizeof(float);
-  profile_begin(2, st);
-  hipLaunchKernelGGL((fast3_bwd_chunk_kernel<Q0, Q1, Q2, R1, R2>), dim3(chunk_waves(s, nnz, kCPWB)), dim3(64), lds, st, cores.c[2],
-                     (uint32_t)G, (uint32_t)s.p[2], (uint32_t)nnz, d_output, (uint32_t)(B * s.D * 4), plan);
-  profile_end(2, st);
-  rc = check_hip(hipGetLastError(), "fast3_bwd_chunk_kernel");
-  if (rc) return rc;
+  constexpr size_t wave_lds = (size_t)(C::PB_FLOATS + C::BB2_FLOATS + C::OB_FLOATS) * sizeof(float);
+  const bool fused = fused_dg2(s);
+  if (fused) {   // chunk products and the dG2 reduction in one launch
+    if (wave_lds != bwd_wave_lds_floats(s) * sizeof(float)) return fail(TTEMB_E_HIP, "internal: LDS size formula out of step");
+    const size_t lds = kFuseWaves * wave_lds + (size_t)(C::ROW2 + kFuseWaves * 33 + 3 + kFuseWaves * (kWave / (C::ROW2 / 4)) * kFuseQuads) * sizeof(uint32_t);
+    static bool lds_ok = false;
+    rc = allow_lds(reinterpret_cast<const void*>(fast3_bwd_chunk_kernel<Q0, Q1, Q2, R1, R2, true>), lds, &lds_ok);
+    if (rc) return rc;
+    profile_begin(2, st);
+    hipLaunchKernelGGL((fast3_bwd_chunk_kernel<Q0, Q1, Q2, R1, R2, true>), dim3((unsigned)fused_tiles(s, nnz)), dim3(kFuseWaves * 64),
+                       lds, st, cores.c[2], (uint32_t)G, (uint32_t)s.p[2], (uint32_t)nnz, d_output, (uint32_t)(B * s.D * 4), plan);
+    profile_end(2, st);
+    rc = check_hip(hipGetLastError(), "fast3_bwd_chunk_kernel (fused)");
+    if (rc) return rc;
+  } else {
+    const size_t lds = kChainWaves * wave_lds;
+    static bool lds_ok = false;
+    unsigned grid = 0;
+    rc = chain_grid(reinterpret_cast<const void*>(fast3_bwd_chunk_kernel<Q0, Q1, Q2, R1, R2, false>), lds, kBwdWgsPerCu, &lds_ok, &grid);
+    if (rc) return rc;
+    profile_begin(2, st);
+    hipLaunchKernelGGL((fast3_bwd_chunk_kernel<Q0, Q1, Q2, R1, R2, false>), dim3(grid), dim3(kChainWaves * 64), lds, st, cores.c[2],
+                       (uint32_t)G, (uint32_t)s.p[2], (uint32_t)nnz, d_output, (uint32_t)(B * s.D * 4), plan);
+    profile_end(2, st);
+    rc = check_hip(hipGetLastError(), "fast3_bwd_chunk_kernel");
+    if (rc) return rc;
+  }
   const int tiles = (int)reduce_tiles(nnz);
   const size_t reduce_lds = (size_t)(2 * s.p[2] + 1) * 4 + kRowsB * 2;
-  if (shared_slab(s)) {
+  if (fused) {
+    // nothing: the slabs are written
+  } else if (shared_slab(s)) {
     rc = launch_zero(plan.g2part, (size_t)s.p[2] * C::ROW2 * 4, st, "zero the shared dG2 slab");
     if (rc) return rc;
     hipLaunchKernelGGL((fast3_dg2_reduce_kernel<C::ROW2, kRowsB, NWB, true>), dim3((unsigned)tiles), dim3(NWB * 64), reduce_lds, st,
