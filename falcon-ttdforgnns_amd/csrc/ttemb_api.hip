@@ -102,6 +102,13 @@ static bool use_fast3(const DevShape& s, int64_t nnz, int64_t B) {
   return path == TTEMB_PATH_FAST3 || fast3_pays(s, nnz);
 }
 
+// small batches of an instantiated 3-core shape whose ids come with their bag boundaries: one wavefront per bag, MFMA per
+// id (ttemb_small3.inc) instead of the wave-per-id scalar kernels
+static bool use_small3(const DevShape& s, int64_t nnz, int64_t B, const int64_t* rowidx, const int64_t* offsets) {
+  return current_path() == TTEMB_PATH_AUTO && rowidx == nullptr && offsets != nullptr && small3_supported(s) &&
+         !use_fast3(s, nnz, B);
+}
+
 // ---------------------------------------------------------------------------------
 // 4-core tables on the grouped path.  row = G0[i0].G1[i1].G2[i2].G3[i3] is a 3-core row over the table
 // (p0 p1, p2, p3) with the VIRTUAL first core V[(i0, i1)] = G0[i0].G1[i1]  (q0 q1 x r2) -- or over (p0, p1, p2 p3)
@@ -452,6 +459,8 @@ static int backward_into(const DevShape& ds, const CorePtrs& cp, const int64_t* 
   if (current_path() == TTEMB_PATH_FAST3) return fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
   int rc = launch_zero_cores(ds, dst, st);
   if (rc) return rc;
+  if (use_small3(ds, nnz, B, rowidx, offsets))
+    return launch_backward_small3(ds, cp, indices, offsets, nnz, nnz_dev, B, d_output, dst, st);
   return launch_backward_generic(ds, cp, indices, rowidx, offsets, B, nnz, nnz_dev, d_output, dst, st);
 }
 
@@ -564,6 +573,8 @@ static int forward_phase(int phase, const ttemb_shape_t* shape, const float* con
                                 workspace_bytes, plan, plan_bytes, 2, reinterpret_cast<hipStream_t>(stream));
   }
   if (rowidx == nullptr && offsets == nullptr && nnz > 0) return fail(TTEMB_E_BADARG, "rowidx and offsets are both null");
+  if (!f3 && use_small3(ds, nnz, B, rowidx, offsets))   // one launch: every output row written once, zeros for an empty bag
+    return launch_forward_small3(ds, cp, indices, offsets, nnz, nnz_dev, B, output, st);
   char* ws = reinterpret_cast<char*>(workspace);
   // the row-index slot at the head of the workspace is part of the layout on both paths; the fast path derives
   // rows (and clears the rows of bags that do not hold exactly one id) inside its grouping pass

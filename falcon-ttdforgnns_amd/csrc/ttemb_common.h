@@ -78,6 +78,14 @@ int launch_backward_fast3(const DevShape& s, const CorePtrs& cores, const int64_
                           int64_t ws_bytes, const void* plan, int64_t plan_bytes, hipStream_t st,
                           const FusedUpdate* update = nullptr);
 
+// small batches of a 3-core table (ttemb_small3.inc): one wavefront per bag, MFMA per id, no grouping; `offsets` required.
+// The backward ADDS into d_cores (zeroed by the caller) with float atomics.
+bool small3_supported(const DevShape& s);
+int launch_forward_small3(const DevShape& s, const CorePtrs& cores, const int64_t* indices, const int64_t* offsets, int64_t nnz,
+                          const int32_t* nnz_dev, int64_t B, float* output, hipStream_t st);
+int launch_backward_small3(const DevShape& s, const CorePtrs& cores, const int64_t* indices, const int64_t* offsets, int64_t nnz,
+                           const int32_t* nnz_dev, int64_t B, const float* d_output, const CorePtrsMut& d_cores, hipStream_t st);
+
 // zero `bytes` (a multiple of 4) at `p` with a kernel on `st`.  Used instead of hipMemsetAsync everywhere: inside a
 // captured HIP graph (ROCm 7.2) a memset node was seen to race the kernel node that follows it.
 int launch_zero(void* p, size_t bytes, hipStream_t st, const char* what);

@@ -2129,4 +2129,6 @@ int launch_backward_fast3(const DevShape& s, const CorePtrs& cores, const int64_
   return fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
 }
 
+#include "ttemb_small3.inc"
+
 }  // namespace ttemb

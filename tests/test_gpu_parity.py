@@ -366,6 +366,40 @@ def test_random_shapes_generic(nat, orc, seed):
     assert_grads_close(grads, orc.tt_dense_backward(idx, offsets, d_out, cores, p, q, R), rel=2e-4)
 
 
+@pytest.mark.parametrize("shape", sorted(FAST3_SHAPES))
+@pytest.mark.parametrize("n_ids", [1, 700, 3000])
+def test_small_batches_on_the_per_bag_mfma_kernels(nat, orc, shape, n_ids):
+    """Below the grouped path's crossover AUTO runs every instantiated 3-core shape on the per-bag MFMA kernels (one wavefront
+    per bag, no grouping, forward in one launch) when the ids come with their offsets and no row index -- what the module
+    passes.  Ragged bags (empty ones, one of 37 ids), duplicates: forward, dense gradients, fused SGD against the oracle."""
+    q, R = list(shape[:3]), [1, shape[3], shape[4], 1]
+    nat.set_path(nat.PATH_AUTO)
+    rng = np.random.default_rng(5 * n_ids + sum(shape))
+    p = [int(rng.integers(2, 40)), int(rng.integers(2, 40)), int(rng.integers(2, 200))]
+    cores = [(rng.standard_normal((p[t], R[t] * q[t] * R[t + 1])) * 0.3).astype(np.float32) for t in range(3)]
+    idx, offsets = _random_bags(rng, int(np.prod(p)), n_ids)
+    B, nnz, D = offsets.shape[0] - 1, idx.shape[0], int(np.prod(q))
+    shp, ws = nat.make_shape(p, q, R), nat.Workspace()
+    c = [dev(x) for x in cores]
+    di, do = dev(idx, torch.int64), dev(offsets, torch.int64)
+    out = torch.full((B, D), float("nan"), device="cuda")
+    nat.forward(shp, c, di, None, do, nnz, None, B, out, ws)
+    want = orc.tt_forward(idx, offsets, cores, p, q, R)
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(want).max())))
+    d_out = ((rng.random(want.shape) - 0.5) * 0.2).astype(np.float32)
+    grads = [torch.full_like(x, float("nan")) for x in c]
+    nat.backward_dense(shp, c, di, None, nnz, None, B, dev(d_out), grads, ws, None, do)
+    torch.cuda.synchronize()
+    want_g = orc.tt_dense_backward(idx, offsets, d_out, cores, p, q, R)
+    assert_grads_close([g.cpu().numpy() for g in grads], want_g, rel=2e-4)
+    lr = 0.05
+    nat.backward_sgd(shp, c, di, None, nnz, None, B, dev(d_out), lr, ws, None, do)
+    torch.cuda.synchronize()
+    for t in range(3):
+        np.testing.assert_allclose(c[t].cpu().numpy(), cores[t] - np.float32(lr) * want_g[t], rtol=0,
+                                   atol=1e-5 + 2e-4 * float(np.abs(lr * want_g[t]).max()))
+
+
 @pytest.mark.parametrize("q,r", [([5, 5, 4], 256), ([5, 5, 4], 128), ([4, 4, 8], 256), ([4, 5, 5], 8)])
 def test_generic_kernels_take_the_rank_sweep_of_the_run_scripts(nat, orc, q, r):
     """run_script.sh:250-288 sweeps --tt-rank up to 256,256 with q = 5,5,4 / 4,4,8: the wave-per-id kernels need up to
