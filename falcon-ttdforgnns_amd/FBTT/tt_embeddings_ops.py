@@ -27,7 +27,7 @@ from torch import nn
 import ttemb_native as _nat
 
 __all__ = ["OptimType", "BufferList", "tt_matrix_to_full", "suggested_tt_shapes", "TTLookupFunction",
-           "TableBatchedTTEmbeddingBag", "TTEmbeddingBag"]
+           "TableBatchedTTEmbeddingBag", "TTEmbeddingBag", "CapturedLookup"]
 
 _LOG = logging.getLogger(__name__)
 
@@ -291,6 +291,93 @@ class TTLookupFunction(torch.autograd.Function):
         return (None,) * (n_fixed - 1) + (d_cache,) + tuple(full)
 
 
+class _SparseLookup(torch.autograd.Function):
+    """The common training call -- one table, ``sparse=True``, no live cache -- with as little Python around the two
+    native calls as autograd allows: ONE tensor input (the first core, so that the node is recorded; every gradient is
+    ``None`` because the update happens inside backward), bound native arguments (``ttemb_native.LeanCalls``).  Same
+    kernels and results as ``TTLookupFunction``."""
+
+    @staticmethod
+    def forward(ctx, anchor: torch.Tensor, module: "TableBatchedTTEmbeddingBag", indices: torch.Tensor,
+                offsets: torch.Tensor, B: int) -> torch.Tensor:
+        nnz = indices.numel()
+        out = torch.empty((B, module.embedding_dim), dtype=torch.float32, device=indices.device)
+        ctx.module, ctx.indices, ctx.offsets, ctx.B = module, indices, offsets, B
+        ctx.plan = module._lean.forward(module._cores(), indices, offsets, nnz, B, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_output: torch.Tensor):
+        m = ctx.module
+        if d_output.dtype != torch.float32 or not d_output.is_contiguous():
+            d_output = d_output.contiguous().float()
+        state = None if m.optimizer in _SGD_LIKE else m._states()
+        m._lean.backward(m._cores(), state, ctx.indices, ctx.offsets, ctx.indices.numel(), ctx.B, d_output,
+                         float(m.learning_rate), float(m.eps), ctx.plan)
+        return None, None, None, None, None
+
+
+class _ReplayLookup(torch.autograd.Function):
+    """Autograd node of a captured lookup: forward and backward are one HIP-graph replay each."""
+
+    @staticmethod
+    def forward(ctx, anchor: torch.Tensor, cap: "CapturedLookup") -> torch.Tensor:
+        ctx.cap = cap
+        cap.fwd_graph.replay()
+        return cap.output
+
+    @staticmethod
+    def backward(ctx, d_output: torch.Tensor):
+        cap = ctx.cap
+        cap.d_output.copy_(d_output)
+        cap.bwd_graph.replay()
+        return None, None
+
+
+class CapturedLookup:
+    """``emb.capture(nnz, B)``: a lookup of fixed size whose forward and whose backward (gradient + fused optimiser step)
+    are each ONE HIP-graph replay -- for steps so small that Python and launch overhead are most of their time (the metric's
+    literal "batch 2048": ~25 us of kernels under ~75-115 us of eager host work).  Call it like the module:
+    ``out = cap(indices[, offsets])``; ``out`` is a static buffer that the next call overwrites (as with
+    ``torch.cuda.make_graphed_callables``).  The workspace and plan the graphs were captured with are owned by this object,
+    so other calls on the module cannot move them.  ``sparse=True`` modules with one table and no live cache."""
+
+    def __init__(self, module: "TableBatchedTTEmbeddingBag", nnz: int, B: int, offsets: Optional[torch.Tensor] = None) -> None:
+        assert module.sparse and module.num_tables == 1, "capture() covers the fused-optimiser mode of a single table"
+        assert not (module.use_cache and not module.warmup), "capture() with a live row cache is not supported"
+        self.module, self.nnz, self.B = module, int(nnz), int(B)
+        dev = module.tt_cores[0].device
+        self.indices = torch.zeros(self.nnz, dtype=torch.int64, device=dev)
+        self.offsets = (torch.arange(self.B + 1, dtype=torch.int64, device=dev) if offsets is None
+                        else offsets.to(dev, torch.int64).contiguous().clone())
+        self.output = torch.empty((self.B, module.embedding_dim), dtype=torch.float32, device=dev)
+        self.d_output = torch.zeros_like(self.output)
+        self._lean = _nat.LeanCalls(module._shape, _nat.Workspace())   # private workspace: pinned for the graphs' lifetime
+        cores = module._cores()
+        state = None if module.optimizer in _SGD_LIKE else module._states()
+        lr, eps = float(module.learning_rate), float(module.eps)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):   # warm-up outside capture: workspace allocation, LDS-size attributes, size queries
+            plan = self._lean.forward(cores, self.indices, self.offsets, self.nnz, self.B, self.output)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.fwd_graph, self.bwd_graph = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.fwd_graph):
+            self.plan = self._lean.forward(cores, self.indices, self.offsets, self.nnz, self.B, self.output)
+        with torch.cuda.graph(self.bwd_graph):   # (a zero gradient: the captured update leaves the cores as they are)
+            self._lean.backward(cores, state, self.indices, self.offsets, self.nnz, self.B, self.d_output, lr, eps, self.plan)
+        self._lr = lr
+
+    def __call__(self, indices: torch.Tensor, offsets: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if float(self.module.learning_rate) != self._lr:
+            raise RuntimeError("the learning rate is part of the captured backward: capture() again after set_learning_rate()")
+        self.indices.copy_(indices)
+        if offsets is not None:
+            self.offsets.copy_(offsets)
+        return _ReplayLookup.apply(self.module._cores()[0], self)
+
+
 # --------------------------------------------------------------------------------------
 # the module
 # --------------------------------------------------------------------------------------
@@ -377,6 +464,10 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         self._bucket_filled = False   # set by the backward when it wrote the core gradients into the wrapper's bucket
         self._shape = _nat.make_shape(self.tt_p_shapes, self.tt_q_shapes, self.tt_ranks)
         self._ws = _nat.Workspace()
+        self._lean = _nat.LeanCalls(self._shape, self._ws)
+        self._use_lean = True   # (tools/host_breakdown.py switches it off to time the general autograd bridge)
+        self._core_list: Optional[tuple] = None
+        self._state_list: Optional[tuple] = None
         self.register_load_state_dict_post_hook(TableBatchedTTEmbeddingBag._after_load)
 
     @staticmethod
@@ -427,12 +518,32 @@ class TableBatchedTTEmbeddingBag(nn.Module):
                                 self.cache_state, self.cache_weight.data, self._ws)
             self.warmup = False
 
+    def capture(self, nnz: int, B: int, offsets: Optional[torch.Tensor] = None) -> CapturedLookup:
+        """Fixed-size lookup whose forward and backward replay captured HIP graphs (see ``CapturedLookup``)."""
+        return CapturedLookup(self, nnz, B, offsets)
+
     # ---- lookup -------------------------------------------------------------------
+    def _cores(self) -> tuple:
+        """The core Parameters as a tuple (walking the ParameterList costs microseconds per call); rebuilt when the list's
+        first Parameter object is no longer the cached one."""
+        cl = self._core_list
+        if cl is None or cl[0] is not self.tt_cores._parameters.get("0"):
+            cl = self._core_list = tuple(self.tt_cores)
+        return cl
+
+    def _states(self) -> tuple:
+        sl = self._state_list
+        if sl is None or sl[0] is not self.optimizer_state._buffers.get("optimizer_state0"):
+            sl = self._state_list = tuple(self.optimizer_state)
+        return sl
+
     def _lookup_one_table(self, table: int, B: int, indices: torch.Tensor, offsets: torch.Tensor) -> torch.Tensor:
         nnz = indices.numel()
         dev = indices.device
         live = self.use_cache and not self.warmup
         if not live:  # rows are derived from `offsets` inside the native calls: no separate launch, no tensor
+            if self.sparse and self.num_tables == 1 and self._use_lean:
+                return _SparseLookup.apply(self._cores()[0], self, indices, offsets, B)
             return TTLookupFunction.apply(self, table, B, indices, None, offsets, None, None, None,
                                           *self.tt_cores)
         rowidx = torch.empty(nnz, dtype=torch.int64, device=dev)

@@ -169,9 +169,14 @@ class Workspace:
 _size_cache: dict = {}   # (kind, shape bytes, op, nnz, B) -> bytes; emptied when the kernel family changes
 
 
+path_epoch = 0   # bumped when the kernel family changes: callers that keep their own size caches compare it
+
+
 def set_path(path: int) -> None:
+    global path_epoch
     _check(LIB.ttemb_set_path(path))
     _size_cache.clear()
+    path_epoch += 1
 
 
 def profile_enable(on: bool) -> None:
@@ -375,3 +380,70 @@ def core_views(tt_cores: Sequence[torch.Tensor], table: int = 0) -> List[torch.T
             raise RuntimeError("tt_cores must be contiguous")
         out.append(v)
     return out
+
+
+class LeanCalls:
+    """The two native calls of a training step (forward, fused-optimiser backward) of ONE single-table module with their
+    invariant arguments bound once: shape reference, core / optimiser-state pointer arrays (refreshed only when a
+    parameter's storage moved), workspace and plan sizes per (nnz, B).  At 2 048 ids the GPU work of a step is ~25 us, so
+    every microsecond of Python between the two launches is step time."""
+
+    def __init__(self, shape: Shape, ws: Workspace) -> None:
+        self.shape, self.shape_ref, self.ws = shape, ctypes.byref(shape), ws
+        self.sizes: dict = {}
+        self.epoch = -1
+        self.core_key, self.core_arr = None, None
+        self.state_key, self.state_arr = None, None
+
+    def _entry(self, nnz: int, B: int):
+        if self.epoch != path_epoch:
+            self.sizes.clear()
+            self.epoch = path_epoch
+        e = self.sizes.get((nnz, B))
+        if e is None:
+            if len(self.sizes) > 1024:
+                self.sizes.clear()
+            e = self.sizes[(nnz, B)] = (workspace_bytes(self.shape, OP_FORWARD, nnz, B),
+                                        workspace_bytes(self.shape, OP_BACKWARD, nnz, B), plan_bytes(self.shape, nnz))
+        return e
+
+    @staticmethod
+    def _ptrs(tensors, key, arr):
+        k = tuple(t.data_ptr() for t in tensors)
+        if k != key:
+            arr = core_ptrs(tensors)   # validates dtype / device / contiguity
+            key = k
+        return key, arr
+
+    def forward(self, cores, indices, offsets, nnz: int, B: int, out):
+        fwd_ws, _, plan_n = self._entry(nnz, B)
+        self.core_key, self.core_arr = self._ptrs(cores, self.core_key, self.core_arr)
+        dev = out.device
+        w = self.ws.get(fwd_ws, dev)
+        plan = torch.empty(plan_n, dtype=torch.uint8, device=dev) if plan_n > 0 else None
+        with _on_device(dev):
+            rc = LIB.ttemb_forward(self.shape_ref, self.core_arr, indices.data_ptr() if nnz else None, None, offsets.data_ptr(),
+                                   nnz, None, B, out.data_ptr() if B else None, w.data_ptr(), w.numel(),
+                                   plan.data_ptr() if plan is not None else None, plan_n, _stream(out))
+        if rc:
+            _check(rc)
+        return plan
+
+    def backward(self, cores, state, indices, offsets, nnz: int, B: int, d_output, lr: float, eps: float, plan):
+        _, bwd_ws, plan_n = self._entry(nnz, B)
+        self.core_key, self.core_arr = self._ptrs(cores, self.core_key, self.core_arr)
+        dev = d_output.device
+        w = self.ws.get(bwd_ws, dev)
+        pp, pn = (plan.data_ptr(), plan_n) if plan is not None else (None, 0)
+        ids = indices.data_ptr() if nnz else None
+        with _on_device(dev):
+            if state is None:
+                rc = LIB.ttemb_backward_sgd(self.shape_ref, self.core_arr, ids, None, offsets.data_ptr(), nnz, None, B,
+                                            d_output.data_ptr() if B else None, lr, w.data_ptr(), w.numel(), pp, pn, _stream(d_output))
+            else:
+                self.state_key, self.state_arr = self._ptrs(state, self.state_key, self.state_arr)
+                rc = LIB.ttemb_backward_adagrad(self.shape_ref, self.core_arr, self.state_arr, ids, None, offsets.data_ptr(), nnz, None,
+                                                B, d_output.data_ptr() if B else None, lr, eps, w.data_ptr(), w.numel(), pp, pn,
+                                                _stream(d_output))
+        if rc:
+            _check(rc)

@@ -628,3 +628,31 @@ def test_bucket_accumulates_over_two_backwards_before_the_step(ops, orc):
     for c, c0, g in zip(emb.tt_cores, cores, want):
         np.testing.assert_allclose(c.detach()[0].cpu().numpy(), c0 - np.float32(lr) * g, rtol=0,
                                    atol=1e-6 + 2e-4 * float(np.abs(lr * g).max()))
+
+
+@pytest.mark.parametrize("optimizer", ["SGD", "EXACT_ADAGRAD"])
+def test_captured_lookup_trains_like_the_eager_module(ops, orc, optimizer):
+    """emb.capture(nnz, B): forward and backward as HIP-graph replays give the rows and the in-backward update of the eager
+    module on the same inputs, step after step (two steps with different ids through the same graphs)."""
+    torch.manual_seed(11)
+    p, q, r = [125, 140, 140], [4, 5, 5], [16, 16]
+    mk = lambda: ops.TTEmbeddingBag(2449029, 100, r, p, q, optimizer=getattr(ops.OptimType, optimizer), sparse=True, use_cache=False,
+                                    weight_dist="normal", learning_rate=0.1)
+    a, b = mk(), mk()
+    for ca, cb in zip(a.tt_cores, b.tt_cores):
+        ca.data.mul_(300.0)
+        cb.data.copy_(ca.data)
+    n = 2048
+    cap = b.capture(n, n)
+    rng = np.random.default_rng(2)
+    for _ in range(2):
+        ids = torch.tensor(rng.choice(2449029, size=n, replace=False).astype(np.int64)).cuda()
+        d = torch.tensor(((rng.random((n, 100)) - 0.5) * 0.05).astype(np.float32)).cuda()
+        out_a = a(ids, torch.arange(n + 1).cuda())
+        out_b = cap(ids)
+        torch.testing.assert_close(out_b, out_a, rtol=1e-5, atol=1e-6)
+        out_a.backward(d)
+        out_b.backward(d)
+        torch.cuda.synchronize()
+        for ca, cb in zip(a.tt_cores, b.tt_cores):   # float atomics: the two runs differ by summation order only
+            torch.testing.assert_close(cb.data, ca.data, rtol=1e-4, atol=1e-6)

@@ -43,6 +43,17 @@ def native_only():
 print(f"{n} ids")
 print(f"  native calls only (ctypes)        : {timeit(native_only):6.1f} us/step")
 print(f"  module + autograd, sparse         : {timeit(lambda: emb(ids, offs).backward(d)):6.1f} us/step")
+emb._use_lean = False
+print(f"  ... through the general bridge    : {timeit(lambda: emb(ids, offs).backward(d)):6.1f} us/step")
+emb._use_lean = True
+print(f"  module + autograd, sparse (again) : {timeit(lambda: emb(ids, offs).backward(d)):6.1f} us/step")
+g = torch.cuda.CUDAGraph()
+s_ids, s_d = ids.clone(), d.clone()
+with torch.cuda.graph(g):
+    emb(s_ids, offs).backward(s_d)
+print(f"  the same step captured (graph replay): {timeit(g.replay):6.1f} us/step")
+cap = emb.capture(n, n)
+print(f"  emb.capture(): cap(ids).backward(d) : {timeit(lambda: cap(ids).backward(d)):6.1f} us/step")
 emb2 = TTEmbeddingBag(2449029, 100, [16, 16], [125, 140, 140], [4, 5, 5], sparse=False, use_cache=False, weight_dist="normal",
                       learning_rate=0.01)
 def dense():
