@@ -1675,7 +1675,8 @@ __global__ __launch_bounds__(256) void fast3_finalize_kernel(GroupPlan plan, int
   X(4, 5, 5, 32, 32)          \
   X(4, 4, 8, 32, 32)          \
   X(5, 4, 5, 16, 16)          \
-  X(5, 5, 4, 16, 16)
+  X(5, 5, 4, 16, 16)          \
+  X(5, 5, 4, 32, 32)
 
 static bool shape_is(const DevShape& s, int q0, int q1, int q2, int r1, int r2) {
   return s.q[0] == q0 && s.q[1] == q1 && s.q[2] == q2 && s.R[1] == r1 && s.R[2] == r2;
@@ -1797,6 +1798,7 @@ static bool fused_dg2(const DevShape& s) {
 #endif
   const int lpr = s.row_len[2] / 4;
   if (lpr < 1 || lpr > kWave) return false;
+  if (s.R[2] > 16) return false;   // at rank 32 the fused kernel's registers (operands + slab rows) no longer fit two waves per SIMD
   const int gpw = kWave / lpr;
   if (s.p[2] > kFuseWaves * gpw * kFuseQuads) return false;
   return (size_t)kFuseWaves * bwd_wave_lds_floats(s) * 4 + (size_t)(s.row_len[2] + kFuseWaves * 33 + 3 + kFuseWaves * gpw * kFuseQuads) * 4 <= kCuLds;

@@ -15,6 +15,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 TINY_CASES = ["tt_tiny_T2", "tt_tiny_T3", "tt_tiny_T4", "tt_small_prodshape", "tt_small_arxivshape",
               "tt_small_papershape", "tt_small_q448r16", "tt_small_q844r16", "tt_small_q455r32", "tt_small_q448r32", "tt_small_q545r16", "tt_small_q554r16"]
+RANK_CASES = ["tt_rank_q554r8", "tt_rank_q554r32", "tt_rank_q554r64", "tt_rank_q554r128", "tt_rank_q554r256",
+              "tt_rank_q448r64", "tt_rank_q448r128", "tt_rank_q448r256", "tt_rank_q455r8"]   # run_script.sh:250-288
 ROW_CASES = ["rows_arxiv", "rows_products", "rows_papers", "rows_products_b3", "rows_q448r16_b3"]
 
 
@@ -45,3 +47,14 @@ def seeded_cores(p, q, R, seed, scale):
 def has_gpu():
     import torch
     return torch.cuda.is_available()
+
+
+def rank_case_cores(g):
+    """Cores of a rank-sweep fixture, regenerated from its seed (the file carries their SHA-256)."""
+    import hashlib
+    cores = seeded_cores(g["p"], g["q"], g["R"], g["seed"], g["scale"])
+    h = hashlib.sha256()
+    for c in cores:
+        h.update(np.ascontiguousarray(c).tobytes())
+    assert h.hexdigest() == str(g["cores_sha256"]), "RNG drift: regenerate the golden vectors"
+    return cores

@@ -241,6 +241,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "windows":
         window_case("rows_products_b3", [125, 140, 140], [4, 5, 5], [16, 16], 22, 2449029, 6, 40)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "ranks":   # the rank sweep of run_script.sh
+        rank_sweep_cases()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "scripts":   # the (q, rank) shapes of the reference's run scripts
         script_shape_cases()
         return
@@ -259,6 +262,44 @@ def main():
     murmur_vectors()
     suggested_shape_vectors()
     script_shape_cases()
+    rank_sweep_cases()
+
+
+def rank_case(name, p, q, ranks, seed, scale):
+    """A (q, rank) point of the rank sweep of run_script.sh:250-288.  The cores are NOT stored (the middle core of a rank-256
+    table is megabytes): tests regenerate them from the seed (conftest.seeded_cores, same generator) and the file carries a
+    digest of their bytes; of the middle core's gradient every 61st element is kept."""
+    R = orc.full_ranks(ranks, 3)
+    n_emb, D = int(np.prod(p)), int(np.prod(q))
+    cores = seeded_cores(p, q, R, seed, scale=scale)
+    rng = np.random.default_rng(seed + 1)
+    idx, offsets = ragged_bags(rng, 19, n_emb, 3.0)
+    B = offsets.shape[0] - 1
+    d_out = (rng.random((B, D)).astype(np.float32) * np.float32(0.1))
+    cores_t = [torch.tensor(c, requires_grad=True) for c in cores]
+    out = ref_bag_forward(ref_full(p, q, R, cores_t), idx, offsets)
+    out.backward(torch.tensor(d_out))
+    grads = [c.grad.numpy().copy() for c in cores_t]
+    out_np = out.detach().numpy().copy()
+    o_out = orc.tt_forward(idx, offsets, cores, p, q, R)
+    o_grads = orc.tt_dense_backward(idx, offsets, d_out, cores, p, q, R)
+    assert np.abs(o_out - out_np).max() <= 1e-5 * max(1.0, np.abs(out_np).max()), name
+    for a, b in zip(o_grads, grads):
+        assert np.abs(a - b).max() <= 2e-5 * max(1.0, np.abs(b).max()), name
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), p=np.array(p), q=np.array(q), R=np.array(R), seed=np.int64(seed),
+                        scale=np.float32(scale), cores_sha256=np.array(cores_sha256(cores)), indices=idx, offsets=offsets,
+                        d_output=d_out, out=out_np, grad0=grads[0], grad2=grads[2], grad1_every61=grads[1].reshape(-1)[::61].copy(),
+                        grad1_absmax=np.float32(np.abs(grads[1]).max()))
+    print(f"{name}: B={B} nnz={idx.shape[0]} |out|max={np.abs(out_np).max():.4f} |g1|max={np.abs(grads[1]).max():.4f}")
+
+
+def rank_sweep_cases():
+    """run_script.sh:250-268 (q = 5,5,4, --tt-rank 8,8 ... 256,256) and :270-288 (q = 4,4,8); 4,5,5 at rank 8."""
+    for r in (8, 32, 64, 128, 256):
+        rank_case(f"tt_rank_q554r{r}", [3, 2, 4], [5, 5, 4], [r, r], seed=30 + r, scale=0.7 / np.sqrt(r))
+    for r in (64, 128, 256):
+        rank_case(f"tt_rank_q448r{r}", [2, 3, 3], [4, 4, 8], [r, r], seed=31 + r, scale=0.7 / np.sqrt(r))
+    rank_case("tt_rank_q455r8", [4, 3, 5], [4, 5, 5], [8, 8], seed=29, scale=0.25)
 
 
 def script_shape_cases():

@@ -11,14 +11,14 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import ROW_CASES, TINY_CASES, golden_cores, load_golden, seeded_cores
+from conftest import RANK_CASES, ROW_CASES, TINY_CASES, golden_cores, load_golden, rank_case_cores, seeded_cores
 
 pytestmark = pytest.mark.gpu
 
 PATHS = ["generic", "auto", "fast3"]
 # (q0, q1, q2, r1, r2) of the MFMA path: the BASELINE.json shapes, then the other 3-core shapes of the reference's scripts
 FAST3_SHAPES = {(4, 5, 5, 16, 16), (4, 4, 8, 8, 8), (8, 4, 4, 32, 32), (4, 4, 8, 16, 16), (8, 4, 4, 16, 16),
-                (4, 5, 5, 32, 32), (4, 4, 8, 32, 32), (5, 4, 5, 16, 16), (5, 5, 4, 16, 16)}
+                (4, 5, 5, 32, 32), (4, 4, 8, 32, 32), (5, 4, 5, 16, 16), (5, 5, 4, 16, 16), (5, 5, 4, 32, 32)}
 
 
 @pytest.fixture(scope="module")
@@ -364,6 +364,36 @@ def test_random_shapes_generic(nat, orc, seed):
     d_out = ((rng.random(want.shape) - 0.5) * 0.2).astype(np.float32)
     grads = run_backward_dense(nat, p, q, R, cores, idx, offsets, d_out)
     assert_grads_close(grads, orc.tt_dense_backward(idx, offsets, d_out, cores, p, q, R), rel=2e-4)
+
+
+@pytest.mark.parametrize("with_rowidx", [False, True])
+@pytest.mark.parametrize("name", RANK_CASES)
+def test_rank_sweep_golden(nat, name, with_rowidx):
+    """The (q, rank) points of the reference's rank sweep (run_script.sh:250-288: q = 5,5,4 at 8 ... 256, q = 4,4,8 at
+    64 ... 256) against vectors from the reference's tt_matrix_to_full + autograd, on whatever kernels AUTO picks for the
+    shape (ids with and without a row index: the per-bag MFMA kernels take instantiated shapes only in the second form)."""
+    g = load_golden(name)
+    cores = rank_case_cores(g)
+    p, q, R = [int(x) for x in g["p"]], [int(x) for x in g["q"]], [int(x) for x in g["R"]]
+    nat.set_path(nat.PATH_AUTO)
+    shp, ws = nat.make_shape(p, q, R), nat.Workspace()
+    c = [dev(x) for x in cores]
+    di, do = dev(g["indices"], torch.int64), dev(g["offsets"], torch.int64)
+    B, nnz = do.numel() - 1, di.numel()
+    rowidx = None
+    if with_rowidx:
+        rowidx = torch.empty(nnz, dtype=torch.int64, device="cuda")
+        nat.preprocess(di, do, B, True, None, None, None, rowidx, None, None, ws)
+    out = torch.full((B, int(np.prod(q))), float("nan"), device="cuda")
+    nat.forward(shp, c, di, rowidx, do, nnz, None, B, out, ws)
+    np.testing.assert_allclose(out.cpu().numpy(), g["out"], rtol=1e-4, atol=1e-4)
+    grads = [torch.full_like(x, float("nan")) for x in c]
+    nat.backward_dense(shp, c, di, rowidx, nnz, None, B, dev(g["d_output"]), grads, ws, None, do)
+    torch.cuda.synchronize()
+    got = [x.cpu().numpy() for x in grads]
+    assert_grads_close([got[0], got[2]], [g["grad0"], g["grad2"]], rel=2e-4)
+    err = float(np.abs(got[1].reshape(-1)[::61] - g["grad1_every61"]).max())
+    assert err <= 2e-4 * float(g["grad1_absmax"]) + 1e-6, f"core 1: {err:.3e}"
 
 
 @pytest.mark.parametrize("shape", sorted(FAST3_SHAPES))

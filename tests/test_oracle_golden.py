@@ -5,7 +5,7 @@ import hashlib
 import numpy as np
 import pytest
 
-from conftest import ROW_CASES, TINY_CASES, golden_cores, load_golden, seeded_cores
+from conftest import RANK_CASES, ROW_CASES, TINY_CASES, golden_cores, load_golden, rank_case_cores, seeded_cores
 from oracle import tt_oracle as orc
 
 
@@ -36,6 +36,19 @@ def test_fused_updates_match_closed_form(name):
         np.testing.assert_allclose(sgd[t], g[f"sgd{t}"], rtol=0, atol=1e-6)
         np.testing.assert_allclose(st[t], g[f"ada_state{t}"], rtol=1e-6, atol=0)
         np.testing.assert_allclose(ada[t], g[f"ada{t}"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", RANK_CASES)
+def test_rank_sweep_points_match_reference(name):
+    """(q, rank) points of run_script.sh:250-288: bag sums and autograd gradients through the reference's tt_matrix_to_full."""
+    g = load_golden(name)
+    cores = rank_case_cores(g)
+    out = orc.tt_forward(g["indices"], g["offsets"], cores, g["p"], g["q"], g["R"])
+    np.testing.assert_allclose(out, g["out"], rtol=1e-5, atol=1e-5)
+    grads = orc.tt_dense_backward(g["indices"], g["offsets"], g["d_output"], cores, g["p"], g["q"], g["R"])
+    np.testing.assert_allclose(grads[0], g["grad0"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(grads[2], g["grad2"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(grads[1].reshape(-1)[::61], g["grad1_every61"], rtol=1e-4, atol=2e-5)
 
 
 @pytest.mark.parametrize("name", ROW_CASES)
