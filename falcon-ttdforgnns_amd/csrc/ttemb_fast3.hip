@@ -833,6 +833,7 @@ __global__ __launch_bounds__(kChainWaves * 64) void fast3_forward_kernel(const f
 constexpr int kFuseWaves = TTEMB_FUSE_WAVES;   // a power of two
 constexpr int kFuseQuads = 48 / kFuseWaves;    // register quads of slab rows per wavefront: p2 <= kFuseWaves * GPW * kFuseQuads
 constexpr int kFuseBatch = 6;                  // quads whose list heads / first rows are read together
+constexpr int kFuseSub = 2;                    // chunks a wavefront multiplies between two reductions (one more E region each)
 static_assert(kFuseQuads % kFuseBatch == 0, "quads are handled in whole batches");
 
 template <int Q0, int Q1, int Q2, int R1, int R2, bool FUSE>
@@ -846,7 +847,10 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
   const uint32_t wave = uniform(threadIdx.x >> 6);
   const int hi = lane >> 4, lo = lane & 15;
   const int b_l = lane >> 2, j_l = lane & 3;   // this lane's id inside a chunk, and which pieces of its rows
-  constexpr int WF = C::PB_FLOATS + C::BB2_FLOATS + C::OB_FLOATS;
+  // FUSE: a second region for E rows behind the staging regions -- a wavefront multiplies kFuseSub = 2 chunks between two
+  // reductions (the barriers and the fixed part of the list walk are paid once per two chunks); the first chunk's rows
+  // wait there, the second's take the place of its staged G2 rows
+  constexpr int WF = C::PB_FLOATS + C::BB2_FLOATS + C::OB_FLOATS + (FUSE ? kChunk * C::ROW2 : 0);
   float* pbuf = smem + wave * WF;
   // FUSE: [kFuseWaves] "has a chunk after this one" | [kFuseWaves * 16] list entry of every row of the round: {byte offset
   // of the row in LDS, byte offset of the next entry of its list} | [heads] byte offset of the first entry of every i2's
@@ -855,12 +859,19 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
   // all -- lanes whose list is empty or has ended add zeros -- and a head is reset by storing NIL.
   float* f_zero = smem + NW * WF;                                      // [ROW2] zeros
   uint32_t* f_more = reinterpret_cast<uint32_t*>(f_zero + C::ROW2);
-  uint2* f_tab = reinterpret_cast<uint2*>(f_more + kFuseWaves);        // [kFuseWaves * 16 + 1]: the last one is NIL
-  uint32_t* f_head = reinterpret_cast<uint32_t*>(f_tab + kFuseWaves * 16 + 1);   // [heads + 1]: the last one is for idle lanes
+  constexpr int kRoundRows = kFuseWaves * kFuseSub * 16;
+  uint2* f_tab = reinterpret_cast<uint2*>(f_more + kFuseWaves);        // [kRoundRows + 1]: the last one is NIL
+  uint32_t* f_head = reinterpret_cast<uint32_t*>(f_tab + kRoundRows + 1);   // [heads + 1]: the last one is for idle lanes
   char* const lds0 = reinterpret_cast<char*>(smem);
-  const uint32_t f_nil = (uint32_t)(reinterpret_cast<char*>(f_tab + kFuseWaves * 16) - lds0);
-  const uint32_t my_entry = (uint32_t)(reinterpret_cast<char*>(f_tab + wave * 16 + b_l) - lds0);            // this lane's row: its entry
-  const uint32_t my_row = (uint32_t)((wave * WF + C::PB_FLOATS + b_l * C::ROW2) * sizeof(float));              // ... and its place
+  const uint32_t f_nil = (uint32_t)(reinterpret_cast<char*>(f_tab + kRoundRows) - lds0);
+  // this lane's row of the first / second chunk of a round: its list entry and its place (E region behind the staging
+  // regions / over the staged G2 rows)
+  const uint32_t my_entry0 = (uint32_t)(reinterpret_cast<char*>(f_tab + (wave * kFuseSub + 0) * 16 + b_l) - lds0);
+  const uint32_t my_entry1 = (uint32_t)(reinterpret_cast<char*>(f_tab + (wave * kFuseSub + 1) * 16 + b_l) - lds0);
+  const uint32_t my_row0 = (uint32_t)((wave * WF + C::PB_FLOATS + C::BB2_FLOATS + C::OB_FLOATS + b_l * C::ROW2) * sizeof(float));
+  const uint32_t my_row1 = (uint32_t)((wave * WF + C::PB_FLOATS + b_l * C::ROW2) * sizeof(float));
+  float* ebuf = pbuf + C::PB_FLOATS + C::BB2_FLOATS + C::OB_FLOATS;
+  uint32_t sub = 0;   // which chunk of the round is being multiplied
   float* bbuf = pbuf + C::PB_FLOATS;   // staged G2 rows
   float* dbuf = bbuf + C::BB2_FLOATS;  // staged d_output rows
 
@@ -937,7 +948,7 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
     for (int q = 0; q < kFuseQuads; ++q) slab[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int i = threadIdx.x; i <= kFuseWaves * GPW * kFuseQuads; i += kFuseWaves * kWave) f_head[i] = f_nil;
     for (int i = threadIdx.x; i < C::ROW2; i += kFuseWaves * kWave) f_zero[i] = 0.f;
-    if (threadIdx.x == 0) f_tab[kFuseWaves * 16] = make_uint2((uint32_t)(reinterpret_cast<char*>(f_zero) - lds0), f_nil);
+    if (threadIdx.x == 0) f_tab[kRoundRows] = make_uint2((uint32_t)(reinterpret_cast<char*>(f_zero) - lds0), f_nil);
     __syncthreads();
   }
 
@@ -1132,17 +1143,19 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
     // into [c2][kk]): the chunk's rows are one contiguous block indexed col * r2 + c2, written in 16-byte pieces
     // through a descriptor that covers exactly this chunk's rows.
     if constexpr (FUSE) {
-      // (the wave barrier above: every staged-G2 read of this chunk is done, the region takes the E rows)
+      // (the wave barrier above: every staged-G2 read of this chunk is done; the second chunk's E rows take that region)
+      float* const eb = sub == 0 ? ebuf : bbuf;
 #pragma unroll
       for (int nt = 0; nt < C::NT2; ++nt) {
         if ((uint32_t)(16 * nt) < len * Q2) {
 #pragma unroll
           for (int t = 0; t < C::RT2; ++t)
-            if (ewr[nt][t] >= 0) *reinterpret_cast<f32x4*>(bbuf + ewr[nt][t]) = e[t][nt];
+            if (ewr[nt][t] >= 0) *reinterpret_cast<f32x4*>(eb + ewr[nt][t]) = e[t][nt];
         }
       }
       if (j_l == 0 && (uint32_t)b_l < len)   // the row joins the list of its i2
-        f_tab[wave * 16 + b_l] = make_uint2(my_row, atomicExch(&f_head[i2_cur], my_entry));
+        f_tab[(wave * kFuseSub + sub) * 16 + b_l] =
+            make_uint2(sub == 0 ? my_row0 : my_row1, atomicExch(&f_head[i2_cur], sub == 0 ? my_entry0 : my_entry1));
       if (lane == 0) f_more[wave] = more1 ? 1u : 0u;
     }
 #if !(defined(TTEMB_ABL) && (TTEMB_ABL & 1))
@@ -1168,7 +1181,17 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
           for (int r = 0; r < 4; ++r) buf_store1(r_dp, dpoff[mt][t] + (uint32_t)(r * R2 * 4), dp[mt][t][r]);
     }
     TTEMB_STAMP(4);
+    bool reduce_now = false;
     if constexpr (FUSE) {
+      reduce_now = sub == kFuseSub - 1;
+      sub = reduce_now ? 0u : sub + 1u;
+      if (!reduce_now) {   // first chunk of the round: its E rows wait in their own region, the staging regions are free
+        stage((d_nxt.z & kFirstBit) != 0u);
+        o_nn = offsets(d_nn, i2_nn, val_nn);
+        asm volatile("" ::"v"(o_nn.row), "v"(o_nn.grow));
+      }
+    }
+    if (FUSE && reduce_now) {
       __syncthreads();   // the round's E rows and their lists are in LDS
       TTEMB_STAMP(5);
       {
@@ -1216,7 +1239,7 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
       asm volatile("" ::"v"(o_nn.row), "v"(o_nn.grow));
       TTEMB_STAMP(8);
       if (!any) break;
-    } else {
+    } else if (!FUSE) {
       if (!more1) break;
     }
     // ---- loads of the chunk after next, pairs of the one after that ----
@@ -1801,10 +1824,11 @@ static bool fused_dg2(const DevShape& s) {
   if (s.R[2] > 16) return false;   // at rank 32 the fused kernel's registers (operands + slab rows) no longer fit two waves per SIMD
   const int gpw = kWave / lpr;
   if (s.p[2] > kFuseWaves * gpw * kFuseQuads) return false;
-  return (size_t)kFuseWaves * bwd_wave_lds_floats(s) * 4 + (size_t)(s.row_len[2] + kFuseWaves * 33 + 3 + kFuseWaves * gpw * kFuseQuads) * 4 <= kCuLds;
+  return (size_t)kFuseWaves * (bwd_wave_lds_floats(s) + (size_t)kChunk * s.row_len[2]) * 4 +
+             (size_t)(s.row_len[2] + kFuseWaves * (1 + 32 * kFuseSub) + 3 + kFuseWaves * gpw * kFuseQuads) * 4 <= kCuLds;
 }
 static int64_t fused_tiles(const DevShape& s, int64_t nnz) {   // workgroups: at least ~2 chunks per wavefront, at most one per CU
-  const int64_t t = (max_chunks(s, nnz) + 2 * kFuseWaves - 1) / (2 * kFuseWaves);
+  const int64_t t = (max_chunks(s, nnz) + 2 * kFuseSub * kFuseWaves - 1) / (2 * kFuseSub * kFuseWaves);
   const int64_t most = (int64_t)chain_cus() * (8 / kFuseWaves);
   return t < 1 ? 1 : (t > most ? most : t);
 }
@@ -2051,7 +2075,8 @@ static int run_backward(const DevShape& s, const CorePtrs& cores, const GroupPla
   const bool fused = fused_dg2(s);
   if (fused) {   // chunk products and the dG2 reduction in one launch
     if (wave_lds != bwd_wave_lds_floats(s) * sizeof(float)) return fail(TTEMB_E_HIP, "internal: LDS size formula out of step");
-    const size_t lds = kFuseWaves * wave_lds + (size_t)(C::ROW2 + kFuseWaves * 33 + 3 + kFuseWaves * (kWave / (C::ROW2 / 4)) * kFuseQuads) * sizeof(uint32_t);
+    const size_t lds = kFuseWaves * (wave_lds + kChunk * C::ROW2 * sizeof(float)) +
+                       (size_t)(C::ROW2 + kFuseWaves * (1 + 32 * kFuseSub) + 3 + kFuseWaves * (kWave / (C::ROW2 / 4)) * kFuseQuads) * sizeof(uint32_t);
     static bool lds_ok = false;
     rc = allow_lds(reinterpret_cast<const void*>(fast3_bwd_chunk_kernel<Q0, Q1, Q2, R1, R2, true>), lds, &lds_ok);
     if (rc) return rc;
