@@ -1771,7 +1771,7 @@ static bool shared_slab(const DevShape& s) { return (int64_t)s.p[2] * s.row_len[
 #define TTEMB_BWD_WGS 2
 #endif
 #ifndef TTEMB_FWD_WGS
-#define TTEMB_FWD_WGS 3
+#define TTEMB_FWD_WGS 4
 #endif
 constexpr int kBwdWgsPerCu = TTEMB_BWD_WGS, kFwdWgsPerCu = TTEMB_FWD_WGS;
 constexpr size_t kCuLds = 160 * 1024;
