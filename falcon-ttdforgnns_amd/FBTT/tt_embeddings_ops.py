@@ -507,8 +507,9 @@ class TableBatchedTTEmbeddingBag(nn.Module):
             self.warmup = True
 
     def update_cache(self, indices: torch.Tensor) -> None:
-        if self.use_cache:
-            _nat.cache_update(indices.long().contiguous(), self.hashtbl, self.cache_freq)
+        if self.use_cache:   # `lfu_one_sweep_insert = True` on the module selects the reference's insert bit for bit
+            _nat.cache_update(indices.long().contiguous(), self.hashtbl, self.cache_freq,
+                              getattr(self, "lfu_one_sweep_insert", False))
 
     def cache_populate(self) -> None:
         """Freeze the LFU statistics: the ``cache_size`` hottest ids get their rows

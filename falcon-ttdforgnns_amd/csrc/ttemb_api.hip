@@ -749,13 +749,23 @@ int ttemb_adagrad_step(float* weights, float* state, const float* grads, int64_t
   return run_adagrad(weights, state, grads, n, lr, eps, reinterpret_cast<hipStream_t>(stream));
 }
 
-int ttemb_cache_update(const int64_t* indices, int64_t nnz, int64_t* hashtbl, int64_t* cache_freq,
-                       int64_t H, void* stream) {
+static int cache_update(const int64_t* indices, int64_t nnz, int64_t* hashtbl, int64_t* cache_freq, int64_t H, bool one_sweep,
+                        void* stream) {
   if (nnz < 0) return fail(TTEMB_E_BADARG, "negative nnz");
   if (nnz == 0) return TTEMB_OK;
   if (H <= 0 || H > 0x7fffffffll) return fail(TTEMB_E_BADARG, "hashtbl_size %lld out of range", (long long)H);
   if (!indices || !hashtbl || !cache_freq) return fail(TTEMB_E_BADARG, "null buffer");
-  return launch_cache_update(indices, nnz, hashtbl, cache_freq, H, reinterpret_cast<hipStream_t>(stream));
+  return launch_cache_update(indices, nnz, hashtbl, cache_freq, H, reinterpret_cast<hipStream_t>(stream), one_sweep);
+}
+
+int ttemb_cache_update(const int64_t* indices, int64_t nnz, int64_t* hashtbl, int64_t* cache_freq,
+                       int64_t H, void* stream) {
+  return cache_update(indices, nnz, hashtbl, cache_freq, H, false, stream);
+}
+
+int ttemb_cache_update_one_sweep(const int64_t* indices, int64_t nnz, int64_t* hashtbl, int64_t* cache_freq,
+                                 int64_t H, void* stream) {
+  return cache_update(indices, nnz, hashtbl, cache_freq, H, true, stream);
 }
 
 int ttemb_cache_populate(const ttemb_shape_t* shape, const float* const* cores, int64_t* hashtbl,

@@ -7,7 +7,7 @@ namespace ttemb {
 static inline int64_t align256(int64_t x) { return (x + 255) & ~int64_t(255); }
 
 int launch_cache_update(const int64_t* indices, int64_t nnz, int64_t* hashtbl, int64_t* freq,
-                        int64_t H, hipStream_t st);
+                        int64_t H, hipStream_t st, bool one_sweep = false);
 int64_t populate_workspace_bytes(int64_t H);
 int launch_cache_populate_rank(int64_t* hashtbl, int64_t* freq, int32_t* state, int64_t H, int64_t C,
                                void* ws, int64_t ws_bytes, int64_t** sorted_keys_out, hipStream_t st);

@@ -100,13 +100,38 @@ __global__ void cache_update_kernel(const int64_t* __restrict__ indices, int64_t
   // three occupied probes: the id is simply not tracked (reference returns -1 and moves on)
 }
 
+// The reference's own insert, for callers that need its table bit for bit: probe and insert in ONE sweep
+// (hashtbl_cuda_utils.cuh:102-133) -- the first probe slot that is empty or already holds the key takes the count.
+// After cache_populate's evictions this re-inserts a cached id into a hole in front of its slot (see above).
+__global__ void cache_update_one_sweep_kernel(const int64_t* __restrict__ indices, int64_t nnz, int64_t* __restrict__ keys,
+                                              int64_t* __restrict__ freq, uint32_t H) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= nnz) return;
+  const int64_t key = indices[n];
+  uint32_t s = hash_slot(key, H);
+#pragma unroll
+  for (int probe = 0; probe < kMaxProbes; ++probe) {
+    const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[s]), (unsigned long long)kEmptyKey,
+                                             (unsigned long long)key);
+    if (old == (unsigned long long)kEmptyKey || old == (unsigned long long)key) {
+      atomicAdd(reinterpret_cast<unsigned long long*>(&freq[s]), 1ull);
+      return;
+    }
+    s = (s + 1 == H) ? 0 : s + 1;
+  }
+}
+
 int launch_cache_update(const int64_t* indices, int64_t nnz, int64_t* hashtbl, int64_t* freq,
-                        int64_t H, hipStream_t st) {
+                        int64_t H, hipStream_t st, bool one_sweep) {
   if (nnz <= 0) return TTEMB_OK;
   const int threads = 256;
   const int64_t blocks = (nnz + threads - 1) / threads;
-  hipLaunchKernelGGL(cache_update_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, indices,
-                     nnz, hashtbl, freq, (uint32_t)H);
+  if (one_sweep)
+    hipLaunchKernelGGL(cache_update_one_sweep_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, indices, nnz, hashtbl, freq,
+                       (uint32_t)H);
+  else
+    hipLaunchKernelGGL(cache_update_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, indices,
+                       nnz, hashtbl, freq, (uint32_t)H);
   return check_hip(hipGetLastError(), "cache_update_kernel");
 }
 

@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = (
     "ttemb_abi_version", "ttemb_last_error", "ttemb_workspace_bytes", "ttemb_plan_bytes", "ttemb_set_path",
     "ttemb_profile_enable", "ttemb_profile_read",
     "ttemb_forward", "ttemb_forward_group", "ttemb_forward_lookup", "ttemb_backward_dense", "ttemb_backward_sgd", "ttemb_backward_adagrad",
-    "ttemb_sgd_step", "ttemb_adagrad_step", "ttemb_cache_update", "ttemb_cache_populate",
+    "ttemb_sgd_step", "ttemb_adagrad_step", "ttemb_cache_update", "ttemb_cache_update_one_sweep", "ttemb_cache_populate",
     "ttemb_preprocess", "ttemb_cache_forward", "ttemb_cache_backward_sgd",
     "ttemb_cache_backward_dense", "ttemb_cache_backward_rowwise_adagrad",
 )
@@ -84,6 +84,7 @@ def _load() -> ctypes.CDLL:
     lib.ttemb_sgd_step.argtypes = [vp, vp, i64, f32, vp]
     lib.ttemb_adagrad_step.argtypes = [vp, vp, vp, i64, f32, f32, vp]
     lib.ttemb_cache_update.argtypes = [vp, i64, vp, vp, i64, vp]
+    lib.ttemb_cache_update_one_sweep.argtypes = [vp, i64, vp, vp, i64, vp]
     lib.ttemb_cache_populate.argtypes = [shp, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp]
     lib.ttemb_preprocess.argtypes = [vp, vp, i64, i64, i32, vp, vp, i64, vp, vp, vp, vp, vp, i32, vp, i64, vp]
     lib.ttemb_cache_forward.argtypes = [vp, vp, vp, i64, vp, i64, vp, i64, vp, vp]
@@ -154,15 +155,26 @@ class _on_device:
 
 
 class Workspace:
-    """Grow-only scratch buffer owned by the caller (the library never allocates)."""
+    """Grow-only scratch buffer owned by the caller (the library never allocates).
+
+    A buffer that was handed out while a HIP graph was being captured is baked into that graph: when a later, larger call
+    makes the workspace grow, such a buffer is retired (kept alive for the life of this object) instead of freed, so a
+    replay never writes into memory the allocator has given to someone else."""
 
     def __init__(self) -> None:
         self.buf: Optional[torch.Tensor] = None
+        self._in_a_graph = False
+        self._retired: List[torch.Tensor] = []
 
     def get(self, nbytes: int, device: torch.device) -> torch.Tensor:
         nbytes = max(int(nbytes), 256)
         if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            if self.buf is not None and self._in_a_graph:
+                self._retired.append(self.buf)
+                self._in_a_graph = False
             self.buf = torch.empty(nbytes + nbytes // 4, dtype=torch.uint8, device=device)
+        if not self._in_a_graph and torch.cuda.is_current_stream_capturing():
+            self._in_a_graph = True
         return self.buf
 
 
@@ -291,12 +303,14 @@ def adagrad_step(weights, state, grads, lr: float, eps: float) -> None:
                                       _stream(weights)))
 
 
-def cache_update(indices: torch.Tensor, hashtbl: torch.Tensor, cache_freq: torch.Tensor) -> None:
+def cache_update(indices: torch.Tensor, hashtbl: torch.Tensor, cache_freq: torch.Tensor, one_sweep: bool = False) -> None:
+    """``one_sweep``: the reference's probe-and-insert in one pass (bit-for-bit its table, including the re-insertion of
+    cached ids after evictions) instead of looking the key up in all of its probe slots first."""
     if indices.numel() == 0:
         return
+    fn = LIB.ttemb_cache_update_one_sweep if one_sweep else LIB.ttemb_cache_update
     with _on_device(indices.device):
-        _check(LIB.ttemb_cache_update(_ptr(indices), indices.numel(), _ptr(hashtbl), _ptr(cache_freq),
-                                      hashtbl.numel(), _stream(indices)))
+        _check(fn(_ptr(indices), indices.numel(), _ptr(hashtbl), _ptr(cache_freq), hashtbl.numel(), _stream(indices)))
 
 
 def cache_populate(shape: Shape, cores, hashtbl, cache_freq, cache_state, cache_weight, ws: Workspace) -> None:

@@ -5,8 +5,11 @@
  * Every entry point replaces one function of the reference's pybind module
  * `tt_embeddings` (FBTT/tt_embeddings.cpp:131-161); the replaced interface is cited
  * per function.  The boundary is plain C: raw device pointers, explicit sizes, an
- * opaque `hipStream_t` passed as `void*`, a caller-provided workspace.  No global
- * state, no allocation, no host synchronisation unless a function says so.
+ * opaque `hipStream_t` passed as `void*`, a caller-provided workspace.  No allocation,
+ * no host synchronisation unless a function says so, and no state between calls except
+ * two process-wide DIAGNOSTIC switches that never change a result: the kernel-family
+ * override (ttemb_set_path; tests and benchmarks force a family with it) and the event
+ * profiler (ttemb_profile_enable).  A caller that never touches them has none.
  *
  * Conventions
  *   - all pointers are DEVICE pointers unless the name ends in `_host`;
@@ -174,6 +177,14 @@ int ttemb_adagrad_step(float* weights, float* state, const float* grads, int64_t
  * ------------------------------------------------------------------------------- */
 int ttemb_cache_update(const int64_t* indices, int64_t nnz, int64_t* hashtbl,
                        int64_t* cache_freq, int64_t H, void* stream);
+
+/* The same update with the reference's ONE-SWEEP insert (hashtbl_cuda_utils.cuh:102-133: the first probe slot that is
+ * empty or holds the key takes the count), for callers that need the reference's table bit for bit.  ttemb_cache_update
+ * looks the key up in all of its probe slots first: identical tables until cache_populate has evicted keys; afterwards
+ * the one-sweep form can re-insert a cached id into a hole in front of its slot, after which the id resolves to the new
+ * slot and drops out of the cache (which ids depends on thread order). */
+int ttemb_cache_update_one_sweep(const int64_t* indices, int64_t nnz, int64_t* hashtbl, int64_t* cache_freq,
+                                 int64_t H, void* stream);
 
 /* cache_populate (tt_embeddings.cpp:145, tt_embeddings_cuda.cu:1270-1347): stable
  * descending sort of the H slots by frequency, keep ranks < C (cache_state[slot] =

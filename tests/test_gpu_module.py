@@ -654,5 +654,60 @@ def test_captured_lookup_trains_like_the_eager_module(ops, orc, optimizer):
         out_a.backward(d)
         out_b.backward(d)
         torch.cuda.synchronize()
-        for ca, cb in zip(a.tt_cores, b.tt_cores):   # float atomics: the two runs differ by summation order only
-            torch.testing.assert_close(cb.data, ca.data, rtol=1e-4, atol=1e-6)
+        for ca, cb in zip(a.tt_cores, b.tt_cores):   # float atomics: the two runs differ by summation order only (Adagrad's
+            # g / sqrt(g^2) turns a last-bit difference of a tiny gradient into a visible one: absolute bound 2e-5 there)
+            torch.testing.assert_close(cb.data, ca.data, rtol=1e-4, atol=1e-6 if optimizer == "SGD" else 2e-5)
+
+
+@pytest.mark.parametrize("one_sweep", [False, True])
+def test_lfu_update_on_a_colliding_stream(orc, one_sweep):
+    """cache_update on a table that is far too small for its stream (H = 96, hundreds of distinct ids): whatever the
+    thread order, (1) a key sits in at most one slot, (2) a tracked key's count is exactly its number of occurrences (an
+    occurrence either finds the key or inserts it), (3) an untracked id has its three probe slots taken by other keys --
+    for both insert forms, which only differ after evictions."""
+    import ttemb_native as nat
+    rng = np.random.default_rng(3)
+    H = 96
+    ids = rng.integers(0, 400, size=5000).astype(np.int64)
+    keys = torch.full((H,), -1, dtype=torch.int64, device="cuda")
+    freq = torch.zeros(H, dtype=torch.int64, device="cuda")
+    nat.cache_update(torch.tensor(ids).cuda(), keys, freq, one_sweep)
+    torch.cuda.synchronize()
+    k, f = keys.cpu().numpy(), freq.cpu().numpy()
+    held = k[k >= 0]
+    assert len(set(held.tolist())) == held.shape[0]
+    counts = {int(v): int(c) for v, c in zip(*np.unique(ids, return_counts=True))}
+    for slot in np.nonzero(k >= 0)[0]:
+        assert f[slot] == counts[int(k[slot])]
+    assert (f[k < 0] == 0).all()
+    slots = orc.murmur_slots(np.array(sorted(counts), dtype=np.int64), H)
+    for key, s0 in zip(sorted(counts), slots.tolist()):
+        if key not in set(held.tolist()):
+            assert all(k[(s0 + d) % H] >= 0 and k[(s0 + d) % H] != key for d in range(3))
+    assert int(f.sum()) == sum(counts[int(v)] for v in held)
+
+
+def test_one_sweep_insert_reproduces_the_reference_after_an_eviction(orc):
+    """After cache_populate has evicted the key in FRONT of a tracked key's slot, the reference's one-sweep insert
+    (hashtbl_cuda_utils.cuh:102-133) puts the tracked key into the hole a second time; the default update finds it where it
+    is.  One key, so the outcome does not depend on thread order."""
+    import ttemb_native as nat
+    H = 64
+    # two keys with the same first probe slot: a takes it, b the next one
+    cand = np.arange(0, 20000, dtype=np.int64)
+    slots = orc.murmur_slots(cand, H)
+    s0 = int(slots[0])
+    same = cand[slots == s0]
+    a, b = int(same[0]), int(same[1])
+    for one_sweep, want_slots in ((False, 1), (True, 2)):
+        keys = torch.full((H,), -1, dtype=torch.int64, device="cuda")
+        freq = torch.zeros(H, dtype=torch.int64, device="cuda")
+        nat.cache_update(torch.tensor([a]).cuda(), keys, freq)
+        nat.cache_update(torch.tensor([b]).cuda(), keys, freq)
+        torch.cuda.synchronize()
+        assert int(keys[s0]) == a and int(keys[(s0 + 1) % H]) == b
+        keys[s0], freq[s0] = -1, 0          # what populate does to a key that did not make the cache
+        nat.cache_update(torch.tensor([b, b, b]).cuda(), keys, freq, one_sweep)
+        torch.cuda.synchronize()
+        assert int((keys == b).sum()) == want_slots
+        assert int(freq[keys == b].sum()) == 4

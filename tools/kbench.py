@@ -23,6 +23,12 @@ CFG = {"products": ([125, 140, 140], [4, 5, 5], [1, 16, 16, 1], 2449029),
        "arxiv_4core": ([50, 60, 60, 60], [2, 4, 4, 4], [1, 16, 16, 16, 1], 10800000),
        "products_4core": ([50, 60, 60, 60], [5, 5, 2, 2], [1, 16, 16, 16, 1], 10800000),
        "q2255_4core": ([50, 60, 60, 60], [2, 2, 5, 5], [1, 16, 16, 16, 1], 10800000)}
+# the rank sweep of run_script.sh:250-288 on the products factorisation (use small --n for the ranks the generic kernels take)
+for _r in (8, 32, 64, 128, 256):
+    CFG[f"q554_r{_r}"] = ([125, 140, 140], [5, 5, 4], [1, _r, _r, 1], 2449029)
+for _r in (64, 128, 256):
+    CFG[f"q448_r{_r}"] = ([125, 140, 140], [4, 4, 8], [1, _r, _r, 1], 2449029)
+CFG["q455_r8"] = ([125, 140, 140], [4, 5, 5], [1, 8, 8, 1], 2449029)
 
 
 def main():
