@@ -161,9 +161,48 @@ static bool view3(const DevShape& s, int a, DevShape* out) {   // the 3-core sha
 
 // first choice: merge the first two cores (small virtual core, the per-id operand stays the last core); else the
 // last two (q = 5,5,2,2: the virtual last core has p2 p3 rows of r2 q2 q3 floats, its dG slabs grow with it)
+// 2-core tables ride on the same 3-core kernels: row = G0[i0].G1[i1] = G0[i0].I.G1[i1] is a 3-core row over
+// (p0, 1, p1) with q = (q0, 1, q1), ranks (r1, r1) and the r1 x r1 identity as the only row of a VIRTUAL middle core
+// (a == -1 below).  The groups are the values of i0, the "prefix product" of a group is its G0 row, the gradient of
+// the identity is computed and dropped.  (FBTT/tt_embeddings_cuda.cu:757-779, :81-117 are the reference's 2-core forms.)
+static bool view_lifted2(const DevShape& s, DevShape* out) {
+  DevShape d;
+  memset(&d, 0, sizeof(d));
+  d.T = 3;
+  d.p[0] = s.p[0]; d.p[1] = 1; d.p[2] = s.p[1];
+  d.q[0] = s.q[0]; d.q[1] = 1; d.q[2] = s.q[1];
+  d.R[0] = 1; d.R[1] = s.R[1]; d.R[2] = s.R[1]; d.R[3] = 1;
+  d.D = s.D;
+  d.L[2] = 1; d.L[1] = d.p[2]; d.L[0] = (long long)d.p[1] * d.p[2];
+  long long Q = 1;
+  int pm = 0;
+  for (int t = 0; t < 3; ++t) {
+    Q *= d.q[t];
+    const long long rl = (long long)d.R[t] * d.q[t] * d.R[t + 1], pl = Q * d.R[t + 1];
+    if (rl > (1 << 24) || pl > (1 << 24)) return false;
+    d.row_len[t] = (int)rl;
+    d.part_len[t] = (int)pl;
+    if (t < 2 && d.part_len[t] > pm) pm = d.part_len[t];
+  }
+  d.part_max = pm;
+  *out = d;
+  return true;
+}
+
 static Merged4 merge_first_two(const DevShape& s, int64_t nnz, int64_t B) {
   Merged4 m;
   memset(&m, 0, sizeof(m));
+  if (s.T == 2 && current_path() != TTEMB_PATH_GENERIC) {
+    DevShape d;
+    if (view_lifted2(s, &d) && use_fast3(d, nnz, B)) {
+      m.on = true;
+      m.a = -1;
+      m.s3 = d;
+      m.K = s.R[1];
+      m.v_bytes = align256((long long)m.K * m.K * 4);
+    }
+    return m;
+  }
   if (s.T != 4 || current_path() == TTEMB_PATH_GENERIC) return m;
   for (int a = 0; a <= 2; a += 2) {
     DevShape d;
@@ -252,7 +291,16 @@ __global__ __launch_bounds__(256) void split_pair_kernel(const float* __restrict
   }
 }
 
+__global__ void identity_core_kernel(float* __restrict__ V, int K) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < K * K) V[e] = (e / K == e % K) ? 1.f : 0.f;
+}
+
 static int build_merged_core(const Merged4& m, const CorePtrs& cp, float* V, hipStream_t st) {
+  if (m.a < 0) {   // the lifted 2-core table: the virtual middle core is the identity
+    hipLaunchKernelGGL(identity_core_kernel, dim3((unsigned)((m.K * m.K + 255) / 256)), dim3(256), 0, st, V, m.K);
+    return check_hip(hipGetLastError(), "identity_core_kernel");
+  }
   hipLaunchKernelGGL(merge_pair_kernel, dim3((unsigned)(m.pa * m.pb)), dim3(256), 0, st, cp.c[m.a], cp.c[m.a + 1], m.pb, m.rows,
                      m.K, m.n, V);
   return check_hip(hipGetLastError(), "merge_pair_kernel");
@@ -261,7 +309,8 @@ static int build_merged_core(const Merged4& m, const CorePtrs& cp, float* V, hip
 // the 3-core operand lists of a merged table: V in the place of the pair
 static void merged_cores(const Merged4& m, const CorePtrs& cp, const float* V, CorePtrs* c3) {
   memset(c3, 0, sizeof(*c3));
-  if (m.a == 0) { c3->c[0] = V; c3->c[1] = cp.c[2]; c3->c[2] = cp.c[3]; }
+  if (m.a < 0) { c3->c[0] = cp.c[0]; c3->c[1] = V; c3->c[2] = cp.c[1]; }
+  else if (m.a == 0) { c3->c[0] = V; c3->c[1] = cp.c[2]; c3->c[2] = cp.c[3]; }
   else          { c3->c[0] = cp.c[0]; c3->c[1] = cp.c[1]; c3->c[2] = V; }
 }
 
@@ -447,11 +496,12 @@ static int backward_into(const DevShape& ds, const CorePtrs& cp, const int64_t* 
     CorePtrsMut d3;
     merged_cores(m4, cp, V, &c3);
     memset(&d3, 0, sizeof(d3));
-    if (m4.a == 0) { d3.c[0] = dV; d3.c[1] = dst.c[2]; d3.c[2] = dst.c[3]; }
+    if (m4.a < 0) { d3.c[0] = dst.c[0]; d3.c[1] = dV; d3.c[2] = dst.c[1]; }   // (the identity's gradient is dropped)
+    else if (m4.a == 0) { d3.c[0] = dV; d3.c[1] = dst.c[2]; d3.c[2] = dst.c[3]; }
     else           { d3.c[0] = dst.c[0]; d3.c[1] = dst.c[1]; d3.c[2] = dV; }
     rc = launch_backward_fast3(m4.s3, c3, indices, rowidx, offsets, nnz, nnz_dev, B, d_output, d3,
                                reinterpret_cast<char*>(ws) + 2 * m4.v_bytes, ws_bytes - 2 * m4.v_bytes, plan, plan_bytes, st, nullptr);
-    if (rc) return rc;
+    if (rc || m4.a < 0) return rc;
     hipLaunchKernelGGL(split_pair_kernel, dim3((unsigned)(m4.pa + m4.pb), (unsigned)m4.K), dim3(256), 0, st, cp.c[m4.a], cp.c[m4.a + 1], dV, m4.pa,
                        m4.pb, m4.rows, m4.K, m4.n, dst.c[m4.a], dst.c[m4.a + 1]);
     return check_hip(hipGetLastError(), "split_pair_kernel");

@@ -56,11 +56,10 @@ struct Cfg {
   static constexpr int LDPB = (R2 % 32 == 0) ? R2 + 16 : R2;                            // P rows, read as [4s+hi][lo]
   static constexpr int LDBB = (Q2 % 2 == 1 && ROW2 % 32 == 16) ? ROW2 : ROW2 + 4;       // G2 rows, read as [hi][lo*q2+kk]
   static constexpr int BB2_FLOATS = kChunk * LDBB;
-#ifdef TTEMB_LDOB_PLAIN
-  static constexpr int LDOB = D + 4;
-#else
-  static constexpr int LDOB = ((D + 15) / 32) * 32 + 16;
-#endif                                // d_output rows, read as [hi][m*q2+kk]
+  // d_output rows, read as [hi][m*q2+kk]; when q0 q1 is not a multiple of 4 the last K-step of the E product reads (and
+  // discards) up to three rows past the end: the stride covers them
+  static constexpr int DPAD = (M2 + 3) / 4 * 4 * Q2;
+  static constexpr int LDOB = (((DPAD > D ? DPAD : D) + 15) / 32) * 32 + 16;
   static constexpr int OB_FLOATS = kChunk * LDOB;
   static constexpr int PB_FLOATS = ((M2 * LDPB + 3) / 4) * 4;  // backward reads only the M2 real rows of P
   static constexpr int BO_FLOATS = B_FLOATS > O_FLOATS ? B_FLOATS : O_FLOATS;
@@ -1699,7 +1698,10 @@ __global__ __launch_bounds__(256) void fast3_finalize_kernel(GroupPlan plan, int
   X(4, 4, 8, 32, 32)          \
   X(5, 4, 5, 16, 16)          \
   X(5, 5, 4, 16, 16)          \
-  X(5, 5, 4, 32, 32)
+  X(5, 5, 4, 32, 32)          \
+  X(8, 1, 16, 16, 16)         \
+  X(10, 1, 10, 16, 16)        \
+  X(16, 1, 8, 16, 16)
 
 static bool shape_is(const DevShape& s, int q0, int q1, int q2, int r1, int r2) {
   return s.q[0] == q0 && s.q[1] == q1 && s.q[2] == q2 && s.R[1] == r1 && s.R[2] == r2;
@@ -1812,7 +1814,8 @@ static size_t bwd_wave_lds_floats(const DevShape& s) {   // = Cfg::PB_FLOATS + B
   const int M2 = s.q[0] * s.q[1], R2 = s.R[2], Q2 = s.q[2], ROW2 = R2 * Q2, D = s.D;
   const int LDPB = (R2 % 32 == 0) ? R2 + 16 : R2;
   const int LDBB = (Q2 % 2 == 1 && ROW2 % 32 == 16) ? ROW2 : ROW2 + 4;
-  const int LDOB = ((D + 15) / 32) * 32 + 16;
+  const int DPAD = (M2 + 3) / 4 * 4 * Q2;
+  const int LDOB = (((DPAD > D ? DPAD : D) + 15) / 32) * 32 + 16;
   return (size_t)((M2 * LDPB + 3) / 4 * 4) + (size_t)kChunk * LDBB + (size_t)kChunk * LDOB;
 }
 static bool fused_dg2(const DevShape& s) {

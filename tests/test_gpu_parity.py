@@ -366,6 +366,28 @@ def test_random_shapes_generic(nat, orc, seed):
     assert_grads_close(grads, orc.tt_dense_backward(idx, offsets, d_out, cores, p, q, R), rel=2e-4)
 
 
+@pytest.mark.parametrize("p,q,r,n_ids", [([300, 500], [8, 16], 16, 30000), ([90, 4000], [10, 10], 16, 20000),
+                                         ([7, 33], [16, 8], 16, 9000), ([1000, 60], [10, 10], 16, 50000)])
+def test_two_core_tables_on_the_grouped_path(nat, orc, p, q, r, n_ids):
+    """2-core tables (FBTT/tt_embeddings_cuda.cu:757-779 are the reference's 2-core forms) lifted onto the 3-core MFMA
+    kernels with an identity middle core: q = 8,16 / 10,10 / 16,8 at rank 16, groups = values of i0.  Ragged bags and
+    duplicates against the oracle; AUTO and the forced MFMA path give the same kernels from ~4 k ids on."""
+    R = [1, r, 1]
+    rng = np.random.default_rng(p[0] + q[0])
+    cores = [(rng.standard_normal((p[t], R[t] * q[t] * R[t + 1])) * 0.3).astype(np.float32) for t in range(2)]
+    idx, offsets = _random_bags(rng, int(np.prod(p)), n_ids)
+    want = orc.tt_forward(idx, offsets, cores, p, q, R)
+    d_out = ((rng.random(want.shape) - 0.5) * 0.2).astype(np.float32)
+    want_g = orc.tt_dense_backward(idx, offsets, d_out, cores, p, q, R)
+    for path in (nat.PATH_AUTO, nat.PATH_FAST3):
+        nat.set_path(path)
+        out, _ = run_forward(nat, p, q, R, cores, idx, offsets)
+        np.testing.assert_allclose(out, want, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(want).max())))
+        grads = run_backward_dense(nat, p, q, R, cores, idx, offsets, d_out)
+        assert_grads_close(grads, want_g, rel=2e-4)
+    nat.set_path(nat.PATH_AUTO)
+
+
 @pytest.mark.parametrize("with_rowidx", [False, True])
 @pytest.mark.parametrize("name", RANK_CASES)
 def test_rank_sweep_golden(nat, name, with_rowidx):
