@@ -81,6 +81,7 @@ int launch_backward_fast3(const DevShape& s, const CorePtrs& cores, const int64_
 // small batches of a 3-core table (ttemb_small3.inc): one wavefront per bag, MFMA per id, no grouping; `offsets` required.
 // The backward ADDS into d_cores (zeroed by the caller) with float atomics.
 bool small3_supported(const DevShape& s);
+bool small3_only(const DevShape& s);   // a rank-sweep shape only these kernels are instantiated for
 int launch_forward_small3(const DevShape& s, const CorePtrs& cores, const int64_t* indices, const int64_t* offsets, int64_t nnz,
                           const int32_t* nnz_dev, int64_t B, float* output, hipStream_t st);
 int launch_backward_small3(const DevShape& s, const CorePtrs& cores, const int64_t* indices, const int64_t* offsets, int64_t nnz,

@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--dist", default="uniform", choices=["uniform", "windows", "arange", "grouped"])
     ap.add_argument("--path", default="auto")
     ap.add_argument("--what", default="both", choices=["both", "fwd", "bwd"])
+    ap.add_argument("--no-rowidx", action="store_true", help="ids + offsets only, as the module passes them (the per-bag kernels need this form)")
     a = ap.parse_args()
     p, q, R, n_emb = CFG[a.cfg]
     D = int(np.prod(q))
@@ -65,6 +66,8 @@ def main():
         offs = torch.arange(N + 1, device="cuda")
         rowidx = torch.empty(N, dtype=torch.int64, device="cuda")
         nat.preprocess(idx, offs, N, True, None, None, None, rowidx, None, None, ws)
+        if a.no_rowidx:
+            rowidx = None
         out = torch.empty(N, D, device="cuda")
         d_out = (torch.rand(N, D, device="cuda") - 0.5) * 0.1
         grads = [torch.empty_like(c) for c in cores]
@@ -75,7 +78,7 @@ def main():
                 if i >= 3:
                     f.append(nat.profile_read(0))
             if a.what in ("both", "bwd"):
-                nat.backward_dense(shape, cores, idx, rowidx, N, None, N, d_out, grads, ws)
+                nat.backward_dense(shape, cores, idx, rowidx, N, None, N, d_out, grads, ws, None, offs)
                 if i >= 3:
                     b.append(nat.profile_read(1))
                     c.append(nat.profile_read(2))
