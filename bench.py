@@ -391,6 +391,14 @@ def main():
             torch.set_num_threads(all_thr)
             best = max(by_thr.values())
             cpu["one_thread_value"] = round(r1["lookups_per_s"], 1)
+            # BASELINE.json configs[0] (the reference's own CPU-runnable case): ogbn-arxiv shapes, batch 256, einsum on the
+            # host.  The product has no CPU path (a CPU fallback would void parity), so this leg exists on the baseline
+            # side only; its GPU counterpart is matrix["arxiv_r8_256"].
+            pa, qa, ra, na = SHAPES["arxiv_r8"]
+            rr = cpu_einsum.time_baseline(pa, qa, [1] + ra + [1], 256, na, seed=1234, budget_s=2.0, threads=8)
+            torch.set_num_threads(all_thr)
+            cpu["arxiv_r8_batch256"] = {"value": round(rr["lookups_per_s"], 1), "unit": "lookups/s", "cores": 8,
+                                        "sample": "fwd+bwd+SGD steps of 256 unique ids, ~2 s"}
             cpu2048 = {"value": best, "unit": "lookups/s", "by_threads": by_thr, "kind": "port",
                        "sample": "fwd+bwd+SGD steps of 2048 unique uniform ids, ~2.5 s per thread count",
                        "gpu_over_cpu": None if small is None else round(small["lookups_per_s"] / best, 1)}
@@ -401,7 +409,8 @@ def main():
                       "products_r16_2048": matrix_leg(nat, "products_r16", 2048, "uniform"),
                       "papers100M_r32_819200": matrix_leg(nat, "papers100M_r32", 819200, "uniform", iters=20),
                       "papers100M_r32_4096": matrix_leg(nat, "papers100M_r32", 4096, "uniform"),
-                      "arxiv_r8_full_graph": matrix_leg(nat, "arxiv_r8", 169343, "arange")}
+                      "arxiv_r8_full_graph": matrix_leg(nat, "arxiv_r8", 169343, "arange"),
+                      "arxiv_r8_256": matrix_leg(nat, "arxiv_r8", 256, "uniform")}
         result = {
             "metric": "tt_embedding_lookups_per_sec", "value": round(value, 1), "unit": "lookups/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
