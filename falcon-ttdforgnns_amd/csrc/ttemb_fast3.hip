@@ -899,10 +899,18 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
 
   // ---- kernel-lifetime lane constants ----
   // LDS offsets of the MFMA operands.  dP step (b4, kk): lane group `hi` contributes id b = 4 b4 + hi, column kk of it
+  // When the last row tile of dP holds at most four rows (q0 q1 = 20: rows 16..19) it is multiplied by the 16-block
+  // 4x4x1 MFMA instead of a padded 16x16x4 one: 8 cycles instead of 32 for the same K-step.  Block (hi, lo / 4) of that
+  // instruction takes A = dO[id hi][row 16 (MT2-1) + lo % 4] and B = the SAME register the wide tiles use
+  // (G2[id hi][c2 = lo]), and leaves in lane (hi, lo) the sum over "its" id of every K-step for dP[row][c2 = lo]: the
+  // four lane groups are added when the group's dP is stored.
+  constexpr int kTailRows = C::M2 - 16 * (C::MT2 - 1);
+  constexpr bool kNarrowTail = C::MT2 > 1 && kTailRows <= 4;
   int offA[C::MT2], offB[C::RT2], offE[C::NT2];
 #pragma unroll
   for (int mt = 0; mt < C::MT2; ++mt) {
-    const int m = 16 * mt + lo < C::M2 ? 16 * mt + lo : C::M2 - 1;  // rows past M2 are discarded
+    int m = 16 * mt + lo < C::M2 ? 16 * mt + lo : C::M2 - 1;  // rows past M2 are discarded
+    if (kNarrowTail && mt == C::MT2 - 1) m = 16 * mt + (lo & 3) < C::M2 ? 16 * mt + (lo & 3) : C::M2 - 1;
     offA[mt] = hi * C::LDOB + m * Q2;
   }
 #pragma unroll
@@ -1077,8 +1085,12 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
 #pragma unroll
           for (int mt = 0; mt < C::MT2; ++mt)
 #pragma unroll
-            for (int t = 0; t < C::RT2; ++t)
-              dp[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv[t], dp[mt][t], 0, 0, 0);
+            for (int t = 0; t < C::RT2; ++t) {
+              if (kNarrowTail && mt == C::MT2 - 1)
+                dp[mt][t] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[mt], bv[t], dp[mt][t], 0, 0, 0);
+              else
+                dp[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv[t], dp[mt][t], 0, 0, 0);
+            }
         }
       }
       __builtin_amdgcn_sched_barrier(0);  // keeps operand loads from piling up in registers
@@ -1177,7 +1189,18 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
 #pragma unroll
         for (int t = 0; t < C::RT2; ++t)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) buf_store1(r_dp, dpoff[mt][t] + (uint32_t)(r * R2 * 4), dp[mt][t][r]);
+          for (int r = 0; r < 4; ++r) {
+            if (kNarrowTail && mt == C::MT2 - 1) {
+              // narrow tile: register r of lane (hi, lo) is lane group hi's share of dP[16 mt + r][c2 = 16 t + lo]
+              float v = dp[mt][t][r];
+              v += __shfl_xor(v, 16, kWave);
+              v += __shfl_xor(v, 32, kWave);
+              const bool mine = hi == 0 && 16 * t + lo < R2 && r < kTailRows;
+              buf_store1(r_dp, mine ? (uint32_t)((16 * mt + r) * R2 + 16 * t + lo) * 4u : kOobBase, v);
+            } else {
+              buf_store1(r_dp, dpoff[mt][t] + (uint32_t)(r * R2 * 4), dp[mt][t][r]);
+            }
+          }
     }
     TTEMB_STAMP(4);
     bool reduce_now = false;

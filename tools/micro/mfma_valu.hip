@@ -67,6 +67,12 @@ __device__ __forceinline__ void body(int role, float* out, float* lds) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
   }
+  else if (role == 6) {   // the 16-block 4x4x1 form (512 flop per instruction)
+    for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, acc[i], 0, 0, 0);
+    }
+  }
   float s = 0.f;
   for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
   for (int i = 0; i < 8; ++i) s += v[i];
@@ -115,6 +121,8 @@ int main() {
   t = run<0>(1, 4, out); printf("2 waves/SIMD MFMA | ds_read_b32      : %7.3f ms\n", t);
   t = run<2>(5, 0, out); printf("1 wave/SIMD  MFMA + 2 ds_read each   : %7.3f ms = %6.1f cyc/MFMA\n", t, cyc(t));
   t = run<4>(5, 0, out); printf("1 wave/SIMD  MFMA + 4 ds_read each   : %7.3f ms = %6.1f cyc/MFMA\n", t, cyc(t));
+  t = run<0>(6, 0, out); printf("1 wave/SIMD  v_mfma_f32_4x4x1_16b only: %7.3f ms = %6.1f cyc per instruction (512 flop)\n", t, cyc(t));
+  t = run<0>(6, 6, out); printf("2 waves/SIMD 4x4x1 | 4x4x1           : %7.3f ms = %6.1f cyc per pair\n", t, cyc(t));
   t = run<2>(3, 3, out); printf("2 waves/SIMD both MFMA + 2 v_fma     : %7.3f ms = %6.1f cyc per MFMA pair\n", t, cyc(t));
   t = run<4>(3, 3, out); printf("2 waves/SIMD both MFMA + 4 v_fma     : %7.3f ms = %6.1f cyc per MFMA pair\n", t, cyc(t));
   return 0;
