@@ -537,13 +537,11 @@ __global__ __launch_bounds__(256) void cache_rowwise_adagrad_kernel(
     mult = lr * (1.0f / (sqrtf(old + g2) + eps));
   }
   mult = __shfl(mult, 0, kWave);
-  float4* w = reinterpret_cast<float4*>(weight + (int64_t)l * D);
-  for (int c = lane; c * 4 < D; c += kWave) {
-    const float4 v = g[c];
-    float4 cur = w[c];
-    cur.x -= v.x * mult; cur.y -= v.y * mult; cur.z -= v.z * mult; cur.w -= v.w * mult;
-    w[c] = cur;
-  }
+  // A cache row can occur several times in a batch (the reference's read-modify-write loses updates then,
+  // tt_embeddings_cuda.cu:1746-1806): the row is updated with float atomics, 64 consecutive floats per instruction.
+  float* w = weight + (int64_t)l * D;
+  const float* gs = grad + rowidx[n] * D;
+  for (int c = lane; c < D; c += kWave) atomicAdd(w + c, -gs[c] * mult);
 }
 
 static inline unsigned wave_blocks(int64_t nnz) { return (unsigned)((nnz + 3) / 4); }

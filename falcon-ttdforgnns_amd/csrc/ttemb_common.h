@@ -125,6 +125,10 @@ __device__ __forceinline__ int64_t live_count(int64_t nnz, const int32_t* nnz_de
 
 // id -> per-core row numbers (reference: FBTT/tt_embeddings_cuda.cu:796-802).
 __device__ __forceinline__ void split_index(const DevShape& s, int64_t idx, int (&i)[TTEMB_MAX_CORES]) {
+  // an id outside the table is clamped as a whole (to the first / last row), the rule of every kernel family, so a bad
+  // id gives the same row whichever kernels a batch size selects
+  const int64_t rows = (int64_t)s.L[0] * s.p[0];
+  idx = idx < 0 ? 0 : (idx >= rows ? rows - 1 : idx);
 #pragma unroll
   for (int t = 0; t < TTEMB_MAX_CORES; ++t) {
     if (t < s.T) {

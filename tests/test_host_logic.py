@@ -268,3 +268,29 @@ def test_import_resolution_next_to_a_reference_shaped_tree(tmp_path):
         who, parser, _, ops_file, has_class, shim = out.stdout.split()   # "reference parser" prints as two words
         assert who == "reference" and parser == "reference"
         assert ops_file.startswith(PKG) and has_class == "True" and shim.startswith(PKG)
+
+
+def test_bench_starts_its_own_ranks_when_started_plainly(monkeypatch):
+    """`python bench.py --gpus N` without a launcher: the same command line goes under torch.distributed.run as a child
+    process (one rank per GPU, rendezvous on 127.0.0.1) before the parent has touched the GPU."""
+    import importlib.util
+    import subprocess
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return subprocess.CompletedProcess(cmd, 0)
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    assert bench._launch_ranks(4) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "7"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
