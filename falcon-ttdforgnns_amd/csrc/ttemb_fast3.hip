@@ -38,7 +38,7 @@ struct Cfg {
   static constexpr int KS1 = R1 / 4;             // k-steps (K = 4 per MFMA)
   static constexpr int KS2 = R2 / 4;
   static constexpr int N1 = Q1 * R2;             // columns of the prefix product
-  static constexpr int NT1 = N1 / 16;
+  static constexpr int NT1 = (N1 + 15) / 16;     // (a last tile that q1 r2 does not fill is masked: q1 = 5 at rank 8)
   static constexpr int NT2 = Q2;                 // (16 ids * Q2 columns) / 16
   static constexpr int D = Q0 * Q1 * Q2;
   static constexpr int ROW0 = Q0 * R1;           // floats per core row
@@ -75,7 +75,7 @@ struct Cfg {
   static_assert(LDOB >= (M2 + 3) / 4 * 4 * Q2, "the padded K-step of the E product reads inside the staged row");
   static_assert(Q0 <= 16, "stage 1 pads q0 to one 16-row tile");
   static_assert(R1 % 4 == 0 && R2 % 4 == 0, "ranks must be multiples of the MFMA K");
-  static_assert(N1 % 16 == 0, "q1*r2 must tile by 16");
+  static_assert(N1 % 4 == 0, "rows of the prefix product move as float4");
   static_assert(D % 4 == 0 && ROW2 % 4 == 0, "rows move as float4");
   static_assert(ROW2 <= 256, "the dG2 reduce reads one E row per wavefront load");
 };
@@ -502,7 +502,8 @@ __device__ __forceinline__ void prefix_unit(const float* __restrict__ G0, const 
 #pragma unroll
   for (int s = 0; s < C::KS1; ++s)
 #pragma unroll
-    for (int nt = 0; nt < C::NT1; ++nt) bv[s][nt] = g1[(4 * s + hi) * C::N1 + 16 * nt + lo];
+    for (int nt = 0; nt < C::NT1; ++nt)
+      bv[s][nt] = (C::N1 % 16 == 0 || 16 * nt + lo < C::N1) ? g1[(4 * s + hi) * C::N1 + 16 * nt + lo] : 0.f;
   for (uint32_t base = 0; base < (uint32_t)kPrefixGroups; base += GM) {
     if (!((live >> base) & ((1ull << GM) - 1))) continue;  // none of these groups holds an id
     const uint32_t i0a = i0_begin + base + lo / Q0;         // A operand: row lo = (group lo / q0, core row lo % q0)
@@ -528,7 +529,7 @@ __device__ __forceinline__ void prefix_unit(const float* __restrict__ G0, const 
 #pragma unroll
       for (int nt = 0; nt < C::NT1; ++nt) {
         const int n = 16 * nt + lo;
-        dst[(a * Q1 + n / R2) * R2 + n % R2] = acc[nt][r];
+        if (C::N1 % 16 == 0 || n < C::N1) dst[(a * Q1 + n / R2) * R2 + n % R2] = acc[nt][r];
       }
     }
   }
@@ -1537,7 +1538,8 @@ __device__ __forceinline__ void epilogue_unit(
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int nt = 0; nt < C::NT1; ++nt) b1[s][nt] = dpbuf[(4 * s + hi) * LDD + 16 * nt + lo];
+      for (int nt = 0; nt < C::NT1; ++nt)
+        b1[s][nt] = (C::N1 % 16 == 0 || 16 * nt + lo < C::N1) ? dpbuf[(4 * s + hi) * LDD + 16 * nt + lo] : 0.f;
     float a3[KS3], b3[KS3][C::RT1];   // dG0: A[rho = lo][k = n = 4 s + hi], B[k = n][c = 16 t + lo] = G1[c][n]
 #pragma unroll
     for (int s = 0; s < KS3; ++s) {
@@ -1591,7 +1593,7 @@ __device__ __forceinline__ void epilogue_unit(
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int c = 16 * t + 4 * hi + r;
-        if (c < R1) dst[c * C::N1 + 16 * nt + lo] = g1acc[t][nt][r];
+        if (c < R1 && (C::N1 % 16 == 0 || 16 * nt + lo < C::N1)) dst[c * C::N1 + 16 * nt + lo] = g1acc[t][nt][r];
       }
 }
 
@@ -1710,7 +1712,7 @@ __global__ __launch_bounds__(256) void fast3_finalize_kernel(GroupPlan plan, int
 // ---------------------------------------------------------------------------------
 // The (q, ranks) shapes with an instantiated chain: the three BASELINE.json configurations first, then the other
 // 3-core shapes the reference's run scripts train with (q = 4,4,8 / 4,5,5 / 8,4,4 at rank 16; the rank sweep of
-// the products shape).  q1 r2 has to tile by 16, so 4,5,5 at rank 8 stays on the generic path.
+// the products shape; a last column tile of q1 r2 that is not full is masked: q1 = 5 at rank 8).
 #define TTEMB_FAST3_SHAPES(X) \
   X(4, 5, 5, 16, 16)          \
   X(4, 4, 8, 8, 8)            \
@@ -1722,6 +1724,8 @@ __global__ __launch_bounds__(256) void fast3_finalize_kernel(GroupPlan plan, int
   X(5, 4, 5, 16, 16)          \
   X(5, 5, 4, 16, 16)          \
   X(5, 5, 4, 32, 32)          \
+  X(5, 5, 4, 8, 8)            \
+  X(4, 5, 5, 8, 8)            \
   X(8, 1, 16, 16, 16)         \
   X(10, 1, 10, 16, 16)        \
   X(16, 1, 8, 16, 16)

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 PATHS = ["generic", "auto", "fast3"]
 # (q0, q1, q2, r1, r2) of the MFMA path: the BASELINE.json shapes, then the other 3-core shapes of the reference's scripts
 FAST3_SHAPES = {(4, 5, 5, 16, 16), (4, 4, 8, 8, 8), (8, 4, 4, 32, 32), (4, 4, 8, 16, 16), (8, 4, 4, 16, 16),
-                (4, 5, 5, 32, 32), (4, 4, 8, 32, 32), (5, 4, 5, 16, 16), (5, 5, 4, 16, 16), (5, 5, 4, 32, 32)}
+                (4, 5, 5, 32, 32), (4, 4, 8, 32, 32), (5, 4, 5, 16, 16), (5, 5, 4, 16, 16), (5, 5, 4, 32, 32), (5, 5, 4, 8, 8), (4, 5, 5, 8, 8)}
 
 
 @pytest.fixture(scope="module")
