@@ -1311,7 +1311,7 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
 // with float atomics, a whole row (contiguous floats) per non-empty bucket, instead of a slab per tile (a 4-core
 // table with a merged last pair has 0.9 MB slabs: 256 of them were 236 MB to write and read back).
 template <int ROW2, int kRowsMax, int NWB, bool SHARED>
-__global__ __launch_bounds__(NWB * 64) void fast3_dg2_reduce_kernel(GroupPlan plan, int G, uint32_t p2, uint32_t kRowsB) {
+__global__ __launch_bounds__(NWB * 64) void fast3_dg2_reduce_kernel(GroupPlan plan, int G, uint32_t p2, uint32_t kRowsB, uint32_t stride) {
   extern __shared__ uint32_t lds_u[];   // [p2 + 1] bucket starts | [p2] cursors | [kRowsMax] row list (uint16)
   uint32_t* bstart = lds_u;
   uint32_t* cursor = lds_u + p2 + 1;
@@ -1322,7 +1322,10 @@ __global__ __launch_bounds__(NWB * 64) void fast3_dg2_reduce_kernel(GroupPlan pl
   const uint32_t total = (uint32_t)plan.gpre[G];
   const uint32_t s0 = blockIdx.x * kRowsB;
   const uint32_t n_rows = s0 >= total ? 0u : (s0 + kRowsB < total ? kRowsB : total - s0);
-  float* slab = plan.g2part + (SHARED ? (size_t)0 : (size_t)blockIdx.x * p2 * ROW2);  // this tile's partial dG2, every row written
+  // rows wider than a wavefront load (the wide-rank chain) are reduced ROW2 floats at a time: launch row blockIdx.y
+  // takes columns [ROW2 y, ROW2 (y + 1)) of every E row (`stride` floats apart) and of the slab
+  const uint32_t col0 = blockIdx.y * ROW2;
+  float* slab = plan.g2part + (SHARED ? (size_t)0 : (size_t)blockIdx.x * p2 * stride) + col0;  // this tile's partial dG2, every row written
   for (uint32_t e = tid; e <= p2; e += NWB * 64) bstart[e] = 0;
   __syncthreads();
   // histogram of i2 over the tile (integer LDS atomics; 8 ids per thread)
@@ -1375,7 +1378,7 @@ __global__ __launch_bounds__(NWB * 64) void fast3_dg2_reduce_kernel(GroupPlan pl
         for (int u = 0; u < U; ++u) {
           v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
           if (rr[u] != 0xffffffffu)
-            v[u] = *reinterpret_cast<const float4*>(plan.etab + (size_t)(s0 + rr[u]) * ROW2 + 4 * c4);
+            v[u] = *reinterpret_cast<const float4*>(plan.etab + (size_t)(s0 + rr[u]) * stride + col0 + 4 * c4);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -1398,10 +1401,10 @@ __global__ __launch_bounds__(NWB * 64) void fast3_dg2_reduce_kernel(GroupPlan pl
         const float x = __shfl(acc.x, src, kWave), y = __shfl(acc.y, src, kWave);
         const float z = __shfl(acc.z, src, kWave), w = __shfl(acc.w, src, kWave);
         const float v = (e & 3) == 0 ? x : ((e & 3) == 1 ? y : ((e & 3) == 2 ? z : w));
-        if (e < ROW2) atomicAdd(slab + (size_t)i2 * ROW2 + e, v);
+        if (e < ROW2) atomicAdd(slab + (size_t)i2 * stride + e, v);
       }
     } else {
-      if (lane < F4) *reinterpret_cast<float4*>(slab + (size_t)i2 * ROW2 + 4 * lane) = acc;
+      if (lane < F4) *reinterpret_cast<float4*>(slab + (size_t)i2 * stride + 4 * lane) = acc;
     }
   }
 }
@@ -1629,11 +1632,11 @@ __device__ __forceinline__ void finalize_emit(const FusedUpdate& upd, int t, flo
 __global__ __launch_bounds__(256) void fast3_finalize_kernel(GroupPlan plan, int tiles, int slices, int p0, int p1,
                                                              int g2_floats, int row0, int g1_floats, int q2, int r2,
                                                              float* __restrict__ dG0, float* __restrict__ dG1,
-                                                             float* __restrict__ dG2, FusedUpdate upd) {
+                                                             float* __restrict__ dG2, FusedUpdate upd, int all_parts) {
   __shared__ float part[8][33];
   const int x = threadIdx.x & 31, y = threadIdx.x >> 5;
   const int n0 = p0 * row0;
-  const bool sparse = sparse_groups(plan, (uint32_t)(p0 * p1));   // the form the epilogue kernel took
+  const bool sparse = !all_parts && sparse_groups(plan, (uint32_t)(p0 * p1));   // the form the epilogue kernel took (the wide-rank chain writes every part)
   // dG1 has few terms per output (one per slice): one thread per output, 256 outputs per workgroup, the workgroups
   // after those of dG2 / dG0 (eight threads per output as below made 8x the workgroups for the largest of the cores)
   const int wg_a = (g2_floats + n0 + 31) / 32;
@@ -1707,6 +1710,8 @@ __global__ __launch_bounds__(256) void fast3_finalize_kernel(GroupPlan plan, int
   }
 }
 
+#include "ttemb_wide3.inc"
+
 // ---------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------
@@ -1730,6 +1735,15 @@ __global__ __launch_bounds__(256) void fast3_finalize_kernel(GroupPlan plan, int
   X(10, 1, 10, 16, 16)        \
   X(16, 1, 8, 16, 16)
 
+// the wide-rank chain (ttemb_wide3.inc): the upper half of the reference's rank sweep
+#define TTEMB_WIDE3_SHAPES(X) \
+  X(5, 5, 4, 64, 64)          \
+  X(5, 5, 4, 128, 128)        \
+  X(5, 5, 4, 256, 256)        \
+  X(4, 4, 8, 64, 64)          \
+  X(4, 4, 8, 128, 128)        \
+  X(4, 4, 8, 256, 256)
+
 static bool shape_is(const DevShape& s, int q0, int q1, int q2, int r1, int r2) {
   return s.q[0] == q0 && s.q[1] == q1 && s.q[2] == q2 && s.R[1] == r1 && s.R[2] == r2;
 }
@@ -1743,7 +1757,16 @@ static bool classify(const DevShape& s) {
   return false;
 }
 
-bool fast3_supported(const DevShape& s) { return classify(s); }
+static bool wide(const DevShape& s) {
+  if (s.T != 3) return false;
+  if ((long long)s.L[0] * s.p[0] >= 0x7fffffffll) return false;
+#define TTEMB_X(a, b, c, d, e) if (shape_is(s, a, b, c, d, e)) return true;
+  TTEMB_WIDE3_SHAPES(TTEMB_X)
+#undef TTEMB_X
+  return false;
+}
+
+bool fast3_supported(const DevShape& s) { return classify(s) || wide(s); }
 
 static int64_t num_groups(const DevShape& s) { return (int64_t)s.p[0] * s.p[1]; }
 
@@ -1771,7 +1794,7 @@ bool fast3_pays(const DevShape& s, int64_t nnz) {
 // reduce keeps two counters per i2 in LDS (p2 <= 4096: 36 KB); p1 is a grid.y extent
 bool fast3_fits(const DevShape& s, int64_t nnz, int64_t B) {
   const int64_t lim = int64_t(1) << 31;   // an offset of 2 GiB marks "no row" in the chain kernels (kOobBase)
-  return B * s.D * 4 < lim && B < (int64_t(1) << 24) && nnz * (int64_t)s.row_len[2] * 4 < lim &&
+  return B * s.D * 4 < lim && B < (int64_t(1) << 24) && (wide(s) || nnz * (int64_t)s.row_len[2] * 4 < lim) &&
          num_groups(s) * (int64_t)s.q[0] * s.q[1] * s.R[2] * 4 < lim && s.p[2] <= 4096 && s.p[1] < 65536 &&
          num_groups(s) <= (int64_t)kMaxRanges * 4096;   // the grouping pass: <= 512 ranges of <= 4096 groups (64 KB of LDS)
 }
@@ -1870,7 +1893,11 @@ static int epi_groups_per_wave(const DevShape& s) {
   int gpw = (s.p[0] + kEpiSlices - 1) / kEpiSlices;
   return gpw < 1 ? 1 : (gpw > 64 ? 64 : gpw);
 }
-static int epi_slices(const DevShape& s) { const int g = epi_groups_per_wave(s); return (s.p[0] + g - 1) / g; }
+static int epi_slices(const DevShape& s) {   // (the wide-rank chain forms dG1[i1] whole: one slab)
+  if (wide(s)) return 1;
+  const int g = epi_groups_per_wave(s);
+  return (s.p[0] + g - 1) / g;
+}
 
 // What forward and backward share ("plan"): grouped (i2, row) pairs, group sizes / starts, the chunk table and
 // the prefix products.  It lives in a caller buffer when one is given, else in the workspace.  A backward that
@@ -1991,10 +2018,12 @@ static int group_ids(const DevShape& s, const CorePtrs& cores, const int64_t* in
                      *plan);
   rc = check_hip(hipGetLastError(), "fast3_count_kernel");
   if (rc) return rc;
-  if (with_prefix) return run_place_prefix(s, cores, *plan, nnz, ranges, shift, st);
+  if (with_prefix && !wide(s)) return run_place_prefix(s, cores, *plan, nnz, ranges, shift, st);
   hipLaunchKernelGGL(fast3_place_kernel, dim3((unsigned)ranges), dim3(kRangeThreads), span * 16, st, (uint32_t)nnz,
                      (uint32_t)max_chunks(s, nnz), (uint32_t)G, (uint32_t)shift, *plan);
-  return check_hip(hipGetLastError(), "fast3_place_kernel");
+  rc = check_hip(hipGetLastError(), "fast3_place_kernel");
+  if (rc == TTEMB_OK && with_prefix) rc = run_prefix(s, cores, *plan, st);   // wide ranks: the prefix products are a GEMM of their own
+  return rc;
 }
 
 // resolve where the plan lives, carve the workspace, group the ids unless a ready plan was passed
@@ -2031,7 +2060,29 @@ static int run_prefix_t(const DevShape& s, const CorePtrs& cores, const GroupPla
   return check_hip(hipGetLastError(), "fast3_prefix_kernel");
 }
 
+// ---- wide-rank chain: launches ----
+template <bool A_KC, bool B_KC>
+static int run_wide_gemm(const WideGemm& g, uint32_t batches, hipStream_t st, const char* what) {
+  const uint32_t units = g.tiles_m * g.tiles_n;
+  hipLaunchKernelGGL((wide3_gemm_kernel<A_KC, B_KC>), dim3((units + 3) / 4, batches), dim3(256), 0, st, g);
+  return check_hip(hipGetLastError(), what);
+}
+
+// P[i1] (p0 q0 x q1 r2) = G0 (p0 q0 x r1) . G1[i1] (r1 x q1 r2), every group
+static int run_prefix_wide(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, hipStream_t st) {
+  const uint32_t M = (uint32_t)(s.p[0] * s.q[0]), N = (uint32_t)(s.q[1] * s.R[2]), K = (uint32_t)s.R[1];
+  WideGemm g;
+  g.A = cores.c[0]; g.B = cores.c[1]; g.C = plan.ptab;
+  g.K = K;
+  g.lda = K; g.ldb = N; g.ldc = N;
+  g.a_batch = 0; g.b_batch = K * N; g.c_batch = M * N;
+  g.a_bytes = M * K * 4; g.b_bytes = K * N * 4; g.c_bytes = M * N * 4;
+  g.tiles_m = (M + 63) / 64; g.tiles_n = N / 64;
+  return run_wide_gemm<true, false>(g, (uint32_t)s.p[1], st, "wide3_gemm_kernel (prefix)");
+}
+
 static int run_prefix(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, hipStream_t st) {
+  if (wide(s)) return run_prefix_wide(s, cores, plan, st);
   if (classify(s)) {
 #define TTEMB_X(a, b, c, d, e) if (shape_is(s, a, b, c, d, e)) return run_prefix_t<a, b, c, d, e>(s, cores, plan, st);
     TTEMB_FAST3_SHAPES(TTEMB_X)
@@ -2077,6 +2128,78 @@ static int run_forward(const DevShape& s, const CorePtrs& cores, const GroupPlan
   return check_hip(hipGetLastError(), "fast3_forward_kernel");
 }
 
+template <int Q0, int Q1, int Q2, int R1, int R2>
+static int run_forward_wide(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int64_t nnz, int64_t B,
+                            float* output, hipStream_t st) {
+  const uint32_t waves = (uint32_t)max_chunks(s, nnz);   // the chunk count is known on the device only: surplus wavefronts leave at once
+  profile_begin(0, st);
+  hipLaunchKernelGGL((wide3_forward_kernel<Q0, Q1, Q2, R1, R2>), dim3((waves + 3) / 4), dim3(256), 0, st, cores.c[2], plan,
+                     (uint32_t)num_groups(s), (uint32_t)s.p[2], output, (uint32_t)(B * s.D * 4));
+  profile_end(0, st);
+  return check_hip(hipGetLastError(), "wide3_forward_kernel");
+}
+
+// backward of the wide-rank chain: per-group products, the E reduce (a column slice of 256 floats per launch row),
+// dG1 / dG0 as GEMMs over the dP table, the shared finalize kernel
+template <int Q0, int Q1, int Q2, int R1, int R2>
+static int run_backward_wide(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int64_t nnz, int64_t B,
+                             const float* d_output, const CorePtrsMut& d_cores, const FusedUpdate& upd, hipStream_t st) {
+  using C = WideCfg<Q0, Q1, Q2, R1, R2>;
+  const int64_t G = num_groups(s);
+  profile_begin(1, st);
+  profile_begin(2, st);
+  hipLaunchKernelGGL((wide3_bwd_chunk_kernel<Q0, Q1, Q2, R1, R2>), dim3((unsigned)((G * C::TS + 3) / 4)), dim3(256), 0, st, cores.c[2],
+                     (uint32_t)G, (uint32_t)s.p[2], d_output, (uint32_t)(B * s.D * 4), plan);
+  profile_end(2, st);
+  int rc = check_hip(hipGetLastError(), "wide3_bwd_chunk_kernel");
+  if (rc) return rc;
+  static_assert(C::ROW2 % 256 == 0, "the E reduce takes 256 columns per launch row");
+  const int tiles = (int)reduce_tiles(nnz);
+  const size_t reduce_lds = (size_t)(2 * s.p[2] + 1) * 4 + kRowsB * 2;
+  if (shared_slab(s)) {
+    rc = launch_zero(plan.g2part, (size_t)s.p[2] * C::ROW2 * 4, st, "zero the shared dG2 slab");
+    if (rc) return rc;
+    hipLaunchKernelGGL((fast3_dg2_reduce_kernel<256, kRowsB, NWB, true>), dim3((unsigned)tiles, C::ROW2 / 256), dim3(NWB * 64), reduce_lds,
+                       st, plan, (int)G, (uint32_t)s.p[2], (uint32_t)reduce_rows(nnz), (uint32_t)C::ROW2);
+  } else {
+    hipLaunchKernelGGL((fast3_dg2_reduce_kernel<256, kRowsB, NWB, false>), dim3((unsigned)tiles, C::ROW2 / 256), dim3(NWB * 64), reduce_lds,
+                       st, plan, (int)G, (uint32_t)s.p[2], (uint32_t)reduce_rows(nnz), (uint32_t)C::ROW2);
+  }
+  rc = check_hip(hipGetLastError(), "fast3_dg2_reduce_kernel (wide)");
+  if (rc) return rc;
+  const uint32_t M = (uint32_t)(s.p[0] * Q0), N1 = (uint32_t)C::N1;
+  {  // dG1[i1] (r1 x q1 r2) = G0^T (r1 x p0 q0) . dP[i1] (p0 q0 x q1 r2)
+    WideGemm g;
+    g.A = cores.c[0]; g.B = plan.dptab; g.C = plan.g1part;
+    g.K = M;
+    g.lda = R1; g.ldb = N1; g.ldc = N1;
+    g.a_batch = 0; g.b_batch = M * N1; g.c_batch = (uint32_t)C::ROW1;
+    g.a_bytes = M * R1 * 4; g.b_bytes = M * N1 * 4; g.c_bytes = (uint32_t)C::ROW1 * 4;
+    g.tiles_m = R1 / 64; g.tiles_n = N1 / 64;
+    rc = run_wide_gemm<false, false>(g, (uint32_t)s.p[1], st, "wide3_gemm_kernel (dG1)");
+    if (rc) return rc;
+  }
+  {  // dG0 parts of i1 (p0 q0 x r1) = dP[i1] (p0 q0 x q1 r2) . G1[i1]^T (q1 r2 x r1); the finalize kernel sums over i1
+    WideGemm g;
+    g.A = plan.dptab; g.B = cores.c[1]; g.C = plan.g0part;
+    g.K = N1;
+    g.lda = N1; g.ldb = N1; g.ldc = R1;
+    g.a_batch = M * N1; g.b_batch = (uint32_t)C::ROW1; g.c_batch = M * R1;
+    g.a_bytes = M * N1 * 4; g.b_bytes = (uint32_t)C::ROW1 * 4; g.c_bytes = M * R1 * 4;
+    g.tiles_m = (M + 63) / 64; g.tiles_n = R1 / 64;
+    rc = run_wide_gemm<true, true>(g, (uint32_t)s.p[1], st, "wide3_gemm_kernel (dG0)");
+    if (rc) return rc;
+  }
+  {
+    const int g2_floats = s.p[2] * C::ROW2, g1_floats = s.p[1] * C::ROW1;
+    const int wgs = (g2_floats + s.p[0] * C::ROW0 + 31) / 32 + (g1_floats + 255) / 256;
+    hipLaunchKernelGGL(fast3_finalize_kernel, dim3((unsigned)wgs), dim3(256), 0, st, plan, (int)slab_count(s, nnz), 1, s.p[0], s.p[1],
+                       g2_floats, (int)C::ROW0, g1_floats, Q2, R2, d_cores.c[0], d_cores.c[1], d_cores.c[2], upd, 1);
+  }
+  profile_end(1, st);
+  return check_hip(hipGetLastError(), "fast3_finalize_kernel (wide)");
+}
+
 int launch_forward_fast3(const DevShape& s, const CorePtrs& cores, const int64_t* indices,
                          const int64_t* rowidx, const int64_t* offsets, int64_t nnz, const int32_t* nnz_dev,
                          int64_t B, float* output, bool zero_rows, void* ws, int64_t ws_bytes, void* plan_buf,
@@ -2086,6 +2209,11 @@ int launch_forward_fast3(const DevShape& s, const CorePtrs& cores, const int64_t
   int rc = prepare(s, cores, false, indices, rowidx, offsets, nnz, nnz_dev, B, zero_rows ? output : nullptr, ws, ws_bytes,
                    plan_buf, plan_bytes, phase, &plan, st);   // phase 0 / 1 / 2 = whole forward / ids only / lookup on a grouped plan
   if (rc || phase == 1) return rc;
+  if (wide(s)) {
+#define TTEMB_X(a, b, c, d, e) if (shape_is(s, a, b, c, d, e)) return run_forward_wide<a, b, c, d, e>(s, cores, plan, nnz, B, output, st);
+    TTEMB_WIDE3_SHAPES(TTEMB_X)
+#undef TTEMB_X
+  }
   if (classify(s)) {
 #define TTEMB_X(a, b, c, d, e) if (shape_is(s, a, b, c, d, e)) return run_forward<a, b, c, d, e>(s, cores, plan, nnz, B, output, st);
     TTEMB_FAST3_SHAPES(TTEMB_X)
@@ -2137,10 +2265,10 @@ static int run_backward(const DevShape& s, const CorePtrs& cores, const GroupPla
     rc = launch_zero(plan.g2part, (size_t)s.p[2] * C::ROW2 * 4, st, "zero the shared dG2 slab");
     if (rc) return rc;
     hipLaunchKernelGGL((fast3_dg2_reduce_kernel<C::ROW2, kRowsB, NWB, true>), dim3((unsigned)tiles), dim3(NWB * 64), reduce_lds, st,
-                       plan, (int)G, (uint32_t)s.p[2], (uint32_t)reduce_rows(nnz));
+                       plan, (int)G, (uint32_t)s.p[2], (uint32_t)reduce_rows(nnz), (uint32_t)C::ROW2);
   } else {
     hipLaunchKernelGGL((fast3_dg2_reduce_kernel<C::ROW2, kRowsB, NWB, false>), dim3((unsigned)tiles), dim3(NWB * 64), reduce_lds, st,
-                       plan, (int)G, (uint32_t)s.p[2], (uint32_t)reduce_rows(nnz));
+                       plan, (int)G, (uint32_t)s.p[2], (uint32_t)reduce_rows(nnz), (uint32_t)C::ROW2);
   }
   rc = check_hip(hipGetLastError(), "fast3_dg2_reduce_kernel");
   if (rc) return rc;
@@ -2153,7 +2281,7 @@ static int run_backward(const DevShape& s, const CorePtrs& cores, const GroupPla
     const int g2_floats = s.p[2] * C::ROW2, g1_floats = s.p[1] * C::ROW1;
     const int wgs = (g2_floats + s.p[0] * C::ROW0 + 31) / 32 + (g1_floats + 255) / 256;   // dG2 | dG0, then dG1
     hipLaunchKernelGGL(fast3_finalize_kernel, dim3((unsigned)wgs), dim3(256), 0, st, plan, (int)slab_count(s, nnz), slices,
-                       s.p[0], s.p[1], g2_floats, (int)C::ROW0, g1_floats, Q2, R2, d_cores.c[0], d_cores.c[1], d_cores.c[2], upd);
+                       s.p[0], s.p[1], g2_floats, (int)C::ROW0, g1_floats, Q2, R2, d_cores.c[0], d_cores.c[1], d_cores.c[2], upd, 0);
   }
   profile_end(1, st);
   return check_hip(hipGetLastError(), "fast3_finalize_kernel");
@@ -2178,6 +2306,11 @@ int launch_backward_fast3(const DevShape& s, const CorePtrs& cores, const int64_
                    const_cast<void*>(plan_buf), plan_bytes,
                    plan_buf != nullptr && plan_bytes >= fast3_plan_bytes(s, nnz) ? 3 : 0, &plan, st);
   if (rc) return rc;
+  if (wide(s)) {
+#define TTEMB_X(a, b, c, d, e) if (shape_is(s, a, b, c, d, e)) return run_backward_wide<a, b, c, d, e>(s, cores, plan, nnz, B, d_output, d_cores, upd, st);
+    TTEMB_WIDE3_SHAPES(TTEMB_X)
+#undef TTEMB_X
+  }
   if (classify(s)) {
 #define TTEMB_X(a, b, c, d, e) if (shape_is(s, a, b, c, d, e)) return run_backward<a, b, c, d, e>(s, cores, plan, nnz, B, d_output, d_cores, upd, st);
     TTEMB_FAST3_SHAPES(TTEMB_X)

@@ -490,6 +490,60 @@ def test_random_tables_fast_path(nat, orc, shape, seed):
     assert_grads_close(grads, orc.tt_dense_backward(idx, offsets, d_out, cores, p, q, R), rel=2e-4)
 
 
+# the wide-rank chain (ttemb_wide3.inc): the upper half of the reference's rank sweep on the grouped path
+WIDE3_SHAPES = [(5, 5, 4, 64, 64), (5, 5, 4, 128, 128), (5, 5, 4, 256, 256), (4, 4, 8, 64, 64), (4, 4, 8, 128, 128), (4, 4, 8, 256, 256)]
+
+
+@pytest.mark.parametrize("shape", WIDE3_SHAPES)
+@pytest.mark.parametrize("seed", [0, 1])
+def test_random_tables_wide_rank_chain(nat, orc, shape, seed):
+    """Ranks 64 / 128 / 256 forced onto the grouped path (GEMM prefix, per-chunk forward, per-group backward, E reduce
+    by column slices, dG1 / dG0 GEMMs): random table factorisations incl. p0 q0 that is no multiple of 64, empty
+    groups, bags of several ids, repeated ids."""
+    q, R = list(shape[:3]), [1, shape[3], shape[4], 1]
+    rng = np.random.default_rng(1234 * seed + sum(shape))
+    p = [int(rng.integers(1, 30)), int(rng.integers(1, 12)), int(rng.integers(1, 90))]
+    cores = [(rng.standard_normal((p[t], R[t] * q[t] * R[t + 1])) * (0.3 if t != 1 else 0.05)).astype(np.float32) for t in range(3)]
+    idx, offsets = _random_bags(rng, int(np.prod(p)), int(rng.integers(300, 4000)))
+    nat.set_path(nat.PATH_FAST3)
+    try:
+        out, _ = run_forward(nat, p, q, R, cores, idx, offsets)
+        want = orc.tt_forward(idx, offsets, cores, p, q, R)
+        np.testing.assert_allclose(out, want, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(want).max())))
+        d_out = ((rng.random(want.shape) - 0.5) * 0.2).astype(np.float32)
+        grads = run_backward_dense(nat, p, q, R, cores, idx, offsets, d_out)
+        assert_grads_close(grads, orc.tt_dense_backward(idx, offsets, d_out, cores, p, q, R), rel=2e-4)
+    finally:
+        nat.set_path(nat.PATH_AUTO)
+
+
+@pytest.mark.parametrize("name", [n for n in RANK_CASES if any(f"r{r}" in n for r in (64, 128, 256))])
+def test_rank_sweep_golden_on_the_wide_rank_chain(nat, name):
+    """The rank 64 / 128 / 256 points of the reference's rank sweep, forced onto the grouped wide-rank chain, against the
+    vectors from the reference's tt_matrix_to_full + autograd."""
+    g = load_golden(name)
+    cores = rank_case_cores(g)
+    p, q, R = [int(x) for x in g["p"]], [int(x) for x in g["q"]], [int(x) for x in g["R"]]
+    nat.set_path(nat.PATH_FAST3)
+    try:
+        shp, ws = nat.make_shape(p, q, R), nat.Workspace()
+        c = [dev(x) for x in cores]
+        di, do = dev(g["indices"], torch.int64), dev(g["offsets"], torch.int64)
+        B, nnz = do.numel() - 1, di.numel()
+        out = torch.full((B, int(np.prod(q))), float("nan"), device="cuda")
+        nat.forward(shp, c, di, None, do, nnz, None, B, out, ws)
+        np.testing.assert_allclose(out.cpu().numpy(), g["out"], rtol=1e-4, atol=1e-4)
+        grads = [torch.full_like(x, float("nan")) for x in c]
+        nat.backward_dense(shp, c, di, None, nnz, None, B, dev(g["d_output"]), grads, ws, None, do)
+        torch.cuda.synchronize()
+        got = [x.cpu().numpy() for x in grads]
+        assert_grads_close([got[0], got[2]], [g["grad0"], g["grad2"]], rel=2e-4)
+        err = float(np.abs(got[1].reshape(-1)[::61] - g["grad1_every61"]).max())
+        assert err <= 2e-4 * float(g["grad1_absmax"]) + 1e-6, f"core 1: {err:.3e}"
+    finally:
+        nat.set_path(nat.PATH_AUTO)
+
+
 @pytest.mark.parametrize("p,q,R,n_ids,path", [
     ([10, 12, 30, 40], [2, 4, 4, 4], [1, 16, 16, 16, 1], 30000, "fast3"),   # run scripts: q = 2,4,4,4 -> (8, 4, 4) at rank 16
     ([50, 60, 60, 60], [2, 4, 4, 4], [1, 16, 16, 16, 1], 60000, "auto"),    # the scripts' own table (10.8 M rows)
