@@ -97,7 +97,7 @@ static int64_t grad_scratch_bytes(const DevShape& s) {
 
 static bool use_fast3(const DevShape& s, int64_t nnz, int64_t B) {
   const int path = current_path();
-  if (path == TTEMB_PATH_GENERIC || !fast3_supported(s)) return false;
+  if (path == TTEMB_PATH_GENERIC || path == TTEMB_PATH_PER_BAG || !fast3_supported(s)) return false;
   if (!fast3_fits(s, nnz, B)) return false;  // the fast kernels address their tables with 32-bit byte offsets
   return path == TTEMB_PATH_FAST3 || fast3_pays(s, nnz);
 }
@@ -105,7 +105,8 @@ static bool use_fast3(const DevShape& s, int64_t nnz, int64_t B) {
 // small batches of an instantiated 3-core shape whose ids come with their bag boundaries: one wavefront per bag, MFMA per
 // id (ttemb_small3.inc) instead of the wave-per-id scalar kernels
 static bool use_small3(const DevShape& s, int64_t nnz, int64_t B, const int64_t* rowidx, const int64_t* offsets) {
-  return current_path() == TTEMB_PATH_AUTO && rowidx == nullptr && offsets != nullptr && small3_supported(s) &&
+  const int path = current_path();
+  return (path == TTEMB_PATH_AUTO || path == TTEMB_PATH_PER_BAG) && rowidx == nullptr && offsets != nullptr && small3_supported(s) &&
          !use_fast3(s, nnz, B);
 }
 
@@ -525,7 +526,7 @@ int ttemb_abi_version(void) { return TTEMB_ABI_VERSION; }
 const char* ttemb_last_error(void) { return g_err; }
 
 int ttemb_set_path(int32_t path) {
-  if (path < TTEMB_PATH_AUTO || path > TTEMB_PATH_FAST3) return fail(TTEMB_E_BADARG, "unknown path %d", path);
+  if (path < TTEMB_PATH_AUTO || path > TTEMB_PATH_PER_BAG) return fail(TTEMB_E_BADARG, "unknown path %d", path);
   g_path.store(path);
   return TTEMB_OK;
 }

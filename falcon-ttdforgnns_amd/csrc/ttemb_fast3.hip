@@ -1786,6 +1786,14 @@ static int sort_ranges(int64_t G) { const int sh = sort_shift(G); return (int)((
 // 101 vs 197 us for the grouped path vs the wave-per-id kernels; the grouped path's fixed cost grows with the number
 // of groups (epilogue / finalize walk all of them)
 bool fast3_pays(const DevShape& s, int64_t nnz) {
+  if (wide(s)) {
+    // wide-rank chain against the per-bag kernels (tools/crossover.py on the products table, 17 500 groups, forward + dense
+    // backward): rank 64 crosses near 3 000 ids (278 vs 418 us at 4 096), rank 128 near 700 (611 vs 744 us at 1 024), rank 256
+    // near 500 (1.96 vs 3.6 ms at 1 024).  The grouped side is almost all fixed cost -- GEMMs over every group -- so the
+    // crossover scales with the number of groups; the per-bag side grows with rank^2.6 per id
+    const int64_t k = s.R[2] < 128 ? 6 : (s.R[2] < 256 ? 24 : 34);
+    return nnz >= 256 && nnz * k >= num_groups(s);
+  }
   const int64_t by_groups = num_groups(s) / 4;
   return nnz >= (by_groups > 4096 ? by_groups : 4096);
 }
@@ -1893,8 +1901,16 @@ static int epi_groups_per_wave(const DevShape& s) {
   int gpw = (s.p[0] + kEpiSlices - 1) / kEpiSlices;
   return gpw < 1 ? 1 : (gpw > 64 ? 64 : gpw);
 }
-static int epi_slices(const DevShape& s) {   // (the wide-rank chain forms dG1[i1] whole: one slab)
-  if (wide(s)) return 1;
+// wide-rank chain: dG1[i1] = G0^T . dP[i1] has (r1 / 64)(q1 r2 / 64) p1 tiles of K = p0 q0; K is split until ~4 tiles per SIMD exist
+static int wide_k_chunk(const DevShape& s) {
+  const int64_t tiles = (int64_t)(s.R[1] / 64) * (s.q[1] * s.R[2] / 64) * s.p[1];
+  int64_t parts = (4096 + tiles - 1) / tiles;
+  parts = parts < 1 ? 1 : (parts > 8 ? 8 : parts);
+  const int64_t K = (int64_t)s.p[0] * s.q[0];
+  return (int)(((K + parts - 1) / parts + 31) / 32 * 32);
+}
+static int epi_slices(const DevShape& s) {   // (the wide-rank chain: one dG1 slab per K part)
+  if (wide(s)) return (int)(((int64_t)s.p[0] * s.q[0] + wide_k_chunk(s) - 1) / wide_k_chunk(s));
   const int g = epi_groups_per_wave(s);
   return (s.p[0] + g - 1) / g;
 }
@@ -2062,9 +2078,11 @@ static int run_prefix_t(const DevShape& s, const CorePtrs& cores, const GroupPla
 
 // ---- wide-rank chain: launches ----
 template <bool A_KC, bool B_KC>
-static int run_wide_gemm(const WideGemm& g, uint32_t batches, hipStream_t st, const char* what) {
+static int run_wide_gemm(WideGemm g, uint32_t batches, hipStream_t st, const char* what, uint32_t k_chunk = 0, uint32_t c_slice = 0) {
   const uint32_t units = g.tiles_m * g.tiles_n;
-  hipLaunchKernelGGL((wide3_gemm_kernel<A_KC, B_KC>), dim3((units + 3) / 4, batches), dim3(256), 0, st, g);
+  g.k_chunk = k_chunk ? k_chunk : (g.K + 31u) / 32u * 32u;
+  g.c_slice = c_slice;
+  hipLaunchKernelGGL((wide3_gemm_kernel<A_KC, B_KC>), dim3((units + 3) / 4, batches, (g.K + g.k_chunk - 1) / g.k_chunk), dim3(256), 0, st, g);
   return check_hip(hipGetLastError(), what);
 }
 
@@ -2176,7 +2194,8 @@ static int run_backward_wide(const DevShape& s, const CorePtrs& cores, const Gro
     g.a_batch = 0; g.b_batch = M * N1; g.c_batch = (uint32_t)C::ROW1;
     g.a_bytes = M * R1 * 4; g.b_bytes = M * N1 * 4; g.c_bytes = (uint32_t)C::ROW1 * 4;
     g.tiles_m = R1 / 64; g.tiles_n = N1 / 64;
-    rc = run_wide_gemm<false, false>(g, (uint32_t)s.p[1], st, "wide3_gemm_kernel (dG1)");
+    rc = run_wide_gemm<false, false>(g, (uint32_t)s.p[1], st, "wide3_gemm_kernel (dG1)", (uint32_t)wide_k_chunk(s),
+                                     (uint32_t)s.p[1] * (uint32_t)C::ROW1);
     if (rc) return rc;
   }
   {  // dG0 parts of i1 (p0 q0 x r1) = dP[i1] (p0 q0 x q1 r2) . G1[i1]^T (q1 r2 x r1); the finalize kernel sums over i1
@@ -2193,7 +2212,7 @@ static int run_backward_wide(const DevShape& s, const CorePtrs& cores, const Gro
   {
     const int g2_floats = s.p[2] * C::ROW2, g1_floats = s.p[1] * C::ROW1;
     const int wgs = (g2_floats + s.p[0] * C::ROW0 + 31) / 32 + (g1_floats + 255) / 256;
-    hipLaunchKernelGGL(fast3_finalize_kernel, dim3((unsigned)wgs), dim3(256), 0, st, plan, (int)slab_count(s, nnz), 1, s.p[0], s.p[1],
+    hipLaunchKernelGGL(fast3_finalize_kernel, dim3((unsigned)wgs), dim3(256), 0, st, plan, (int)slab_count(s, nnz), epi_slices(s), s.p[0], s.p[1],
                        g2_floats, (int)C::ROW0, g1_floats, Q2, R2, d_cores.c[0], d_cores.c[1], d_cores.c[2], upd, 1);
   }
   profile_end(1, st);

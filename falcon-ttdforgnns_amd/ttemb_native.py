@@ -22,7 +22,7 @@ LIB_PATH = os.environ.get("TTEMB_LIB") or os.path.join(_HERE, "lib", "libttemb_h
 
 MAX_CORES = 4
 OP_FORWARD, OP_BACKWARD, OP_PREPROCESS, OP_CACHE_POPULATE = 0, 1, 2, 3
-PATH_AUTO, PATH_GENERIC, PATH_FAST3 = 0, 1, 2
+PATH_AUTO, PATH_GENERIC, PATH_FAST3, PATH_PER_BAG = 0, 1, 2, 3
 
 # every symbol include/ttemb.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = (

@@ -65,7 +65,9 @@ enum {
   TTEMB_PATH_AUTO = 0,          /* fast path when the shape supports it and the batch has at
                                    least max(4096, p0*p1/4) ids (measured crossover), else generic */
   TTEMB_PATH_GENERIC = 1,       /* shape-generic wave-per-id kernels (T = 2..4)    */
-  TTEMB_PATH_FAST3 = 2          /* sorted / grouped MFMA path, T == 3 only         */
+  TTEMB_PATH_FAST3 = 2,         /* sorted / grouped MFMA path, T == 3 only         */
+  TTEMB_PATH_PER_BAG = 3        /* one wavefront per bag (MFMA per id) whenever the shape has it and the ids come
+                                   with their offsets, at every batch size; else generic.  For crossover measurements */
 };
 
 int ttemb_abi_version(void);
