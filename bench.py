@@ -60,10 +60,16 @@ SHAPES = {   # name -> (p, q, ranks, num_embeddings)
 }
 
 
+# the reference's rank sweep (run_script.sh:250-288): the products table with q = 5,5,4 at ranks 8 ... 256 and q = 4,4,8 at
+# 64 ... 256 -- ranks up to 32 run on the register-resident grouped chain, 64 and up on the wide-rank one (GEMM prefix,
+# per-group backward, GEMM dG1 / dG0)
+RANK_SWEEP = [([5, 5, 4], r) for r in (8, 16, 32, 64, 128, 256)] + [([4, 4, 8], r) for r in (64, 128, 256)]
+
+
 def matrix_leg(nat, name, n_ids, dist_kind, iters=50):
     """One row of the §8d matrix at the C-ABI level (cores resident, buffers reused): forward only, dense backward,
     fused-SGD backward and forward + fused backward, median of `iters` HIP-event timings on the compute stream."""
-    p, q, ranks, n_emb = SHAPES[name]
+    p, q, ranks, n_emb = SHAPES[name] if isinstance(name, str) else name
     R = [1] + ranks + [1]
     D = int(np.prod(q))
     rng = np.random.default_rng(5)
@@ -411,6 +417,13 @@ def main():
                       "papers100M_r32_4096": matrix_leg(nat, "papers100M_r32", 4096, "uniform"),
                       "arxiv_r8_full_graph": matrix_leg(nat, "arxiv_r8", 169343, "arange"),
                       "arxiv_r8_256": matrix_leg(nat, "arxiv_r8", 256, "uniform")}
+        sweep = None
+        if world == 1 and not args.no_extras:
+            sweep = {"how": "products table (p = 125,140,140), 409600 unique uniform ids, C-ABI calls as in `matrix`, median of 10"}
+            for qs, r in RANK_SWEEP:
+                sweep["q%s_r%d" % ("".join(str(x) for x in qs), r)] = matrix_leg(
+                    nat, (SHAPES["products_r16"][0], qs, [r, r], N_EMB), 409600, "uniform", iters=10)
+                torch.cuda.empty_cache()
         result = {
             "metric": "tt_embedding_lookups_per_sec", "value": round(value, 1), "unit": "lookups/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -420,7 +433,7 @@ def main():
                                    "2048-seed batch = 409600 unique uniform ids per GPU, bag length 1",
                        "p": P, "q": Q, "tt_ranks": RANKS, "num_embeddings": N_EMB, "ids_per_gpu_step": N,
                        "parallelism": f"dp{world}", "kernel_path": args.path},
-            "dist": dist_info, "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_2048": cpu2048, "matrix": matrix, "batch2048_step": small, "metis_like_step": local,
+            "dist": dist_info, "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_2048": cpu2048, "matrix": matrix, "rank_sweep": sweep, "batch2048_step": small, "metis_like_step": local,
             "cache_on_step": cached, "sage_epoch": epoch,
         }
     if world > 1:

@@ -111,6 +111,42 @@ def test_four_core_module_trains_on_the_grouped_path(ops, q, r):
         torch.testing.assert_close(c.detach(), want, rtol=1e-3, atol=2e-4)
 
 
+@pytest.mark.parametrize("q,r", [([5, 5, 4], [64, 64]), ([4, 4, 8], [128, 128])])
+@pytest.mark.parametrize("mode", ["dense", "SGD", "EXACT_ADAGRAD"])
+def test_wide_rank_module_on_the_grouped_chain(ops, q, r, mode):
+    """Rank 64 / 128 tables through the module: batches of >= 256 ids take the wide-rank grouped chain (GEMM prefix,
+    per-group backward, GEMM dG1 / dG0, optimiser step in the finalize kernel); checked against autograd through
+    tt_matrix_to_full."""
+    torch.manual_seed(11)
+    p = [6, 7, 9]
+    n, D = int(np.prod(p)), int(np.prod(q))
+    lr, eps = 0.05, 1e-10
+    kw = {} if mode == "dense" else {"optimizer": getattr(ops.OptimType, mode), "learning_rate": lr, "eps": eps}
+    emb = ops.TTEmbeddingBag(n, D, r, p, q, sparse=(mode != "dense"), use_cache=False, weight_dist="uniform", **kw)
+    before = [c.detach().clone() for c in emb.tt_cores]
+    clones = [c.detach().clone().requires_grad_(True) for c in emb.tt_cores]
+    idx, offs = ragged(np.random.default_rng(5), 400, n, 3.0)
+    assert idx.numel() >= 256
+    out = emb(idx, offs)
+    want = reference_bag(ops.tt_matrix_to_full(p, q, r, clones, [1, 0, 2, 3]), idx, offs)
+    torch.testing.assert_close(out, want, rtol=1e-4, atol=1e-4 * float(want.detach().abs().max()))
+    d_out = torch.rand_like(out) * 0.1
+    out.backward(d_out)
+    want.backward(d_out)
+    for t, (c, b, ref) in enumerate(zip(emb.tt_cores, before, clones)):
+        tol = 2e-4 * float(ref.grad.abs().max())
+        if mode == "dense":
+            torch.testing.assert_close(c.grad, ref.grad, rtol=1e-3, atol=tol)
+        elif mode == "SGD":
+            assert c.grad is None
+            torch.testing.assert_close(c.data, b - lr * ref.grad, rtol=0, atol=lr * tol + 1e-6)
+        else:
+            st = emb.optimizer_state[t]
+            torch.testing.assert_close(st, ref.grad ** 2, rtol=2e-3, atol=1e-4 * float((ref.grad ** 2).max()))
+            big = ref.grad.abs() > 1e-2 * ref.grad.abs().max()
+            torch.testing.assert_close(c.data[big], (b - lr * ref.grad / (ref.grad.abs() + eps))[big], rtol=0, atol=1e-4)
+
+
 @pytest.mark.parametrize("optimizer", ["SGD", "EXACT_ADAGRAD"])
 def test_sparse_mode_updates_in_backward(ops, optimizer):
     torch.manual_seed(3)
