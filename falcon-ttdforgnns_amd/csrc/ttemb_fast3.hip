@@ -2131,9 +2131,16 @@ static int run_place_prefix(const DevShape& s, const CorePtrs& cores, const Grou
 }
 
 template <int Q0, int Q1, int Q2, int R1, int R2>
+static int run_forward_direct(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int64_t nnz, int64_t B,
+                              float* output, hipStream_t st);
+
+template <int Q0, int Q1, int Q2, int R1, int R2>
 static int run_forward(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int64_t nnz, int64_t B,
                        float* output, hipStream_t st) {
   using C = Cfg<Q0, Q1, Q2, R1, R2>;
+#ifdef TTEMB_FWD_DIRECT   // experiment: the LDS-free forward of the wide ranks on a narrow-rank shape (slower there, see ttemb_wide3.inc)
+  if constexpr (DirectCfg<Q0, Q1, Q2, R1, R2>::ok) return run_forward_direct<Q0, Q1, Q2, R1, R2>(s, cores, plan, nnz, B, output, st);
+#endif
   const size_t lds = (size_t)kChainWaves * C::WAVE_FLOATS * sizeof(float);
   static bool lds_ok = false;
   unsigned grid = 0;
@@ -2147,14 +2154,14 @@ static int run_forward(const DevShape& s, const CorePtrs& cores, const GroupPlan
 }
 
 template <int Q0, int Q1, int Q2, int R1, int R2>
-static int run_forward_wide(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int64_t nnz, int64_t B,
+static int run_forward_direct(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int64_t nnz, int64_t B,
                             float* output, hipStream_t st) {
   const uint32_t waves = (uint32_t)max_chunks(s, nnz);   // the chunk count is known on the device only: surplus wavefronts leave at once
   profile_begin(0, st);
-  hipLaunchKernelGGL((wide3_forward_kernel<Q0, Q1, Q2, R1, R2>), dim3((waves + 3) / 4), dim3(256), 0, st, cores.c[2], plan,
+  hipLaunchKernelGGL((direct_forward_kernel<Q0, Q1, Q2, R1, R2>), dim3((waves + 3) / 4), dim3(256), 0, st, cores.c[2], plan,
                      (uint32_t)num_groups(s), (uint32_t)s.p[2], output, (uint32_t)(B * s.D * 4));
   profile_end(0, st);
-  return check_hip(hipGetLastError(), "wide3_forward_kernel");
+  return check_hip(hipGetLastError(), "direct_forward_kernel");
 }
 
 // backward of the wide-rank chain: per-group products, the E reduce (a column slice of 256 floats per launch row),
@@ -2229,7 +2236,7 @@ int launch_forward_fast3(const DevShape& s, const CorePtrs& cores, const int64_t
                    plan_buf, plan_bytes, phase, &plan, st);   // phase 0 / 1 / 2 = whole forward / ids only / lookup on a grouped plan
   if (rc || phase == 1) return rc;
   if (wide(s)) {
-#define TTEMB_X(a, b, c, d, e) if (shape_is(s, a, b, c, d, e)) return run_forward_wide<a, b, c, d, e>(s, cores, plan, nnz, B, output, st);
+#define TTEMB_X(a, b, c, d, e) if (shape_is(s, a, b, c, d, e)) return run_forward_direct<a, b, c, d, e>(s, cores, plan, nnz, B, output, st);
     TTEMB_WIDE3_SHAPES(TTEMB_X)
 #undef TTEMB_X
   }
