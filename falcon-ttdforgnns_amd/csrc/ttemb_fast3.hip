@@ -183,6 +183,8 @@ struct GroupPlan {           // device pointers into the caller's plan buffer / 
   float* g0part;             // [G][ROW0] per-group contribution to dG0
   float* g1part;             // [slices][p1][ROW1] per-slice partial dG1
   uint32_t* epi_live;        // [slices][p1] sparse form only: 1 when the slice of that i1 holds an id (its slab exists)
+  uint32_t* wrows;           // wide-rank chain: [p1][stride] the rows (i0, a) of every i1 whose group holds an id (wide3_rows_kernel)
+  uint32_t* wnrows;          // [p1] their number
 };
 
 __device__ __forceinline__ uint64_t pack_count(uint32_t c) {   // ids in the low word, chunks of <= kChunk ids in the high word
@@ -1636,7 +1638,10 @@ __global__ __launch_bounds__(256) void fast3_finalize_kernel(GroupPlan plan, int
   __shared__ float part[8][33];
   const int x = threadIdx.x & 31, y = threadIdx.x >> 5;
   const int n0 = p0 * row0;
-  const bool sparse = !all_parts && sparse_groups(plan, (uint32_t)(p0 * p1));   // the form the epilogue kernel took (the wide-rank chain writes every part)
+  // the form the epilogue kernel took; the wide-rank chain (all_parts) writes every dG1 slab and the dG0 parts of the non-empty groups
+  const bool sparse_any = sparse_groups(plan, (uint32_t)(p0 * p1));
+  const bool sparse = all_parts ? true : sparse_any;          // dG0 parts: skip the groups without ids by their counts
+  const bool sparse_g1 = all_parts ? false : sparse_any;      // dG1 slabs: skip the slices without ids by their flags
   // dG1 has few terms per output (one per slice): one thread per output, 256 outputs per workgroup, the workgroups
   // after those of dG2 / dG0 (eight threads per output as below made 8x the workgroups for the largest of the cores)
   const int wg_a = (g2_floats + n0 + 31) / 32;
@@ -1650,7 +1655,7 @@ __global__ __launch_bounds__(256) void fast3_finalize_kernel(GroupPlan plan, int
       float v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u)   // slices without ids wrote nothing (sparse form)
-        on[u] = t + u < slices && (!sparse || plan.epi_live[(size_t)(t + u) * p1 + i1] != 0u);
+        on[u] = t + u < slices && (!sparse_g1 || plan.epi_live[(size_t)(t + u) * p1 + i1] != 0u);
 #pragma unroll
       for (int u = 0; u < 8; ++u) v[u] = on[u] ? plan.g1part[(size_t)(t + u) * g1_floats + o] : 0.f;
       tot += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
@@ -1787,12 +1792,13 @@ static int sort_ranges(int64_t G) { const int sh = sort_shift(G); return (int)((
 // of groups (epilogue / finalize walk all of them)
 bool fast3_pays(const DevShape& s, int64_t nnz) {
   if (wide(s)) {
-    // wide-rank chain against the per-bag kernels (tools/crossover.py on the products table, 17 500 groups, forward + dense
-    // backward): rank 64 crosses near 3 000 ids (278 vs 418 us at 4 096), rank 128 near 700 (611 vs 744 us at 1 024), rank 256
-    // near 500 (1.96 vs 3.6 ms at 1 024).  The grouped side is almost all fixed cost -- GEMMs over every group -- so the
-    // crossover scales with the number of groups; the per-bag side grows with rank^2.6 per id
-    const int64_t k = s.R[2] < 128 ? 6 : (s.R[2] < 256 ? 24 : 34);
-    return nnz >= 256 && nnz * k >= num_groups(s);
+    // wide-rank chain against the per-bag kernels (tools/crossover.py --paths per_bag fast3 on the products table, 17 500
+    // groups, forward + dense backward; profiles/r02_wide_crossover.txt): rank 64 crosses at 1 300 (q = 5,5,4) / 2 700 ids
+    // (q = 4,4,8), rank 128 below 128 / near 800, rank 256 never (32 ids: 0.52 against 1.37 ms -- at that rank the per-bag
+    // backward's zero-fill and atomics on the 183 MB of dG1 cost more than the whole grouped chain).  The grouped side's
+    // cost follows the number of non-empty groups (compacted GEMMs), its floor the size of the cores it has to write
+    if (s.R[2] >= 256) return nnz >= 1;
+    return nnz * (s.R[2] >= 128 ? 24 : 8) >= num_groups(s);
   }
   const int64_t by_groups = num_groups(s) / 4;
   return nnz >= (by_groups > 4096 ? by_groups : 4096);
@@ -1909,6 +1915,7 @@ static int wide_k_chunk(const DevShape& s) {
   const int64_t K = (int64_t)s.p[0] * s.q[0];
   return (int)(((K + parts - 1) / parts + 31) / 32 * 32);
 }
+static int64_t wide_rows_stride(const DevShape& s) { return ((int64_t)s.p[0] * s.q[0] + 63) / 64 * 64 + 64; }
 static int epi_slices(const DevShape& s) {   // (the wide-rank chain: one dG1 slab per K part)
   if (wide(s)) return (int)(((int64_t)s.p[0] * s.q[0] + wide_k_chunk(s) - 1) / wide_k_chunk(s));
   const int g = epi_groups_per_wave(s);
@@ -1979,6 +1986,14 @@ static int64_t carve_workspace(const DevShape& s, int64_t nnz, bool bwd, bool pl
       pl->rcount = rc;
       pl->lpre = lp;
       pl->rtot = rt;
+    }
+  }
+  if (wide(s)) {   // the lists of non-empty rows the compacted GEMMs walk (rebuilt from the plan's counts by every call)
+    uint32_t* wr = (uint32_t*)take((int64_t)s.p[1] * wide_rows_stride(s) * 4);
+    uint32_t* wn = (uint32_t*)take((int64_t)s.p[1] * 4);
+    if (pl) {
+      pl->wrows = wr;
+      pl->wnrows = wn;
     }
   }
   if (bwd) {
@@ -2077,17 +2092,30 @@ static int run_prefix_t(const DevShape& s, const CorePtrs& cores, const GroupPla
 }
 
 // ---- wide-rank chain: launches ----
-template <bool A_KC, bool B_KC>
-static int run_wide_gemm(WideGemm g, uint32_t batches, hipStream_t st, const char* what, uint32_t k_chunk = 0, uint32_t c_slice = 0) {
+template <bool A_KC, bool B_KC, int COMPACT>
+static int run_wide_gemm(WideGemm g, const DevShape& s, const GroupPlan& plan, hipStream_t st, const char* what, uint32_t k_chunk = 0,
+                         uint32_t c_slice = 0) {
   const uint32_t units = g.tiles_m * g.tiles_n;
   g.k_chunk = k_chunk ? k_chunk : (g.K + 31u) / 32u * 32u;
   g.c_slice = c_slice;
-  hipLaunchKernelGGL((wide3_gemm_kernel<A_KC, B_KC>), dim3((units + 3) / 4, batches, (g.K + g.k_chunk - 1) / g.k_chunk), dim3(256), 0, st, g);
+  g.rows = plan.wrows;
+  g.n_rows = plan.wnrows;
+  g.rows_stride = (uint32_t)wide_rows_stride(s);
+  hipLaunchKernelGGL((wide3_gemm_kernel<A_KC, B_KC, COMPACT>), dim3((units + 3) / 4, (unsigned)s.p[1], (g.K + g.k_chunk - 1) / g.k_chunk),
+                     dim3(256), 0, st, g);
   return check_hip(hipGetLastError(), what);
 }
 
-// P[i1] (p0 q0 x q1 r2) = G0 (p0 q0 x r1) . G1[i1] (r1 x q1 r2), every group
+static int run_wide_rows(const DevShape& s, const GroupPlan& plan, hipStream_t st) {
+  hipLaunchKernelGGL(wide3_rows_kernel, dim3((unsigned)s.p[1]), dim3(256), 0, st, plan, (uint32_t)s.p[0], (uint32_t)s.q[0],
+                     (uint32_t)wide_rows_stride(s), plan.wrows, plan.wnrows);
+  return check_hip(hipGetLastError(), "wide3_rows_kernel");
+}
+
+// P[i1] (p0 q0 x q1 r2) = G0 (p0 q0 x r1) . G1[i1] (r1 x q1 r2), the rows of the groups that hold an id
 static int run_prefix_wide(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, hipStream_t st) {
+  int rc = run_wide_rows(s, plan, st);
+  if (rc) return rc;
   const uint32_t M = (uint32_t)(s.p[0] * s.q[0]), N = (uint32_t)(s.q[1] * s.R[2]), K = (uint32_t)s.R[1];
   WideGemm g;
   g.A = cores.c[0]; g.B = cores.c[1]; g.C = plan.ptab;
@@ -2096,7 +2124,7 @@ static int run_prefix_wide(const DevShape& s, const CorePtrs& cores, const Group
   g.a_batch = 0; g.b_batch = K * N; g.c_batch = M * N;
   g.a_bytes = M * K * 4; g.b_bytes = K * N * 4; g.c_bytes = M * N * 4;
   g.tiles_m = (M + 63) / 64; g.tiles_n = N / 64;
-  return run_wide_gemm<true, false>(g, (uint32_t)s.p[1], st, "wide3_gemm_kernel (prefix)");
+  return run_wide_gemm<true, false, 1>(g, s, plan, st, "wide3_gemm_kernel (prefix)");
 }
 
 static int run_prefix(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, hipStream_t st) {
@@ -2172,11 +2200,13 @@ static int run_backward_wide(const DevShape& s, const CorePtrs& cores, const Gro
   using C = WideCfg<Q0, Q1, Q2, R1, R2>;
   const int64_t G = num_groups(s);
   profile_begin(1, st);
+  int rc = run_wide_rows(s, plan, st);   // (the workspace of this call; the forward's lists are not part of the plan)
+  if (rc) return rc;
   profile_begin(2, st);
   hipLaunchKernelGGL((wide3_bwd_chunk_kernel<Q0, Q1, Q2, R1, R2>), dim3((unsigned)((G * C::TS + 3) / 4)), dim3(256), 0, st, cores.c[2],
                      (uint32_t)G, (uint32_t)s.p[2], d_output, (uint32_t)(B * s.D * 4), plan);
   profile_end(2, st);
-  int rc = check_hip(hipGetLastError(), "wide3_bwd_chunk_kernel");
+  rc = check_hip(hipGetLastError(), "wide3_bwd_chunk_kernel");
   if (rc) return rc;
   static_assert(C::ROW2 % 256 == 0, "the E reduce takes 256 columns per launch row");
   const int tiles = (int)reduce_tiles(nnz);
@@ -2201,8 +2231,8 @@ static int run_backward_wide(const DevShape& s, const CorePtrs& cores, const Gro
     g.a_batch = 0; g.b_batch = M * N1; g.c_batch = (uint32_t)C::ROW1;
     g.a_bytes = M * R1 * 4; g.b_bytes = M * N1 * 4; g.c_bytes = (uint32_t)C::ROW1 * 4;
     g.tiles_m = R1 / 64; g.tiles_n = N1 / 64;
-    rc = run_wide_gemm<false, false>(g, (uint32_t)s.p[1], st, "wide3_gemm_kernel (dG1)", (uint32_t)wide_k_chunk(s),
-                                     (uint32_t)s.p[1] * (uint32_t)C::ROW1);
+    rc = run_wide_gemm<false, false, 2>(g, s, plan, st, "wide3_gemm_kernel (dG1)", (uint32_t)wide_k_chunk(s),
+                                        (uint32_t)s.p[1] * (uint32_t)C::ROW1);
     if (rc) return rc;
   }
   {  // dG0 parts of i1 (p0 q0 x r1) = dP[i1] (p0 q0 x q1 r2) . G1[i1]^T (q1 r2 x r1); the finalize kernel sums over i1
@@ -2213,7 +2243,7 @@ static int run_backward_wide(const DevShape& s, const CorePtrs& cores, const Gro
     g.a_batch = M * N1; g.b_batch = (uint32_t)C::ROW1; g.c_batch = M * R1;
     g.a_bytes = M * N1 * 4; g.b_bytes = (uint32_t)C::ROW1 * 4; g.c_bytes = M * R1 * 4;
     g.tiles_m = (M + 63) / 64; g.tiles_n = R1 / 64;
-    rc = run_wide_gemm<true, true>(g, (uint32_t)s.p[1], st, "wide3_gemm_kernel (dG0)");
+    rc = run_wide_gemm<true, true, 1>(g, s, plan, st, "wide3_gemm_kernel (dG0)");
     if (rc) return rc;
   }
   {
