@@ -2101,8 +2101,9 @@ static int run_wide_gemm(WideGemm g, const DevShape& s, const GroupPlan& plan, h
   g.rows = plan.wrows;
   g.n_rows = plan.wnrows;
   g.rows_stride = (uint32_t)wide_rows_stride(s);
-  hipLaunchKernelGGL((wide3_gemm_kernel<A_KC, B_KC, COMPACT>), dim3((units + 3) / 4, (unsigned)s.p[1], (g.K + g.k_chunk - 1) / g.k_chunk),
-                     dim3(256), 0, st, g);
+  g.full = (uint32_t)(s.p[0] * s.q[0]);
+  const dim3 grid((units + 3) / 4, (unsigned)s.p[1], (g.K + g.k_chunk - 1) / g.k_chunk);
+  hipLaunchKernelGGL((wide3_gemm_kernel<A_KC, B_KC, COMPACT>), grid, dim3(256), 0, st, g);
   return check_hip(hipGetLastError(), what);
 }
 

@@ -4,6 +4,7 @@
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 for c in "$@"; do
+  rm -rf $R/gpurun_out/prof_$c
   rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$c -- python3 $R/tools/kbench.py --cfg $c --iters 5 --no-rowidx > $R/gpurun_out/prof_$c.log 2>&1 || exit 1
   f=$(find $R/gpurun_out/prof_$c -name "*kernel_stats.csv" | head -1)
   echo "== $c"

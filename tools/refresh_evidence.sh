@@ -15,4 +15,6 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $O/bench_profiled.json 2> $O/bench_profiled.err || exit 1
 cp $O/prof/*/*kernel_stats.csv $O/bench_kernel_stats.csv
 cd $R && python3 bench.py > $O/bench_default.json 2> $O/bench_default.err || exit 1
+# per-kernel summaries of the wide-rank chain (ranks 64 / 256 of the rank sweep), uniform and METIS-like ids
+bash $R/tools/prof_cfg.sh q554_r64 q554_r256 q448_r256 < /dev/null 2>&1 | grep -E "^==|uniform|calls" > $O/wide_kernels.txt || exit 1
 cat $O/bench_default.json
