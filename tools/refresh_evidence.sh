@@ -17,4 +17,5 @@ cp $O/prof/*/*kernel_stats.csv $O/bench_kernel_stats.csv
 cd $R && python3 bench.py > $O/bench_default.json 2> $O/bench_default.err || exit 1
 # per-kernel summaries of the wide-rank chain (ranks 64 / 256 of the rank sweep), uniform and METIS-like ids
 bash $R/tools/prof_cfg.sh q554_r64 q554_r256 q448_r256 < /dev/null 2>&1 | grep -E "^==|uniform|calls" > $O/wide_kernels.txt || exit 1
+cd $R && for c in q554_r64 q554_r256; do python3 tools/kbench.py --cfg $c --iters 5 --no-rowidx --dist windows 2>/dev/null | tail -1 >> $O/wide_kernels.txt; done
 cat $O/bench_default.json
