@@ -43,6 +43,32 @@ def test_abi_argument_validation_without_gpu():
         nat.make_shape([3, 4], [2, 2, 2], [4])
 
 
+def test_workspace_and_plan_sizes_follow_the_kernel_family():
+    """Host-side sizing only (no kernel runs): which family a (shape, batch) gets shows in what it asks for."""
+    lib = nat.LIB
+    G, n = 125 * 140, 409600
+    wide = nat.make_shape([125, 140, 140], [5, 5, 4], [256, 256])
+    narrow = nat.make_shape([125, 140, 140], [5, 5, 4], [32, 32])
+    ws = lambda shp, op, nnz: lib.ttemb_workspace_bytes(ctypes.byref(shp), op, nnz, nnz)
+    # wide-rank chain: the backward keeps an E table of nnz * r2 q2 floats and a dP table of G * q0 q1 r2 floats
+    assert ws(wide, nat.OP_BACKWARD, n) >= n * 256 * 4 * 4 + G * 25 * 256 * 4
+    assert ws(wide, nat.OP_BACKWARD, n) < 6 * 2**30
+    assert ws(wide, nat.OP_FORWARD, n) < ws(wide, nat.OP_BACKWARD, n)
+    # the plan carries the prefix products of every group
+    assert lib.ttemb_plan_bytes(ctypes.byref(wide), n) >= G * 25 * 256 * 4
+    assert lib.ttemb_plan_bytes(ctypes.byref(narrow), n) >= G * 25 * 32 * 4
+    # rank 256 takes the grouped chain at every batch size, rank 64 only past its crossover (per-bag kernels: no plan)
+    assert lib.ttemb_plan_bytes(ctypes.byref(wide), 8) > 0
+    r64 = nat.make_shape([125, 140, 140], [5, 5, 4], [64, 64])
+    assert lib.ttemb_plan_bytes(ctypes.byref(r64), 256) == 0
+    assert lib.ttemb_plan_bytes(ctypes.byref(r64), 8192) > 0
+    # the per-bag family can be forced for crossover measurements, and only known families are accepted
+    assert lib.ttemb_set_path(nat.PATH_PER_BAG) == 0
+    assert lib.ttemb_plan_bytes(ctypes.byref(wide), n) == 0
+    assert lib.ttemb_set_path(nat.PATH_AUTO) == 0
+    assert lib.ttemb_set_path(4) == -1
+
+
 def test_suggested_shapes_match_reference_answers():
     t = load_golden("suggest_kat")["table"]
     for row in t.tolist():
