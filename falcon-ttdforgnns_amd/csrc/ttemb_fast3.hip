@@ -2102,7 +2102,9 @@ static int run_wide_gemm(WideGemm g, const DevShape& s, const GroupPlan& plan, h
   g.n_rows = plan.wnrows;
   g.rows_stride = (uint32_t)wide_rows_stride(s);
   g.full = (uint32_t)(s.p[0] * s.q[0]);
-  const dim3 grid((units + 3) / 4, (unsigned)s.p[1], (g.K + g.k_chunk - 1) / g.k_chunk);
+  g.batches = (uint32_t)s.p[1];
+  g.splits = (g.K + g.k_chunk - 1) / g.k_chunk;
+  const dim3 grid((((units + 3) / 4) * g.batches * g.splits + 7u) / 8u * 8u);   // 1-D, a multiple of the 8 XCDs
   hipLaunchKernelGGL((wide3_gemm_kernel<A_KC, B_KC, COMPACT>), grid, dim3(256), 0, st, g);
   return check_hip(hipGetLastError(), what);
 }
