@@ -1247,24 +1247,25 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
           for (int u = 0; u < kFuseBatch; ++u) en[u] = my_head[(q0 + u) * qstep];   // heads past p2 hold NIL for ever
 #pragma unroll
           for (int u = 0; u < kFuseBatch; ++u) my_head[(q0 + u) * qstep] = f_nil;   // (every lane of the group stores the same word)
-          // first row of every list: entries, then rows, in flight together
-          uint2 ent[kFuseBatch];
+          // The lists of the batch are walked TOGETHER, one entry of each per step: entries, then rows, in flight together; a
+          // list that has ended (or was empty) keeps visiting NIL and adds zeros.  The number of steps is the longest list of
+          // the batch (~3: 128 rows over ~140 values of i2) -- walking the tails list by list cost one dependent LDS round
+          // trip pair per extra entry of every list: 3 600 of the 9 700 cycles of an iteration.
+          for (;;) {
+            uint2 ent[kFuseBatch];
 #pragma unroll
-          for (int u = 0; u < kFuseBatch; ++u) ent[u] = *reinterpret_cast<const uint2*>(lds0 + en[u]);
-          f32x4 x[kFuseBatch];
+            for (int u = 0; u < kFuseBatch; ++u) ent[u] = *reinterpret_cast<const uint2*>(lds0 + en[u]);
+            f32x4 x[kFuseBatch];
 #pragma unroll
-          for (int u = 0; u < kFuseBatch; ++u) x[u] = *reinterpret_cast<const f32x4*>(rows + ent[u].x);
+            for (int u = 0; u < kFuseBatch; ++u) x[u] = *reinterpret_cast<const f32x4*>(rows + ent[u].x);
+            bool left = false;
 #pragma unroll
-          for (int u = 0; u < kFuseBatch; ++u) slab[q0 + u] += x[u];
-          // what is left of longer lists (128 rows over ~140 values of i2: a third of the rows share their i2 with another)
-#pragma unroll
-          for (int u = 0; u < kFuseBatch; ++u) {
-            uint32_t e = ent[u].y;
-            while (__ballot(e != f_nil) != 0ull) {
-              const uint2 e2 = *reinterpret_cast<const uint2*>(lds0 + e);
-              slab[q0 + u] += *reinterpret_cast<const f32x4*>(rows + e2.x);
-              e = e2.y;
+            for (int u = 0; u < kFuseBatch; ++u) {
+              slab[q0 + u] += x[u];
+              en[u] = ent[u].y;
+              left = left || en[u] != f_nil;
             }
+            if (__ballot(left) == 0ull) break;
           }
         }
       }
