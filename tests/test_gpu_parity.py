@@ -517,6 +517,41 @@ def test_random_tables_wide_rank_chain(nat, orc, shape, seed):
         nat.set_path(nat.PATH_AUTO)
 
 
+@pytest.mark.parametrize("shape", [(5, 5, 4, 64, 64), (4, 4, 8, 128, 128)])
+@pytest.mark.parametrize("kind", ["few_groups", "one_i1_full", "windows"])
+def test_wide_rank_chain_on_frontiers_that_leave_groups_empty(nat, orc, shape, kind):
+    """The wide-rank GEMMs walk the non-empty groups only: frontiers that touch a few (i0, i1) groups, that fill every
+    group of ONE i1 (that batch takes the plain form, the others the compacted one or nothing), and METIS-like windows of
+    consecutive ids; p0 q0 is no multiple of 64 and some values of i1 hold no id at all."""
+    q, R = list(shape[:3]), [1, shape[3], shape[4], 1]
+    p = [27, 9, 31]
+    rng = np.random.default_rng(9 + sum(shape))
+    cores = [(rng.standard_normal((p[t], R[t] * q[t] * R[t + 1])) * (0.3 if t != 1 else 0.05)).astype(np.float32) for t in range(3)]
+    n_emb, per_i0 = int(np.prod(p)), p[1] * p[2]
+    if kind == "few_groups":       # 11 groups out of 243, several ids each, some ids repeated
+        groups = rng.choice(p[0] * p[1], size=11, replace=False)
+        idx = (groups[rng.integers(0, 11, size=900)] // p[1]) * per_i0 + (groups[rng.integers(0, 11, size=900)] % p[1]) * p[2]
+        idx = idx + rng.integers(0, p[2], size=900)
+    elif kind == "one_i1_full":    # every i0 of i1 = 4 (a full batch), plus a handful of ids elsewhere
+        i0 = np.repeat(np.arange(p[0]), 12)
+        idx = np.concatenate([i0 * per_i0 + 4 * p[2] + rng.integers(0, p[2], size=i0.size), rng.integers(0, n_emb, size=40)])
+    else:                          # windows of consecutive ids
+        starts = rng.choice(n_emb - 64, size=20, replace=False)
+        idx = (starts[:, None] + np.arange(48)[None, :]).reshape(-1)
+    idx = idx.astype(np.int64)
+    offsets = np.arange(idx.size + 1, dtype=np.int64)
+    nat.set_path(nat.PATH_FAST3)
+    try:
+        out, _ = run_forward(nat, p, q, R, cores, idx, offsets)
+        want = orc.tt_forward(idx, offsets, cores, p, q, R)
+        np.testing.assert_allclose(out, want, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(want).max())))
+        d_out = ((rng.random(want.shape) - 0.5) * 0.2).astype(np.float32)
+        grads = run_backward_dense(nat, p, q, R, cores, idx, offsets, d_out)
+        assert_grads_close(grads, orc.tt_dense_backward(idx, offsets, d_out, cores, p, q, R), rel=2e-4)
+    finally:
+        nat.set_path(nat.PATH_AUTO)
+
+
 @pytest.mark.parametrize("name", [n for n in RANK_CASES if any(f"r{r}" in n for r in (64, 128, 256))])
 def test_rank_sweep_golden_on_the_wide_rank_chain(nat, name):
     """The rank 64 / 128 / 256 points of the reference's rank sweep, forced onto the grouped wide-rank chain, against the
