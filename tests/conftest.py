@@ -20,6 +20,16 @@ RANK_CASES = ["tt_rank_q554r8", "tt_rank_q554r32", "tt_rank_q554r64", "tt_rank_q
 ROW_CASES = ["rows_arxiv", "rows_products", "rows_papers", "rows_products_b3", "rows_q448r16_b3"]
 
 
+@pytest.fixture(autouse=True)
+def _kernel_family_back_to_auto():
+    """ttemb_set_path is process-wide: a test that forces a kernel family must not leak it into the next one, whatever the
+    order the files run in."""
+    yield
+    mod = sys.modules.get("ttemb_native")
+    if mod is not None:
+        mod.set_path(mod.PATH_AUTO)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
