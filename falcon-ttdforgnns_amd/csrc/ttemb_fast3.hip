@@ -2210,6 +2210,18 @@ template <int Q0, int Q1, int Q2, int R1, int R2>
 static int run_forward_direct(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int64_t nnz, int64_t B,
                             float* output, hipStream_t st) {
   const uint32_t waves = (uint32_t)max_chunks(s, nnz);   // the chunk count is known on the device only: surplus wavefronts leave at once
+#ifndef TTEMB_WIDE_FWD_SIMPLE
+  if constexpr (DirectCfg<Q0, Q1, Q2, R1, R2>::NS >= 2) {   // wide ranks: the persistent chain
+#ifndef TTEMB_WIDE_FWD_WGS
+#define TTEMB_WIDE_FWD_WGS 4
+#endif
+    profile_begin(0, st);
+    hipLaunchKernelGGL((direct_forward_chain_kernel<Q0, Q1, Q2, R1, R2>), dim3((unsigned)(chain_cus() * TTEMB_WIDE_FWD_WGS)), dim3(256), 0, st,
+                       cores.c[2], plan, (uint32_t)num_groups(s), (uint32_t)s.p[2], output, (uint32_t)(B * s.D * 4));
+    profile_end(0, st);
+    return check_hip(hipGetLastError(), "direct_forward_chain_kernel");
+  }
+#endif
   profile_begin(0, st);
   hipLaunchKernelGGL((direct_forward_kernel<Q0, Q1, Q2, R1, R2>), dim3((waves + 3) / 4), dim3(256), 0, st, cores.c[2], plan,
                      (uint32_t)num_groups(s), (uint32_t)s.p[2], output, (uint32_t)(B * s.D * 4));
