@@ -1664,25 +1664,33 @@ __global__ __launch_bounds__(256) void fast3_finalize_kernel(GroupPlan plan, int
   const bool sparse_any = sparse_groups(plan, (uint32_t)(p0 * p1));
   const bool sparse = all_parts ? true : sparse_any;          // dG0 parts: skip the groups without ids by their counts
   const bool sparse_g1 = all_parts ? false : sparse_any;      // dG1 slabs: skip the slices without ids by their flags
-  // dG1 has few terms per output (one per slice): one thread per output, 256 outputs per workgroup, the workgroups
-  // after those of dG2 / dG0 (eight threads per output as below made 8x the workgroups for the largest of the cores)
+  // dG1 has few terms per output (one per slice): one thread per FOUR consecutive outputs (16-byte loads; a row of G1 is a
+  // whole number of them), 1024 outputs per workgroup, the workgroups after those of dG2 / dG0.  (One output per thread
+  // was 180 000 tiny workgroups for the 183 MB of dG1 at rank 256: the kernel was bound by their launch rate.)
   const int wg_a = (g2_floats + n0 + 31) / 32;
   if ((int)blockIdx.x >= wg_a) {
-    const int o = ((int)blockIdx.x - wg_a) * 256 + (int)threadIdx.x;
+    const int o = (((int)blockIdx.x - wg_a) * 256 + (int)threadIdx.x) * 4;
     if (o >= g1_floats) return;
     const int i1 = o / (g1_floats / p1);
-    float tot = 0.f;
-    for (int t = 0; t < slices; t += 8) {
-      bool on[8];
-      float v[8];
+    float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < slices; t += 4) {
+      bool on[4];
+      float4 v[4];
 #pragma unroll
-      for (int u = 0; u < 8; ++u)   // slices without ids wrote nothing (sparse form)
+      for (int u = 0; u < 4; ++u)   // slices without ids wrote nothing (sparse form)
         on[u] = t + u < slices && (!sparse_g1 || plan.epi_live[(size_t)(t + u) * p1 + i1] != 0u);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = on[u] ? plan.g1part[(size_t)(t + u) * g1_floats + o] : 0.f;
-      tot += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+      for (int u = 0; u < 4; ++u)
+        v[u] = on[u] ? *reinterpret_cast<const float4*>(plan.g1part + (size_t)(t + u) * g1_floats + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+      tot.x += (v[0].x + v[1].x) + (v[2].x + v[3].x);
+      tot.y += (v[0].y + v[1].y) + (v[2].y + v[3].y);
+      tot.z += (v[0].z + v[1].z) + (v[2].z + v[3].z);
+      tot.w += (v[0].w + v[1].w) + (v[2].w + v[3].w);
     }
-    finalize_emit(upd, 1, dG1, o, tot);
+    finalize_emit(upd, 1, dG1, o + 0, tot.x);
+    finalize_emit(upd, 1, dG1, o + 1, tot.y);
+    finalize_emit(upd, 1, dG1, o + 2, tot.z);
+    finalize_emit(upd, 1, dG1, o + 3, tot.w);
     return;
   }
   const int e = blockIdx.x * 32 + x;
@@ -2285,7 +2293,7 @@ static int run_backward_wide(const DevShape& s, const CorePtrs& cores, const Gro
   }
   {
     const int g2_floats = s.p[2] * C::ROW2, g1_floats = s.p[1] * C::ROW1;
-    const int wgs = (g2_floats + s.p[0] * C::ROW0 + 31) / 32 + (g1_floats + 255) / 256;
+    const int wgs = (g2_floats + s.p[0] * C::ROW0 + 31) / 32 + (g1_floats + 1023) / 1024;
     hipLaunchKernelGGL(fast3_finalize_kernel, dim3((unsigned)wgs), dim3(256), 0, st, plan, (int)slab_count(s, nnz), epi_slices(s), s.p[0], s.p[1],
                        g2_floats, (int)C::ROW0, g1_floats, Q2, R2, d_cores.c[0], d_cores.c[1], d_cores.c[2], upd, 1);
   }
@@ -2372,7 +2380,7 @@ static int run_backward(const DevShape& s, const CorePtrs& cores, const GroupPla
   if (rc) return rc;
   {
     const int g2_floats = s.p[2] * C::ROW2, g1_floats = s.p[1] * C::ROW1;
-    const int wgs = (g2_floats + s.p[0] * C::ROW0 + 31) / 32 + (g1_floats + 255) / 256;   // dG2 | dG0, then dG1
+    const int wgs = (g2_floats + s.p[0] * C::ROW0 + 31) / 32 + (g1_floats + 1023) / 1024;   // dG2 | dG0, then dG1
     hipLaunchKernelGGL(fast3_finalize_kernel, dim3((unsigned)wgs), dim3(256), 0, st, plan, (int)slab_count(s, nnz), slices,
                        s.p[0], s.p[1], g2_floats, (int)C::ROW0, g1_floats, Q2, R2, d_cores.c[0], d_cores.c[1], d_cores.c[2], upd, 0);
   }
