@@ -670,16 +670,22 @@ def test_full_size_properties(nat, orc, cfg, N):
     assert abs(fd - an) <= 2e-3 * max(abs(an), 1.0), (fd, an)
 
 
-@pytest.mark.parametrize("live", [0, 1, 7000])
-def test_fast_path_with_a_device_side_live_count(nat, orc, live):
+@pytest.mark.parametrize("live,wide", [(0, False), (1, False), (7000, False), (0, True), (1, True), (2500, True)])
+def test_fast_path_with_a_device_side_live_count(nat, orc, live, wide):
     """The launch is sized by nnz, the kernels use the device-side count (what ttemb_preprocess leaves behind): only
     the first `live` ids exist.  0 and 1 are the degenerate ends (no chunk at all / one chunk of one id); rows are
-    derived from `offsets` (rowidx NULL) and the two-phase forward (group, then lookup) must give the same."""
+    derived from `offsets` (rowidx NULL) and the two-phase forward (group, then lookup) must give the same.  `wide`: the
+    same on the wide-rank chain (q = 5,5,4 at rank 64 on a small table)."""
     p, q, R, n_emb = CONFIGS["products"]
-    set_path(nat, "fast3", q, R)
+    if wide:
+        p, q, R = [23, 12, 40], [5, 5, 4], [1, 64, 64, 1]
+        n_emb = int(np.prod(p))
+        nat.set_path(nat.PATH_FAST3)
+    else:
+        set_path(nat, "fast3", q, R)
     rng = np.random.default_rng(3 + live)
-    cores = [(rng.standard_normal((p[t], R[t] * q[t] * R[t + 1])) * 0.3).astype(np.float32) for t in range(3)]
-    N = 9000
+    cores = [(rng.standard_normal((p[t], R[t] * q[t] * R[t + 1])) * (0.05 if wide and t == 1 else 0.3)).astype(np.float32) for t in range(3)]
+    N = 3000 if wide else 9000
     idx = rng.integers(0, n_emb, size=N).astype(np.int64)
     offsets = np.arange(N + 1, dtype=np.int64)
     shape = nat.make_shape(p, q, R)
