@@ -1456,10 +1456,22 @@ __device__ __forceinline__ bool sparse_groups(const GroupPlan& plan, uint32_t G)
 // SKIP: walk only the batches that hold an id and leave the dG0 parts of the others unwritten (the finalize kernel
 // then skips them by their counts) -- the form for frontiers that touch a small share of the groups.  Without SKIP
 // the loop is the plain counted one, and every group gets a part (zeros for an empty one).
+// Wavefronts per workgroup of the epilogue: they take consecutive slices of one i1 and share its G1 row in LDS.  One is
+// enough while that row is small; at rank 32 (16-20 KB next to a wavefront's 8-10 KB of dP) one-wave workgroups filled
+// the CU's LDS with six wavefronts, and the kernel is a chain of round trips per batch: four share the row then.
+template <int Q0, int Q1, int Q2, int R1, int R2>
+struct EpiCfg {
+  static constexpr int G1_BYTES = R1 * (Q1 * R2 + 1) * 4;
+#ifndef TTEMB_EPI_SHARE_BYTES
+#define TTEMB_EPI_SHARE_BYTES (8 * 1024)
+#endif
+  static constexpr int WAVES = G1_BYTES > TTEMB_EPI_SHARE_BYTES ? 4 : 1;
+};
+
 template <int Q0, int Q1, int Q2, int R1, int R2, bool SKIP>
 __device__ __forceinline__ void epilogue_unit(
     const float* __restrict__ G0, const float* __restrict__ G1, uint32_t p0, uint32_t p1, uint32_t gpw, const GroupPlan& plan,
-    float* dpbuf, float* g1buf) {
+    float* dpbuf, float* g1buf, uint32_t slice, uint32_t slices) {
   using C = Cfg<Q0, Q1, Q2, R1, R2>;
   constexpr int GM = 16 / Q0;            // groups per batch: their q0 rows fill one 16-row MFMA tile
   constexpr int LDD = C::N1 + 4;         // row stride of the staged dP rows (16-byte aligned rows)
@@ -1468,12 +1480,14 @@ __device__ __forceinline__ void epilogue_unit(
   constexpr int NLB = (BF4 + kWave - 1) / kWave;
   constexpr int KS3 = C::N1 / 4;
   static_assert(C::N1 % 4 == 0, "dP rows move as float4");
-  const int lane = threadIdx.x;
+  constexpr int EW = EpiCfg<Q0, Q1, Q2, R1, R2>::WAVES;
+  const int lane = threadIdx.x & 63;
   const int hi = lane >> 4, lo = lane & 15;
   const uint32_t i1 = blockIdx.y;
-  const uint32_t i0_begin = blockIdx.x * gpw;
+  const bool active = slice < slices;   // (a workgroup's last wavefronts may have no slice: they only help with G1)
+  const uint32_t i0_begin = active ? slice * gpw : p0;
   const uint32_t i0_end = i0_begin + gpw < p0 ? i0_begin + gpw : p0;
-  const uint32_t g_begin = i1 * p0 + i0_begin;
+  const uint32_t g_begin = i1 * p0 + (active ? i0_begin : 0u);
   const uint32_t G = p0 * p1;
   const rsrc_t r_dp = make_rsrc(plan.dptab, G * (uint32_t)PF * 4u);
   const rsrc_t r_g0 = make_rsrc(G0, p0 * (uint32_t)C::ROW0 * 4u);
@@ -1486,7 +1500,7 @@ __device__ __forceinline__ void epilogue_unit(
     for (int nt = 0; nt < C::NT1; ++nt) g1acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // which of this wave's groups hold ids (one lane per group; gpw <= 64)
-  const uint32_t cnt_l = (i0_begin + lane < i0_end) ? plan.counts[g_begin + lane] : 0u;
+  const uint32_t cnt_l = (i0_begin + lane < i0_end) ? plan.counts[g_begin + lane] : 0u;   // (an inactive wavefront: none)
   const unsigned long long live = __ballot(cnt_l != 0);
   float4 nxt[NLB];
   float nxt_g0[4][C::RT1];
@@ -1519,26 +1533,31 @@ __device__ __forceinline__ void epilogue_unit(
     return k;
   };
   if constexpr (SKIP) {   // a slice without ids leaves no slab and no parts: one flag says so
-    if (lane == 0) plan.epi_live[(size_t)blockIdx.x * p1 + i1] = live != 0ull ? 1u : 0u;
-    if (live == 0ull) return;
+    if (active && lane == 0) plan.epi_live[(size_t)slice * p1 + i1] = live != 0ull ? 1u : 0u;
+    if (EW == 1 && live == 0ull) return;
   }
   const uint32_t k_first = next_live(0);
   request(k_first);
   {
     // G1[i1] -> LDS (also for a slice without ids: 0 x stale LDS could be NaN): all loads first -- a load / wait /
-    // store per piece would serialise ~20 L2 round trips
+    // store per piece would serialise ~20 L2 round trips.  The workgroup's wavefronts take every EW-th piece.
     const float* g1 = G1 + (size_t)i1 * C::ROW1;
-    constexpr int NG1 = (C::ROW1 + kWave - 1) / kWave;
+    constexpr int NG1 = (C::ROW1 + EW * kWave - 1) / (EW * kWave);
+    const int t0 = (int)threadIdx.x;   // 0 .. EW * 64 - 1
     float g1v[NG1];
 #pragma unroll
     for (int it = 0; it < NG1; ++it) {
-      const int e = it * kWave + lane;
-      g1v[it] = (C::ROW1 % kWave == 0 || e < C::ROW1) ? g1[e] : 0.f;
+      const int e = it * EW * kWave + t0;
+      g1v[it] = (C::ROW1 % (EW * kWave) == 0 || e < C::ROW1) ? g1[e] : 0.f;
     }
 #pragma unroll
     for (int it = 0; it < NG1; ++it) {
-      const int e = it * kWave + lane;
-      if (C::ROW1 % kWave == 0 || e < C::ROW1) g1buf[(e / C::N1) * C::LDG + e % C::N1] = g1v[it];
+      const int e = it * EW * kWave + t0;
+      if (C::ROW1 % (EW * kWave) == 0 || e < C::ROW1) g1buf[(e / C::N1) * C::LDG + e % C::N1] = g1v[it];
+    }
+    if constexpr (EW > 1) {
+      __syncthreads();   // every wavefront of the workgroup is here: none has left yet
+      if (!active || (SKIP && live == 0ull)) return;
     }
   }
   const uint32_t n_here = i0_end - i0_begin;
@@ -1612,7 +1631,7 @@ __device__ __forceinline__ void epilogue_unit(
     k0 = k_next;
   }
   // this slice's dG1[i1] slab: every element is written (zeros when the slice holds no id)
-  float* dst = plan.g1part + ((size_t)blockIdx.x * p1 + i1) * C::ROW1;
+  float* dst = plan.g1part + ((size_t)slice * p1 + i1) * C::ROW1;
 #pragma unroll
   for (int t = 0; t < C::RT1; ++t)
 #pragma unroll
@@ -1625,15 +1644,19 @@ __device__ __forceinline__ void epilogue_unit(
 }
 
 template <int Q0, int Q1, int Q2, int R1, int R2>
-__global__ __launch_bounds__(64) void fast3_group_epilogue_kernel(
-    const float* __restrict__ G0, const float* __restrict__ G1, uint32_t p0, uint32_t p1, uint32_t gpw, GroupPlan plan) {
+__global__ __launch_bounds__((EpiCfg<Q0, Q1, Q2, R1, R2>::WAVES * 64)) void fast3_group_epilogue_kernel(
+    const float* __restrict__ G0, const float* __restrict__ G1, uint32_t p0, uint32_t p1, uint32_t gpw, uint32_t slices, GroupPlan plan) {
   using C = Cfg<Q0, Q1, Q2, R1, R2>;
-  __shared__ __attribute__((aligned(16))) float dpbuf[16 * (C::N1 + 4)];
+  constexpr int EW = EpiCfg<Q0, Q1, Q2, R1, R2>::WAVES;
+  __shared__ __attribute__((aligned(16))) float dpbuf_all[EW][16 * (C::N1 + 4)];
   __shared__ __attribute__((aligned(16))) float g1buf[R1 * C::LDG];
+  const uint32_t wave = threadIdx.x >> 6;
+  float* dpbuf = dpbuf_all[wave];
+  const uint32_t slice = blockIdx.x * EW + wave;
   if (sparse_groups(plan, p0 * p1))
-    epilogue_unit<Q0, Q1, Q2, R1, R2, true>(G0, G1, p0, p1, gpw, plan, dpbuf, g1buf);
+    epilogue_unit<Q0, Q1, Q2, R1, R2, true>(G0, G1, p0, p1, gpw, plan, dpbuf, g1buf, slice, slices);
   else
-    epilogue_unit<Q0, Q1, Q2, R1, R2, false>(G0, G1, p0, p1, gpw, plan, dpbuf, g1buf);
+    epilogue_unit<Q0, Q1, Q2, R1, R2, false>(G0, G1, p0, p1, gpw, plan, dpbuf, g1buf, slice, slices);
 }
 
 // D. finalize (and, in the fused modes, the optimiser step: every core element is produced exactly once here, so
@@ -2374,8 +2397,9 @@ static int run_backward(const DevShape& s, const CorePtrs& cores, const GroupPla
   rc = check_hip(hipGetLastError(), "fast3_dg2_reduce_kernel");
   if (rc) return rc;
   const int gpw = epi_groups_per_wave(s), slices = epi_slices(s);
-  hipLaunchKernelGGL((fast3_group_epilogue_kernel<Q0, Q1, Q2, R1, R2>), dim3((unsigned)slices, (unsigned)s.p[1]),
-                     dim3(64), 0, st, cores.c[0], cores.c[1], (uint32_t)s.p[0], (uint32_t)s.p[1], (uint32_t)gpw, plan);
+  constexpr int EW = EpiCfg<Q0, Q1, Q2, R1, R2>::WAVES;
+  hipLaunchKernelGGL((fast3_group_epilogue_kernel<Q0, Q1, Q2, R1, R2>), dim3((unsigned)((slices + EW - 1) / EW), (unsigned)s.p[1]),
+                     dim3(EW * 64), 0, st, cores.c[0], cores.c[1], (uint32_t)s.p[0], (uint32_t)s.p[1], (uint32_t)gpw, (uint32_t)slices, plan);
   rc = check_hip(hipGetLastError(), "fast3_group_epilogue_kernel");
   if (rc) return rc;
   {
