@@ -686,7 +686,8 @@ def test_captured_lookup_trains_like_the_eager_module(ops, orc, optimizer):
         d = torch.tensor(((rng.random((n, 100)) - 0.5) * 0.05).astype(np.float32)).cuda()
         out_a = a(ids, torch.arange(n + 1).cuda())
         out_b = cap(ids)
-        torch.testing.assert_close(out_b, out_a, rtol=1e-5, atol=1e-6)
+        # (the second step looks up weights that already differ by the first step's summation order: Adagrad's bound below)
+        torch.testing.assert_close(out_b, out_a, rtol=1e-5, atol=1e-6 if optimizer == "SGD" else 1e-5)
         out_a.backward(d)
         out_b.backward(d)
         torch.cuda.synchronize()
