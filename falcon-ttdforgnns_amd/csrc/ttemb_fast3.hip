@@ -1350,6 +1350,35 @@ __global__ __launch_bounds__(NWB * 64) void fast3_dg2_reduce_kernel(GroupPlan pl
   // takes columns [ROW2 y, ROW2 (y + 1)) of every E row (`stride` floats apart) and of the slab
   const uint32_t col0 = blockIdx.y * ROW2;
   float* slab = plan.g2part + (SHARED ? (size_t)0 : (size_t)blockIdx.x * p2 * stride) + col0;  // this tile's partial dG2, every row written
+  if constexpr (SHARED) {
+    // Far more buckets than rows in a tile (a 4-core table with a merged last pair: 3 600 values of i2, <= 2 048 rows): hardly
+    // any two rows of a tile share their i2, so bucketing them costs a scan and a walk over every (mostly empty) bucket
+    // per tile and saves no atomic.  Every row is added to its slab row as it is: SUB rows per 16-byte load, then one
+    // atomic instruction of 64 consecutive floats per row.
+    if (p2 > (uint32_t)kRowsMax && ROW2 == 4 * (ROW2 / 4) && kWave % F4 == 0) {
+      const int sub = lane / F4, c4 = lane - sub * F4;
+      for (uint32_t j0 = wave * SUB; j0 < n_rows; j0 += NWB * SUB) {
+        const uint32_t r = j0 + sub;
+        const bool on = r < n_rows;
+        const uint32_t i2 = on ? plan.i2s[s0 + r] : 0u;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (on) acc = *reinterpret_cast<const float4*>(plan.etab + (size_t)(s0 + r) * stride + col0 + 4 * c4);
+#pragma unroll
+        for (int k = 0; k < SUB; ++k) {   // row j0 + k: its floats sit in lanes k F4 .. k F4 + F4 - 1, four per lane
+          const uint32_t i2k = __shfl(i2, k * F4, kWave);
+          const bool onk = j0 + k < n_rows;
+          for (int e0 = 0; e0 < ROW2; e0 += kWave) {
+            const int e = e0 + lane, src = k * F4 + ((e >> 2) % F4);
+            const float x = __shfl(acc.x, src, kWave), y = __shfl(acc.y, src, kWave);
+            const float z = __shfl(acc.z, src, kWave), w = __shfl(acc.w, src, kWave);
+            const float v = (e & 3) == 0 ? x : ((e & 3) == 1 ? y : ((e & 3) == 2 ? z : w));
+            if (onk && e < ROW2) atomicAdd(slab + (size_t)i2k * stride + e, v);
+          }
+        }
+      }
+      return;
+    }
+  }
   for (uint32_t e = tid; e <= p2; e += NWB * 64) bstart[e] = 0;
   __syncthreads();
   // histogram of i2 over the tile (integer LDS atomics; 8 ids per thread)
@@ -2390,6 +2419,7 @@ static int run_backward(const DevShape& s, const CorePtrs& cores, const GroupPla
     if (rc) return rc;
     hipLaunchKernelGGL((fast3_dg2_reduce_kernel<C::ROW2, kRowsB, NWB, true>), dim3((unsigned)tiles), dim3(NWB * 64), reduce_lds, st,
                        plan, (int)G, (uint32_t)s.p[2], (uint32_t)reduce_rows(nnz), (uint32_t)C::ROW2);
+
   } else {
     hipLaunchKernelGGL((fast3_dg2_reduce_kernel<C::ROW2, kRowsB, NWB, false>), dim3((unsigned)tiles), dim3(NWB * 64), reduce_lds, st,
                        plan, (int)G, (uint32_t)s.p[2], (uint32_t)reduce_rows(nnz), (uint32_t)C::ROW2);
