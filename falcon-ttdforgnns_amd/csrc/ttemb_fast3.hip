@@ -837,6 +837,10 @@ constexpr int kFuseQuads = 48 / kFuseWaves;    // register quads of slab rows pe
 constexpr int kFuseBatch = 6;                  // quads whose list heads / first rows are read together
 constexpr int kFuseSub = 2;                    // chunks a wavefront multiplies between two reductions (one more E region each)
 static_assert(kFuseQuads % kFuseBatch == 0, "quads are handled in whole batches");
+// Shapes whose dP is ONE row tile (q0 q1 <= 16) hold half the accumulators and A operands of the others: their wavefronts
+// have registers for half as many slab quads again, which is what a wide row (r2 q2 = 128: two rows per register quad
+// across the lanes) needs to keep 140 slab rows in four wavefronts (q = 4,4,8 at rank 16, the arxiv shape of the scripts).
+constexpr int fuse_quads(int m2, int row2) { return (m2 <= 16 && row2 >= 128) ? kFuseQuads + kFuseBatch : kFuseQuads; }
 
 template <int Q0, int Q1, int Q2, int R1, int R2, bool FUSE>
 __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / kFuseWaves : 1) void fast3_bwd_chunk_kernel(
@@ -952,11 +956,12 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
   const int s_grp = lane / LPR, s_piece = lane % LPR;
   const int s_kk = s_piece / QK;
   const int rd_off = s_kk * R2 + 4 * ((s_piece % QK) ^ (s_kk & (QK - 1)));   // float offset of this lane's quad inside a row
-  f32x4 slab[kFuseQuads];
+  constexpr int FQ = fuse_quads(C::M2, C::ROW2);
+  f32x4 slab[FQ];
   if constexpr (FUSE) {
 #pragma unroll
-    for (int q = 0; q < kFuseQuads; ++q) slab[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int i = threadIdx.x; i <= kFuseWaves * GPW * kFuseQuads; i += kFuseWaves * kWave) f_head[i] = f_nil;
+    for (int q = 0; q < FQ; ++q) slab[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i <= kFuseWaves * GPW * FQ; i += kFuseWaves * kWave) f_head[i] = f_nil;
     for (int i = threadIdx.x; i < C::ROW2; i += kFuseWaves * kWave) f_zero[i] = 0.f;
     if (threadIdx.x == 0) f_tab[kRoundRows] = make_uint2((uint32_t)(reinterpret_cast<char*>(f_zero) - lds0), f_nil);
     __syncthreads();
@@ -1236,11 +1241,11 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
         // slab row of this lane in quad q: i2 = 8 (q GPW + lane group) + wave.  First the heads of all quads, then the
         // first row of every list (reads in flight together), then whatever is left of longer lists
         // head of this lane's slab row in quad q: f_head[(q GPW + lane group) kFuseWaves + wave]; idle lanes use the spare word
-        uint32_t* const my_head = s_grp < GPW ? f_head + ((uint32_t)s_grp * kFuseWaves + wave) : f_head + kFuseWaves * GPW * kFuseQuads;
+        uint32_t* const my_head = s_grp < GPW ? f_head + ((uint32_t)s_grp * kFuseWaves + wave) : f_head + kFuseWaves * GPW * FQ;
         const int qstep = s_grp < GPW ? GPW * kFuseWaves : 0;
         const char* const rows = lds0 + (uint32_t)rd_off * 4u;
 #pragma unroll
-        for (int q0 = 0; q0 < kFuseQuads; q0 += kFuseBatch) {
+        for (int q0 = 0; q0 < FQ; q0 += kFuseBatch) {
           if ((uint32_t)(q0 * GPW * kFuseWaves) >= p2) break;   // wave-uniform: no slab row in the remaining quads
           uint32_t en[kFuseBatch];   // entry being visited
 #pragma unroll
@@ -1313,7 +1318,7 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
     // one wavefront (zeros where no id came by); the lane's quad goes back to its place in the [kk][c2] row
     float* tile = plan.g2part + (size_t)blockIdx.x * p2 * C::ROW2;
 #pragma unroll
-    for (int q = 0; q < kFuseQuads; ++q) {
+    for (int q = 0; q < FQ; ++q) {
       const uint32_t i2 = (uint32_t)(q * GPW + s_grp) * kFuseWaves + wave;
       if (s_grp < GPW && i2 < p2) *reinterpret_cast<f32x4*>(tile + (size_t)i2 * C::ROW2 + 4 * s_piece) = slab[q];
     }
@@ -1972,9 +1977,10 @@ static bool fused_dg2(const DevShape& s) {
   if (lpr < 1 || lpr > kWave) return false;
   if (s.R[2] > 16) return false;   // at rank 32 the fused kernel's registers (operands + slab rows) no longer fit two waves per SIMD
   const int gpw = kWave / lpr;
-  if (s.p[2] > kFuseWaves * gpw * kFuseQuads) return false;
+  const int fq = fuse_quads(s.q[0] * s.q[1], s.row_len[2]);
+  if (s.p[2] > kFuseWaves * gpw * fq) return false;
   return (size_t)kFuseWaves * (bwd_wave_lds_floats(s) + (size_t)kChunk * s.row_len[2]) * 4 +
-             (size_t)(s.row_len[2] + kFuseWaves * (1 + 32 * kFuseSub) + 3 + kFuseWaves * gpw * kFuseQuads) * 4 <= kCuLds;
+             (size_t)(s.row_len[2] + kFuseWaves * (1 + 32 * kFuseSub) + 3 + kFuseWaves * gpw * fq) * 4 <= kCuLds;
 }
 static int64_t fused_tiles(const DevShape& s, int64_t nnz) {   // workgroups: at least ~2 chunks per wavefront, at most one per CU
   const int64_t t = (max_chunks(s, nnz) + 2 * kFuseSub * kFuseWaves - 1) / (2 * kFuseSub * kFuseWaves);
@@ -2387,7 +2393,7 @@ static int run_backward(const DevShape& s, const CorePtrs& cores, const GroupPla
   if (fused) {   // chunk products and the dG2 reduction in one launch
     if (wave_lds != bwd_wave_lds_floats(s) * sizeof(float)) return fail(TTEMB_E_HIP, "internal: LDS size formula out of step");
     const size_t lds = kFuseWaves * (wave_lds + kChunk * C::ROW2 * sizeof(float)) +
-                       (size_t)(C::ROW2 + kFuseWaves * (1 + 32 * kFuseSub) + 3 + kFuseWaves * (kWave / (C::ROW2 / 4)) * kFuseQuads) * sizeof(uint32_t);
+                       (size_t)(C::ROW2 + kFuseWaves * (1 + 32 * kFuseSub) + 3 + kFuseWaves * (kWave / (C::ROW2 / 4)) * fuse_quads(C::M2, C::ROW2)) * sizeof(uint32_t);
     static bool lds_ok = false;
     rc = allow_lds(reinterpret_cast<const void*>(fast3_bwd_chunk_kernel<Q0, Q1, Q2, R1, R2, true>), lds, &lds_ok);
     if (rc) return rc;
