@@ -62,8 +62,9 @@ enum {
 
 /* Kernel-selection knob for forward/backward (tests drive both; 0 is the default). */
 enum {
-  TTEMB_PATH_AUTO = 0,          /* fast path when the shape supports it and the batch has at
-                                   least max(4096, p0*p1/4) ids (measured crossover), else generic */
+  TTEMB_PATH_AUTO = 0,          /* grouped MFMA path when the shape has it and the batch is past its measured crossover
+                                   (max(4096, p0*p1/4) ids; ranks >= 64: p0*p1/8 at 64, p0*p1/24 at 128, any at 256), else the
+                                   per-bag MFMA kernels (ids + offsets), else generic */
   TTEMB_PATH_GENERIC = 1,       /* shape-generic wave-per-id kernels (T = 2..4)    */
   TTEMB_PATH_FAST3 = 2,         /* sorted / grouped MFMA path, T == 3 only         */
   TTEMB_PATH_PER_BAG = 3        /* one wavefront per bag (MFMA per id) whenever the shape has it and the ids come
