@@ -696,6 +696,33 @@ def test_captured_lookup_trains_like_the_eager_module(ops, orc, optimizer):
             torch.testing.assert_close(cb.data, ca.data, rtol=1e-4, atol=1e-6 if optimizer == "SGD" else 2e-5)
 
 
+def test_captured_lookup_on_the_wide_rank_chain(ops):
+    """emb.capture() on a rank-64 table: the wide-rank chain (GEMM prefix, row lists, per-group backward, column-sliced
+    reduce, GEMMs, finalize) replays from HIP graphs and trains like the eager module."""
+    torch.manual_seed(5)
+    p, q, r = [20, 15, 30], [5, 5, 4], [64, 64]
+    n_emb = int(np.prod(p))
+    mk = lambda: ops.TTEmbeddingBag(n_emb, 100, r, p, q, optimizer=ops.OptimType.SGD, sparse=True, use_cache=False,
+                                    weight_dist="uniform", learning_rate=0.05)
+    a, b = mk(), mk()
+    for ca, cb in zip(a.tt_cores, b.tt_cores):
+        cb.data.copy_(ca.data)
+    n = 1024
+    cap = b.capture(n, n)
+    rng = np.random.default_rng(6)
+    for _ in range(2):
+        ids = torch.tensor(rng.choice(n_emb, size=n, replace=False).astype(np.int64)).cuda()
+        d = torch.tensor(((rng.random((n, 100)) - 0.5) * 0.05).astype(np.float32)).cuda()
+        out_a = a(ids, torch.arange(n + 1).cuda())
+        out_b = cap(ids)
+        torch.testing.assert_close(out_b, out_a, rtol=1e-5, atol=1e-5 * float(out_a.detach().abs().max()))
+        out_a.backward(d)
+        out_b.backward(d)
+        torch.cuda.synchronize()
+        for ca, cb in zip(a.tt_cores, b.tt_cores):   # summation order (row atomics of the shared slab, split-K slabs) differs only
+            torch.testing.assert_close(cb.data, ca.data, rtol=1e-4, atol=1e-5 * float(ca.data.abs().max()))
+
+
 @pytest.mark.parametrize("one_sweep", [False, True])
 def test_lfu_update_on_a_colliding_stream(orc, one_sweep):
     """cache_update on a table that is far too small for its stream (H = 96, hundreds of distinct ids): whatever the
