@@ -367,15 +367,34 @@ class CapturedLookup:
             self.plan = self._lean.forward(cores, self.indices, self.offsets, self.nnz, self.B, self.output)
         with torch.cuda.graph(self.bwd_graph):   # (a zero gradient: the captured update leaves the cores as they are)
             self._lean.backward(cores, state, self.indices, self.offsets, self.nnz, self.B, self.d_output, lr, eps, self.plan)
-        self._lr = lr
+        self._lr, self._eps = lr, eps
+        self._baked = self._pointers()
+
+    def _pointers(self) -> tuple:
+        """What the graphs hold by address: the cores and the optimiser state."""
+        m = self.module
+        ptrs = tuple(c.data_ptr() for c in m._cores())
+        if m.optimizer not in _SGD_LIKE:
+            ptrs += tuple(st.data_ptr() for st in m._states())
+        return ptrs
 
     def __call__(self, indices: torch.Tensor, offsets: Optional[torch.Tensor] = None) -> torch.Tensor:
-        if float(self.module.learning_rate) != self._lr:
-            raise RuntimeError("the learning rate is part of the captured backward: capture() again after set_learning_rate()")
+        m = self.module
+        if m.use_cache and not m.warmup:
+            # after cache_populate() the eager module serves and trains the hot ids in cache_weight; the captured graphs
+            # read and update the TT cores only -- the two would diverge silently
+            raise RuntimeError("the row cache went live after capture(): captured lookups do not cover a live cache")
+        if float(m.learning_rate) != self._lr or float(m.eps) != self._eps:
+            raise RuntimeError("learning rate / eps are part of the captured backward: capture() again after changing them")
+        if self._pointers() != self._baked:
+            raise RuntimeError("tt_cores / optimizer_state were re-allocated after capture() (.to(), .data = ..., "
+                               "load_state_dict into new storage): capture() again")
+        if m.use_cache:   # warm-up: the LFU statistics of a captured step count like those of an eager one
+            m.update_cache(indices)
         self.indices.copy_(indices)
         if offsets is not None:
             self.offsets.copy_(offsets)
-        return _ReplayLookup.apply(self.module._cores()[0], self)
+        return _ReplayLookup.apply(m._cores()[0], self)
 
 
 # --------------------------------------------------------------------------------------
@@ -506,6 +525,12 @@ class TableBatchedTTEmbeddingBag(nn.Module):
             self.cache_state.fill_(-1)
             self.warmup = True
 
+    def _fused_probe(self) -> bool:
+        """Live cache, default insert: update_cache_state and preprocess_indices_sync of a forward are ONE probe pass
+        (``ttemb_preprocess_update``).  The reference-exact one-sweep insert keeps its own launch."""
+        return (self.use_cache and not self.warmup and self.num_tables == 1
+                and not getattr(self, "lfu_one_sweep_insert", False))
+
     def update_cache(self, indices: torch.Tensor) -> None:
         if self.use_cache:   # `lfu_one_sweep_insert = True` on the module selects the reference's insert bit for bit
             _nat.cache_update(indices.long().contiguous(), self.hashtbl, self.cache_freq,
@@ -525,16 +550,18 @@ class TableBatchedTTEmbeddingBag(nn.Module):
 
     # ---- lookup -------------------------------------------------------------------
     def _cores(self) -> tuple:
-        """The core Parameters as a tuple (walking the ParameterList costs microseconds per call); rebuilt when the list's
-        first Parameter object is no longer the cached one."""
+        """The core Parameters as a tuple (walking the ParameterList costs microseconds per call); rebuilt when ANY of the
+        list's Parameter objects is no longer the cached one (2-4 identity tests)."""
         cl = self._core_list
-        if cl is None or cl[0] is not self.tt_cores._parameters.get("0"):
+        live = self.tt_cores._parameters
+        if cl is None or len(cl) != len(live) or any(c is not live.get(str(t)) for t, c in enumerate(cl)):
             cl = self._core_list = tuple(self.tt_cores)
         return cl
 
     def _states(self) -> tuple:
         sl = self._state_list
-        if sl is None or sl[0] is not self.optimizer_state._buffers.get("optimizer_state0"):
+        live = self.optimizer_state._buffers
+        if sl is None or len(sl) != len(live) or any(b is not live.get(f"optimizer_state{t}") for t, b in enumerate(sl)):
             sl = self._state_list = tuple(self.optimizer_state)
         return sl
 
@@ -551,16 +578,16 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         part = torch.empty_like(indices)
         loc = torch.empty(nnz, dtype=torch.int32, device=dev)
         # [number of TT ids, "a cache row occurs twice in this batch"]: both stay on the device.  The second word lets
-        # the cache backward update rows with one writer each without float atomics; it comes from per-row stamps
-        # of a per-call epoch (module scratch, not part of the state dict).
+        # the cache backward update rows with one writer each without float atomics; it comes from per-row position
+        # stamps (module scratch, any content, not part of the state dict).
         nnz_tt = torch.empty(2, dtype=torch.int32, device=dev)
         stamp = getattr(self, "_dup_stamp", None)
         if stamp is None or stamp.device != dev or stamp.numel() != self.cache_weight.shape[0]:
-            stamp = self._dup_stamp = torch.zeros(self.cache_weight.shape[0], dtype=torch.int32, device=dev)
-            self._dup_epoch = 0
-        self._dup_epoch = self._dup_epoch % 0x7FFFFFFE + 1
+            stamp = self._dup_stamp = torch.empty(self.cache_weight.shape[0], dtype=torch.int32, device=dev)
+        # the LFU update of this batch rides in the probe pass (forward() skipped update_cache for it)
+        freq = self.cache_freq if self._fused_probe() else None
         _nat.preprocess(indices, offsets, B, False, self.hashtbl, self.cache_state, part, rowidx, loc, nnz_tt,
-                        self._ws, stamp, self._dup_epoch)
+                        self._ws, stamp, 0, freq)
         return TTLookupFunction.apply(self, table, B, part, rowidx, offsets, nnz_tt, loc, self.cache_weight,
                                       *self.tt_cores)
 
@@ -571,7 +598,8 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         indices, offsets = indices.long().contiguous(), offsets.long().contiguous()
         assert (offsets.numel() - 1) % self.num_tables == 0
         B = (offsets.numel() - 1) // self.num_tables
-        self.update_cache(indices)
+        if not self._fused_probe():
+            self.update_cache(indices)
         if self.num_tables == 1:
             return self._lookup_one_table(0, B, indices, offsets).unsqueeze(0)
         bounds = offsets[:: B].tolist()  # host sync: only the multi-table path pays it
@@ -606,6 +634,6 @@ class TTEmbeddingBag(TableBatchedTTEmbeddingBag):
             indices = indices.long().contiguous()
         if offsets.dtype != torch.int64 or not offsets.is_contiguous():
             offsets = offsets.long().contiguous()
-        if self.use_cache:
+        if self.use_cache and not self._fused_probe():
             self.update_cache(indices)
         return self._lookup_one_table(0, offsets.numel() - 1, indices, offsets)

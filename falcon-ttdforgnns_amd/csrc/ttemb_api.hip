@@ -28,6 +28,31 @@ int check_hip(hipError_t e, const char* what) {
   return fail(TTEMB_E_HIP, "%s: %s", what, hipGetErrorString(e));
 }
 
+int allow_big_lds(const void* kernel, size_t lds_bytes, LdsGate* gate, const char* what) {
+  if (lds_bytes <= kLdsDefault) return TTEMB_OK;
+  if (lds_bytes > kCuLds)
+    return fail(TTEMB_E_UNSUPPORTED, "%s needs %lld bytes of LDS per workgroup, the CU has %lld", what, (long long)lds_bytes, (long long)kCuLds);
+  int dev = 0;
+  int rc = check_hip(hipGetDevice(&dev), "hipGetDevice");
+  if (rc) return rc;
+  const uint64_t bit = dev >= 0 && dev < 64 ? (uint64_t(1) << dev) : 0;
+  if (bit && (gate->devices.load(std::memory_order_acquire) & bit)) return TTEMB_OK;
+  rc = check_hip(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCuLds), what);
+  if (rc == TTEMB_OK && bit) gate->devices.fetch_or(bit, std::memory_order_release);
+  return rc;
+}
+
+int device_cus() {
+  static std::atomic<int> cus[64];   // zero-initialised: "not asked yet"
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  const bool slot = dev >= 0 && dev < 64;
+  if (slot && (n = cus[dev].load(std::memory_order_relaxed)) > 0) return n;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  if (slot) cus[dev].store(n, std::memory_order_relaxed);
+  return n;
+}
+
 int current_path() { return g_path.load(); }
 
 static std::atomic<bool> g_prof_on{false};
@@ -840,13 +865,11 @@ int ttemb_cache_populate(const ttemb_shape_t* shape, const float* const* cores, 
   return launch_forward_generic(ds, cp, sorted_keys, nullptr, nullptr, C, C, nullptr, cache_weight, st);
 }
 
-int ttemb_preprocess(const int64_t* indices, const int64_t* offsets, int64_t nnz, int64_t B,
-                     int32_t warmup, const int64_t* hashtbl, const int32_t* cache_state, int64_t H,
-                     int64_t* indices_out, int64_t* rowidx_out, int32_t* cache_loc_out,
-                     int32_t* nnz_tt_dev, int32_t* dup_stamp, int32_t epoch, void* workspace, int64_t workspace_bytes,
-                     void* stream) {
+static int preprocess_impl(const int64_t* indices, const int64_t* offsets, int64_t nnz, int64_t B, int32_t warmup,
+                           int64_t* hashtbl, int64_t* cache_freq, const int32_t* cache_state, int64_t H,
+                           int64_t* indices_out, int64_t* rowidx_out, int32_t* cache_loc_out, int32_t* nnz_tt_dev,
+                           int32_t* dup_stamp, void* workspace, int64_t workspace_bytes, void* stream) {
   if (nnz < 0 || B < 0) return fail(TTEMB_E_BADARG, "negative size");
-  if (dup_stamp != nullptr && epoch == 0) return fail(TTEMB_E_BADARG, "epoch 0 is the value of a fresh stamp array");
   if (nnz > 0x7fffffffll) return fail(TTEMB_E_BADARG, "nnz exceeds int32 range");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const bool passthrough = warmup != 0 || H == 0;
@@ -865,8 +888,27 @@ int ttemb_preprocess(const int64_t* indices, const int64_t* offsets, int64_t nnz
   if (!hashtbl || !cache_state || !indices_out || !cache_loc_out || !nnz_tt_dev || !workspace)
     return fail(TTEMB_E_BADARG, "null buffer");
   if (indices_out == indices) return fail(TTEMB_E_BADARG, "partition cannot run in place");
-  return launch_partition(indices, offsets, nnz, B, hashtbl, cache_state, H, indices_out, rowidx_out,
-                          cache_loc_out, nnz_tt_dev, dup_stamp, epoch, workspace, workspace_bytes, st);
+  return launch_partition(indices, offsets, nnz, B, hashtbl, cache_freq, cache_state, H, indices_out, rowidx_out,
+                          cache_loc_out, nnz_tt_dev, dup_stamp, workspace, workspace_bytes, st);
+}
+
+int ttemb_preprocess(const int64_t* indices, const int64_t* offsets, int64_t nnz, int64_t B,
+                     int32_t warmup, const int64_t* hashtbl, const int32_t* cache_state, int64_t H,
+                     int64_t* indices_out, int64_t* rowidx_out, int32_t* cache_loc_out,
+                     int32_t* nnz_tt_dev, int32_t* dup_stamp, int32_t epoch, void* workspace, int64_t workspace_bytes,
+                     void* stream) {
+  (void)epoch;   // ABI 1 took a per-call epoch for the stamps; position stamps need none
+  return preprocess_impl(indices, offsets, nnz, B, warmup, const_cast<int64_t*>(hashtbl), nullptr, cache_state, H, indices_out,
+                         rowidx_out, cache_loc_out, nnz_tt_dev, dup_stamp, workspace, workspace_bytes, stream);
+}
+
+int ttemb_preprocess_update(const int64_t* indices, const int64_t* offsets, int64_t nnz, int64_t B, int64_t* hashtbl,
+                            int64_t* cache_freq, const int32_t* cache_state, int64_t H, int64_t* indices_out,
+                            int64_t* rowidx_out, int32_t* cache_loc_out, int32_t* nnz_tt_dev, int32_t* dup_stamp,
+                            void* workspace, int64_t workspace_bytes, void* stream) {
+  if (H <= 0 || !hashtbl || !cache_freq) return fail(TTEMB_E_BADARG, "ttemb_preprocess_update needs the hash table and its counters");
+  return preprocess_impl(indices, offsets, nnz, B, 0, hashtbl, cache_freq, cache_state, H, indices_out, rowidx_out,
+                         cache_loc_out, nnz_tt_dev, dup_stamp, workspace, workspace_bytes, stream);
 }
 
 static int check_cache_args(const void* loc, const void* rowidx, int64_t start, int64_t nnz, int64_t D) {

@@ -14,9 +14,10 @@ int launch_cache_populate_rank(int64_t* hashtbl, int64_t* freq, int32_t* state, 
 int64_t preprocess_workspace_bytes(int64_t nnz);
 int launch_rowidx(const int64_t* offsets, int64_t B, int64_t nnz, int64_t* rowidx, hipStream_t st);
 int launch_set_count(int32_t* dst, int32_t v, hipStream_t st);
+// freq != nullptr: the LFU update of the same ids (find-first form) rides in the probe pass (hashtbl is then written)
 int launch_partition(const int64_t* indices, const int64_t* offsets, int64_t nnz, int64_t B,
-                     const int64_t* hashtbl, const int32_t* state, int64_t H, int64_t* indices_out,
-                     int64_t* rowidx_out, int32_t* loc_out, int32_t* nnz_tt_dev, int32_t* dup_stamp, int32_t epoch,
+                     int64_t* hashtbl, int64_t* freq, const int32_t* state, int64_t H, int64_t* indices_out,
+                     int64_t* rowidx_out, int32_t* loc_out, int32_t* nnz_tt_dev, int32_t* dup_stamp,
                      void* ws, int64_t ws_bytes, hipStream_t st);
 int launch_cache_forward(const int32_t* loc, const int64_t* rowidx, const int64_t* offsets, int64_t start,
                          const int32_t* start_dev, int64_t nnz, const float* weight, int64_t D,

@@ -59,20 +59,18 @@ __device__ __forceinline__ int32_t table_find(int64_t key, const int64_t* __rest
   return -1;
 }
 
-__global__ void cache_update_kernel(const int64_t* __restrict__ indices, int64_t nnz,
-                                    int64_t* __restrict__ keys, int64_t* __restrict__ freq,
-                                    uint32_t H) {
-  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= nnz) return;
-  const int64_t key = indices[n];
+// LFU update of one key: count it in the slot that holds it, else insert it into the first of its probe slots that is
+// empty.  Returns the slot that took the count, or -1 (three occupied probes: the id is simply not tracked, as in the
+// reference).
+// Pass 1, reads only: is the key already in one of its probe slots?  The reference probes and
+// inserts in one sweep (hashtbl_cuda_utils.cuh:102-133), which after cache_populate's evictions
+// re-inserts a cached id into a hole in front of its own slot; the id then resolves to the new slot
+// (cache_state -1) and silently leaves the cache, for a thread-order-dependent set of ids.  Finding
+// first keeps every tracked key in one slot; before any eviction the two are the same table.
+// (A slot never changes once it holds a real key until populate evicts, so what pass 1 saw occupied
+// stays occupied: pass 2 only needs a CAS on the slots it saw empty -- one atomic per id.)
+__device__ __forceinline__ int32_t lfu_count(int64_t key, int64_t* __restrict__ keys, int64_t* __restrict__ freq, uint32_t H) {
   const uint32_t s0 = hash_slot(key, H);
-  // Pass 1, reads only: is the key already in one of its probe slots?  The reference probes and
-  // inserts in one sweep (hashtbl_cuda_utils.cuh:102-133), which after cache_populate's evictions
-  // re-inserts a cached id into a hole in front of its own slot; the id then resolves to the new slot
-  // (cache_state -1) and silently leaves the cache, for a thread-order-dependent set of ids.  Finding
-  // first keeps every tracked key in one slot; before any eviction the two are the same table.
-  // (A slot never changes once it holds a real key until populate evicts, so what pass 1 saw occupied
-  // stays occupied: pass 2 only needs a CAS on the slots it saw empty -- one atomic per id.)
   unsigned long long seen[kMaxProbes];
   uint32_t s = s0;
 #pragma unroll
@@ -80,7 +78,7 @@ __global__ void cache_update_kernel(const int64_t* __restrict__ indices, int64_t
     seen[probe] = (unsigned long long)__builtin_nontemporal_load(&keys[s]);
     if (seen[probe] == (unsigned long long)key) {
       atomicAdd(reinterpret_cast<unsigned long long*>(&freq[s]), 1ull);
-      return;
+      return (int32_t)s;
     }
     s = (s + 1 == H) ? 0 : s + 1;
   }
@@ -92,12 +90,20 @@ __global__ void cache_update_kernel(const int64_t* __restrict__ indices, int64_t
                                                (unsigned long long)kEmptyKey, (unsigned long long)key);
       if (old == (unsigned long long)kEmptyKey || old == (unsigned long long)key) {
         atomicAdd(reinterpret_cast<unsigned long long*>(&freq[s]), 1ull);
-        return;
+        return (int32_t)s;
       }
     }
     s = (s + 1 == H) ? 0 : s + 1;
   }
-  // three occupied probes: the id is simply not tracked (reference returns -1 and moves on)
+  return -1;
+}
+
+__global__ void cache_update_kernel(const int64_t* __restrict__ indices, int64_t nnz,
+                                    int64_t* __restrict__ keys, int64_t* __restrict__ freq,
+                                    uint32_t H) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= nnz) return;
+  (void)lfu_count(indices[n], keys, freq, H);
 }
 
 // The reference's own insert, for callers that need its table bit for bit: probe and insert in ONE sweep
@@ -212,25 +218,40 @@ __global__ void rowidx_kernel(const int64_t* __restrict__ offsets, int64_t B, in
 // -- two launches -- + scatter were five launches and 36 us for 409 600 ids.)
 constexpr int kPartThreads = 256;
 
+// UPDATE: the LFU update of the same ids (ttemb_cache_update, the find-first form) rides in the probe pass -- the class
+// calls update_cache_state and preprocess_indices_sync back to back on the same ids (tt_embeddings_ops.py:836-870), and
+// both visit the same <= 3 slots.  Same table and same locations as the two passes in sequence: the find-first update
+// never moves or evicts a key, so a key resolves to the same slot before, during and after the update of the batch
+// (an id inserted by this very pass sits in a slot whose state is whatever cache_populate left there, which is what
+// the lookup after a separate update would read, too).
+// Duplicate detection among the cached ids (the cache backward may then update rows without float atomics): every cached id
+// stores its POSITION into the stamp of its cache row; the scatter kernel of the same call reads the stamp back and a
+// position that lost its row to another one has met a duplicate.  No returning atomic, no epoch, no initial state.
+template <bool UPDATE>
 __global__ __launch_bounds__(kPartThreads) void cache_lookup_kernel(const int64_t* __restrict__ indices, int64_t nnz,
-                                                                    const int64_t* __restrict__ keys,
+                                                                    int64_t* __restrict__ keys, int64_t* __restrict__ freq,
                                                                     const int32_t* __restrict__ state, uint32_t H,
                                                                     int32_t* __restrict__ loc,
                                                                     int32_t* __restrict__ blockcnt,
-                                                                    int32_t* __restrict__ dup_stamp, int32_t epoch) {
+                                                                    int32_t* __restrict__ dup_stamp, int32_t* __restrict__ nnz_tt) {
   const int64_t n = (int64_t)blockIdx.x * kPartThreads + threadIdx.x;
   int32_t where = -1;
-  bool dup = false;
   if (n < nnz) {
-    const int32_t slot = table_find(indices[n], keys, H);
+    const int64_t key = indices[n];
+    int32_t slot;
+    if constexpr (UPDATE) {
+      slot = lfu_count(key, keys, freq, H);
+      if (key == kEmptyKey) slot = -1;   // (table_find's rule: the empty key is never "found")
+    } else {
+      slot = table_find(key, keys, H);
+    }
     if (slot >= 0) where = state[slot];
     loc[n] = where;   // < 0: not cached, the id goes through the TT chain
-    // a cache row met twice in one call (stamp == this call's epoch already): its backward adds need atomics
-    if (dup_stamp != nullptr && where >= 0) dup = atomicExch(&dup_stamp[where], epoch) == epoch;
+    if (dup_stamp != nullptr && where >= 0) dup_stamp[where] = (int32_t)n;
   }
+  if (n == 0 && dup_stamp != nullptr) nnz_tt[1] = 0;   // "no cache row met twice" until the scatter kernel finds one
   const int c = __syncthreads_count(n < nnz && where < 0);
-  const int d = __syncthreads_or(dup);
-  if (threadIdx.x == 0) blockcnt[blockIdx.x] = c | (d ? (int32_t)0x80000000 : 0);   // bit 31: a duplicate in this block
+  if (threadIdx.x == 0) blockcnt[blockIdx.x] = c;
 }
 
 // selected (TT) items keep input order at the front; rejected (cached) items fill the
@@ -244,7 +265,8 @@ __global__ __launch_bounds__(kPartThreads) void partition_scatter_kernel(int64_t
                                                                          int64_t* __restrict__ indices_out,
                                                                          int64_t* __restrict__ rowidx_out,
                                                                          int32_t* __restrict__ loc_out,
-                                                                         int32_t* __restrict__ nnz_tt, bool write_dups) {
+                                                                         int32_t* __restrict__ nnz_tt,
+                                                                         const int32_t* __restrict__ dup_stamp) {
   __shared__ int wave_cnt[kPartThreads / kWave];
   __shared__ int64_t before_block;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -256,11 +278,12 @@ __global__ __launch_bounds__(kPartThreads) void partition_scatter_kernel(int64_t
     where = loc[n];
     row = bag_of_position(offsets, B, n);
   }
-  const bool last = blockIdx.x == gridDim.x - 1;   // the last block sees every count: it also gathers the duplicate bits
+  // a cached id whose row's stamp is not its own position shares the row with another id of this call
+  const bool dup = dup_stamp != nullptr && n < nnz && where >= 0 && dup_stamp[where] != (int32_t)n;
+  const bool last = blockIdx.x == gridDim.x - 1;
   if (wave == 0) {
     int64_t v = 0;
-    int dups = 0;
-    const int64_t nb = (int64_t)blockIdx.x + (last ? 1 : 0);
+    const int64_t nb = (int64_t)blockIdx.x;
     for (int64_t b0 = 0; b0 < nb; b0 += 8 * kWave) {   // eight loads per lane in flight, then the sums
       int32_t c[8];
 #pragma unroll
@@ -269,15 +292,7 @@ __global__ __launch_bounds__(kPartThreads) void partition_scatter_kernel(int64_t
         c[k] = b < nb ? blockcnt[b] : 0;
       }
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int64_t b = b0 + k * kWave + lane;
-        if (b < (int64_t)blockIdx.x) v += c[k] & 0x7fffffff;
-        dups |= c[k] < 0;
-      }
-    }
-    if (last && nnz_tt != nullptr && write_dups) {
-      const unsigned long long any = __ballot(dups != 0);
-      if (lane == 0) nnz_tt[1] = any != 0ull ? 1 : 0;
+      for (int k = 0; k < 8; ++k) v += c[k];
     }
 #pragma unroll
     for (int d = kWave / 2; d > 0; d >>= 1) {
@@ -297,6 +312,7 @@ __global__ __launch_bounds__(kPartThreads) void partition_scatter_kernel(int64_t
     total += wave_cnt[w];
   }
   if (last && threadIdx.x == 0) nnz_tt[0] = (int32_t)(before_block + total);
+  if (dup) nnz_tt[1] = 1;   // (cleared by the lookup kernel; every writer stores the same word)
   if (n >= nnz) return;
   const int64_t dst = f ? before : (nnz - 1 - (n - before));
   indices_out[dst] = id;
@@ -327,8 +343,8 @@ int launch_set_count(int32_t* dst, int32_t v, hipStream_t st) {
 }
 
 int launch_partition(const int64_t* indices, const int64_t* offsets, int64_t nnz, int64_t B,
-                     const int64_t* hashtbl, const int32_t* state, int64_t H, int64_t* indices_out,
-                     int64_t* rowidx_out, int32_t* loc_out, int32_t* nnz_tt_dev, int32_t* dup_stamp, int32_t epoch,
+                     int64_t* hashtbl, int64_t* freq, const int32_t* state, int64_t H, int64_t* indices_out,
+                     int64_t* rowidx_out, int32_t* loc_out, int32_t* nnz_tt_dev, int32_t* dup_stamp,
                      void* ws, int64_t ws_bytes, hipStream_t st) {
   const int64_t need = preprocess_workspace_bytes(nnz);
   if (need > ws_bytes)
@@ -339,12 +355,16 @@ int launch_partition(const int64_t* indices, const int64_t* offsets, int64_t nnz
   base += align256(nnz * 4);
   int32_t* blockcnt = reinterpret_cast<int32_t*>(base);
   const int64_t blocks = part_blocks(nnz);
-  hipLaunchKernelGGL(cache_lookup_kernel, dim3((unsigned)blocks), dim3(kPartThreads), 0, st, indices, nnz,
-                     hashtbl, state, (uint32_t)H, loc, blockcnt, dup_stamp, epoch);
+  if (freq != nullptr)   // the LFU update of the same ids rides in the probe pass
+    hipLaunchKernelGGL(cache_lookup_kernel<true>, dim3((unsigned)blocks), dim3(kPartThreads), 0, st, indices, nnz,
+                       hashtbl, freq, state, (uint32_t)H, loc, blockcnt, dup_stamp, nnz_tt_dev);
+  else
+    hipLaunchKernelGGL(cache_lookup_kernel<false>, dim3((unsigned)blocks), dim3(kPartThreads), 0, st, indices, nnz,
+                       hashtbl, freq, state, (uint32_t)H, loc, blockcnt, dup_stamp, nnz_tt_dev);
   int rc = check_hip(hipGetLastError(), "cache_lookup_kernel");
   if (rc) return rc;
   hipLaunchKernelGGL(partition_scatter_kernel, dim3((unsigned)blocks), dim3(kPartThreads), 0, st, nnz, B, offsets,
-                     blockcnt, indices, loc, indices_out, rowidx_out, loc_out, nnz_tt_dev, dup_stamp != nullptr);
+                     blockcnt, indices, loc, indices_out, rowidx_out, loc_out, nnz_tt_dev, dup_stamp);
   return check_hip(hipGetLastError(), "partition_scatter_kernel");
 }
 

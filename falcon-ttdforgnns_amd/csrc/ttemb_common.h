@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/ttemb.h"
 
 namespace ttemb {
@@ -40,6 +42,16 @@ int current_path();
 // measurement hook: bracket the main chain kernel with events when profiling is on
 void profile_begin(int which, hipStream_t st);
 void profile_end(int which, hipStream_t st);
+
+// gfx950 has 160 KB of LDS per CU; a launch above the default 64 KB of dynamic LDS has to be allowed per kernel AND per
+// device (hipFuncSetAttribute acts on the current device's function object; a process may drive several GPUs).  One gate
+// per kernel: bit d = "allowed on device d"; devices past 63 ask the runtime every time.
+constexpr size_t kLdsDefault = 64 * 1024, kCuLds = 160 * 1024;
+struct LdsGate {
+  std::atomic<uint64_t> devices{0};
+};
+int allow_big_lds(const void* kernel, size_t lds_bytes, LdsGate* gate, const char* what);
+int device_cus();   // CUs of the current device (cached per device; 256 when it cannot be asked)
 
 // generic kernels (ttemb_generic.hip)
 int64_t generic_fwd_lds_bytes(const DevShape& s);

@@ -18,6 +18,7 @@
 #include "ttemb_common.h"
 #include "ttemb_cache.h"
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 
@@ -128,20 +129,24 @@ __device__ __forceinline__ uint4 load_desc(desc_ptr tab, uint32_t c, uint32_t nc
 // ---------------------------------------------------------------------------------
 // Grouping pass: a two-digit counting sort of the live ids by group' = i1 * p0 + i0, cut into chunks.
 //   value = output row | kMultiBit when the bag holds several ids.
-// ids of one (i0, i1) group end up adjacent, consecutive groups share i1.  No global atomics (one returning
-// atomic per id capped the first version at ~16 G ids/s = 25 us) and no device-wide scan.  The group space is cut
-// into ranges of 2^shift groups (first digit), the id list into slices:
-//   decode   every id -> (group, i2, row | multi); LDS histogram of the slice over the ranges       [one workgroup per slice]
-//   spread   every id moves to its range (ranges in order, slices in order inside a range):
-//            cursor[range] from the slices' histograms, one returning LDS atomic per id             [one workgroup per slice]
-//   count    LDS histogram of a range's ids over its groups, exclusive prefix of (ids, chunks)
-//            inside the range, range totals                                                         [one workgroup per range]
-//   place    every id takes its final position with one returning LDS atomic; the id that opens
-//            a chunk writes its descriptor                                                          [one workgroup per range]
+// ids of one (i0, i1) group end up adjacent, consecutive groups share i1.  THREE launches, no device-wide scan, no
+// counter that has to be cleared before the call (round 2: five launches, one of them a 4.5 us zero-fill of a few KB).
+// The group space is cut into ranges of 2^shift groups (first digit), the id list into slices:
+//   decode   every id -> (group, i2, row | multi); LDS histogram of the slice over the ranges, stored as the slice's row
+//            of a [slices][ranges] table (plain stores); the group is stamped with the call's epoch ("holds an id");
+//            the per-group counters are cleared for the next launch                                  [one workgroup per slice]
+//   spread   every id moves to its range (ranges in order, slices in order inside a range): cursor[range] = column sums
+//            of the histogram table (110 KB, L2), one returning LDS atomic per id; one fire-and-forget global atomic
+//            per id counts its group.  The prefix products of the stamped groups ride in this launch
+//            (they depend on nothing the grouping computes)                                          [one workgroup per slice]
+//   place    first position / first chunk of every group from the group counters (sum over the groups before the range
+//            + a scan inside it); every id takes its final position with one returning LDS atomic; the id that opens
+//            a chunk writes its descriptor                                                           [one workgroup per range]
 // A chunk is <= 16 consecutive ids of one group; its 16-byte descriptor {position, group, length | flags, first
 // chunk of the next group} is all the chain kernels need to walk the grouped ids -- they read descriptors with
-// scalar loads and never decode a key, compare neighbours or shuffle.  The order of ids inside a group is
-// arrival order: every consumer is insensitive to it except for fp32 summation order in the backward.
+// scalar loads and never decode a key, compare neighbours or shuffle.  The order of ids inside a group is slice
+// order, then arrival order inside a slice: every consumer is insensitive to it except for fp32 summation order in the
+// backward.
 // ---------------------------------------------------------------------------------
 constexpr int kSortThreads = 1024;       // decode / spread: one workgroup per slice of the id list
 #ifndef TTEMB_RANGE_THREADS
@@ -165,11 +170,10 @@ struct GroupPlan {           // device pointers into the caller's plan buffer / 
   uint32_t* grp_mid;         // [nnz] the same three, ordered by range
   uint32_t* i2_mid;
   uint32_t* vals_mid;
-  uint32_t* shist;           // [slices][ranges] place of slice s inside range r (arrival order of the slices)
-  uint32_t* rcount;          // [ranges] running / final id count of every range
+  uint16_t* shist;           // [slices][ranges] ids of slice s that fall into range r (a slice holds < 65 536 ids)
   uint32_t* rstart;          // [ranges + 1] first position of every range in the range-ordered arrays
-  uint64_t* lpre;            // [G] prefix of (ids | chunks << 32) inside the group's range
-  uint64_t* rtot;            // [2 * ranges] (ids | chunks << 32) of every range, then its number of non-empty groups
+  uint32_t* gstamp;          // [G] epoch of the last call that saw an id of the group (a stale or foreign word only ever
+                             //     adds a prefix product nobody reads: it needs no clearing and no initial state)
   uint32_t* i2s;             // [nnz] grouped: last index digit of the id
   uint32_t* vals;            // [nnz] grouped: output row | kMultiBit
   uint32_t* counts;          // [G+1] ids per group; entry G = number of groups that hold an id
@@ -224,9 +228,11 @@ __global__ __launch_bounds__(kSortThreads) void fast3_decode_kernel(
     const int64_t* __restrict__ indices, const int64_t* __restrict__ rowidx,
     const int64_t* __restrict__ offsets, uint32_t nnz, uint32_t per_slice,
     const int32_t* __restrict__ nnz_dev, int64_t B, int D, float* __restrict__ zero_out, uint32_t sentinel,
-    uint32_t p0, uint32_t p1, uint32_t p2, uint32_t shift, uint32_t ranges, GroupPlan plan) {
+    uint32_t p0, uint32_t p1, uint32_t p2, uint32_t shift, uint32_t ranges, uint32_t G, uint32_t epoch, GroupPlan plan) {
   __shared__ uint32_t hist[kMaxRanges];
   for (uint32_t i = threadIdx.x; i < ranges; i += kSortThreads) hist[i] = 0u;
+  // the per-group counters the spread step adds into (the launch after this one): every slice clears a share
+  for (uint32_t g = blockIdx.x * kSortThreads + threadIdx.x; g <= G; g += gridDim.x * kSortThreads) plan.counts[g] = 0u;
   __syncthreads();
   const int64_t cnt = live_count(nnz, nnz_dev);
   const uint32_t s0 = blockIdx.x * per_slice;
@@ -290,29 +296,55 @@ __global__ __launch_bounds__(kSortThreads) void fast3_decode_kernel(
       plan.grp_in[n] = group;
       plan.i2_in[n] = rem - i1 * p2;
       plan.vals_in[n] = (uint32_t)row | (multi ? kMultiBit : 0u);
+      plan.gstamp[group] = epoch;   // "this group holds an id" (every writer stores the same word)
       atomicAdd(&hist[group >> shift], 1u);
     }
   }
   __syncthreads();
-  // this slice's place inside every range: arrival order of the slices (one returning atomic per slice and range;
-  // rcount was cleared before the launch and ends up holding the ranges' totals)
-  uint32_t* dst = plan.shist + (size_t)blockIdx.x * ranges;
-  for (uint32_t i = threadIdx.x; i < ranges; i += kSortThreads) dst[i] = atomicAdd(&plan.rcount[i], hist[i]);
+  // the slice's row of the histogram table (plain stores: the spread step sums columns)
+  uint16_t* dst = plan.shist + (size_t)blockIdx.x * ranges;
+  for (uint32_t i = threadIdx.x; i < ranges; i += kSortThreads) dst[i] = (uint16_t)hist[i];
 }
 
-__global__ __launch_bounds__(kSortThreads) void fast3_spread_kernel(uint32_t nnz, uint32_t per_slice, uint32_t shift,
-                                                                   uint32_t ranges, GroupPlan plan) {
-  __shared__ uint32_t cursor[kMaxRanges];
-  __shared__ uint32_t wave_sums[kSortThreads / kWave];
-  const uint32_t s = blockIdx.x;
-  // cursor[r] = ids of earlier ranges + this slice's place inside the range  (ranges <= kMaxRanges <= threads)
-  const uint32_t tot = threadIdx.x < ranges ? plan.rcount[threadIdx.x] : 0u;
-  const uint32_t mine = threadIdx.x < ranges ? plan.shist[(size_t)s * ranges + threadIdx.x] : 0u;
+// One slice of the spread step.  cursor[r] = ids of the ranges before r + ids of the slices before this one in r: both are
+// column sums of the [slices][ranges] histogram table, which every workgroup forms for itself (<= 1024 x 512 uint16: 110 KB
+// at 409 600 ids on the products table, L2-resident; ~1.5 us per workgroup against the launch + the returning global
+// atomics of a shared counter array that would also have to be cleared per call).
+__device__ __forceinline__ void spread_slice(uint32_t s, uint32_t slices, uint32_t nnz, uint32_t per_slice, uint32_t shift,
+                                             uint32_t ranges, const GroupPlan& plan, uint32_t* cursor, uint32_t* part,
+                                             uint32_t* wave_sums) {
+  // rp = ranges rounded up to a power of two (>= 64); thread t sums column t % rp over the slices t / rp, t / rp + L, ...
+  uint32_t rp = 64;
+  while (rp < ranges) rp <<= 1;
+  const uint32_t L = kSortThreads / rp, r = threadIdx.x & (rp - 1), k = threadIdx.x / rp;
+  uint32_t before = 0, total = 0;
+  if (r < ranges) {
+    constexpr int U = 8;   // loads in flight per thread
+    for (uint32_t s2 = k; s2 < slices; s2 += L * U) {
+      uint32_t v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = s2 + u * L < slices ? (uint32_t)plan.shist[(size_t)(s2 + u * L) * ranges + r] : 0u;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        total += v[u];
+        before += s2 + u * L < s ? v[u] : 0u;
+      }
+    }
+  }
+  part[threadIdx.x] = before;
+  part[kSortThreads + threadIdx.x] = total;
+  __syncthreads();
+  uint32_t bef = 0, tot = 0;
+  if (threadIdx.x < ranges)
+    for (uint32_t j = 0; j < L; ++j) {
+      bef += part[j * rp + threadIdx.x];
+      tot += part[kSortThreads + j * rp + threadIdx.x];
+    }
   uint32_t all;
-  const uint32_t before = block_exclusive<uint32_t, kSortThreads>(tot, wave_sums, all);
+  const uint32_t excl = block_exclusive<uint32_t, kSortThreads>(tot, wave_sums, all);
   if (threadIdx.x < ranges) {
-    cursor[threadIdx.x] = before + mine;
-    if (s == 0) plan.rstart[threadIdx.x] = before;
+    cursor[threadIdx.x] = excl + bef;
+    if (s == 0) plan.rstart[threadIdx.x] = excl;
   }
   if (s == 0 && threadIdx.x == 0) plan.rstart[ranges] = all;
   __syncthreads();
@@ -335,8 +367,9 @@ __global__ __launch_bounds__(kSortThreads) void fast3_spread_kernel(uint32_t nnz
 #pragma unroll
     for (int u = 0; u < kSortBatch; ++u) {
       if (g[u] == kNoGroup) continue;
+      atomicAdd(&plan.counts[g[u]], 1u);   // result unused: a fire-and-forget global atomic (cleared by the decode step)
       const uint32_t dst = atomicAdd(&cursor[g[u] >> shift], 1u);
-      if (dst >= nnz) continue;   // cannot happen with consistent counters; a stale counter must not become a wild store
+      if (dst >= nnz) continue;   // cannot happen with a consistent table; a bad counter must not become a wild store
       plan.grp_mid[dst] = g[u];
       plan.i2_mid[dst] = i2v[u];
       plan.vals_mid[dst] = vv[u];
@@ -344,98 +377,87 @@ __global__ __launch_bounds__(kSortThreads) void fast3_spread_kernel(uint32_t nnz
   }
 }
 
-__global__ __launch_bounds__(kRangeThreads) void fast3_count_kernel(uint32_t G, uint32_t shift, GroupPlan plan) {
-  extern __shared__ uint32_t hist[];   // [span]
-  __shared__ uint64_t wave_sums[kRangeThreads / kWave];
-  const uint32_t span = 1u << shift;
-  const uint32_t g0 = blockIdx.x << shift;
-  const uint32_t n0 = plan.rstart[blockIdx.x], n1 = plan.rstart[blockIdx.x + 1];
-  for (uint32_t i = threadIdx.x; i < span; i += kRangeThreads) hist[i] = 0u;
-  __syncthreads();
-  for (uint32_t base = n0 + threadIdx.x; base < n1; base += kRangeThreads * kSortBatch) {
-    uint32_t g[kSortBatch];
-#pragma unroll
-    for (int u = 0; u < kSortBatch; ++u) {
-      const uint32_t n = base + u * kRangeThreads;
-      g[u] = n < n1 ? plan.grp_mid[n] : kNoGroup;
-    }
-#pragma unroll
-    for (int u = 0; u < kSortBatch; ++u)
-      if (g[u] != kNoGroup) atomicAdd(&hist[g[u] - g0], 1u);
-  }
-  __syncthreads();
-  uint64_t carry = 0;
-  uint32_t live_groups = 0;
-  for (uint32_t base = 0; base < span; base += kRangeThreads) {
-    const uint32_t i = base + threadIdx.x;
-    const uint32_t c = i < span ? hist[i] : 0u;
-    uint64_t total;
-    const uint64_t pre = block_exclusive<uint64_t, kRangeThreads>(i < span ? pack_count(c) : 0ull, wave_sums, total);
-    if (i < span && g0 + i < G) {
-      plan.counts[g0 + i] = c;
-      plan.lpre[g0 + i] = carry + pre;
-    }
-    carry += total;
-    live_groups += (uint32_t)__syncthreads_count(c != 0u);
-  }
-  if (threadIdx.x == 0) {
-    plan.rtot[blockIdx.x] = carry;
-    plan.rtot[gridDim.x + blockIdx.x] = live_groups;   // second half of the array: non-empty groups of the range
-  }
+__global__ __launch_bounds__(kSortThreads) void fast3_spread_kernel(uint32_t nnz, uint32_t per_slice, uint32_t shift,
+                                                                   uint32_t ranges, GroupPlan plan) {
+  __shared__ uint32_t cursor[kMaxRanges];
+  __shared__ uint32_t part[2 * kSortThreads];
+  __shared__ uint32_t wave_sums[kSortThreads / kWave];
+  spread_slice(blockIdx.x, gridDim.x, nnz, per_slice, shift, ranges, plan, cursor, part, wave_sums);
 }
 
+// The place step of one range.  Group counters are complete (spread step); the range's first position / first chunk is the
+// sum of (ids | chunks << 32) over every group before it -- up to G words (70 KB on the products table) read by each of
+// the <= 512 workgroups, instead of a separate count launch and its range totals.
 __device__ __forceinline__ void place_range(const uint32_t range, const uint32_t ranges, uint32_t G, uint32_t shift,
                                             uint32_t nnz, uint32_t max_chunks, const GroupPlan& plan, uint32_t* lds_s,
-                                            uint64_t& range_base) {
-  // lds_s: [span] cursor | [span] first position | [span] count | [span] first chunk
+                                            uint64_t* red) {
+  // lds_s: [span] cursor | [span] first position | [span] count | [span] first chunk;  red: [kRangeThreads / 64 + 1] x 2
   const uint32_t span = 1u << shift;
   const uint32_t g0 = range << shift;
   uint32_t* cursor = lds_s;
   uint32_t* gfirst = cursor + span;
   uint32_t* gcount = gfirst + span;
   uint32_t* gchunk = gcount + span;
-  if (threadIdx.x < kWave) {   // (ids, chunks) of the ranges before this one
-    uint64_t v = 0;
-    uint32_t live_groups = 0;
-    // all loads of the lane first (ranges <= kMaxRanges = 8 * 64), then the sums: a running sum would wait for
-    // every load before issuing the next
-    uint64_t tv[kMaxRanges / kWave], lv[kMaxRanges / kWave];
+  constexpr int NWV = kRangeThreads / kWave;
+  uint64_t acc = 0;
+  uint32_t live = 0;
+  {
+    constexpr int U = 16;   // loads in flight per thread: the last ranges read ~G words, two or three round trips
+    for (uint32_t g = threadIdx.x; g < g0; g += kRangeThreads * U) {
+      uint32_t c[U];
 #pragma unroll
-    for (int k = 0; k < kMaxRanges / kWave; ++k) {
-      const uint32_t r = threadIdx.x + k * kWave;
-      tv[k] = r < range ? plan.rtot[r] : 0ull;
-      lv[k] = (range == ranges - 1 && r < range) ? plan.rtot[ranges + r] : 0ull;
-    }
+      for (int u = 0; u < U; ++u) c[u] = g + u * kRangeThreads < g0 ? plan.counts[g + u * kRangeThreads] : 0u;
 #pragma unroll
-    for (int k = 0; k < kMaxRanges / kWave; ++k) {
-      v += tv[k];
-      live_groups += (uint32_t)lv[k];
+      for (int u = 0; u < U; ++u) {
+        acc += pack_count(c[u]);
+        live += c[u] != 0u ? 1u : 0u;
+      }
     }
 #pragma unroll
     for (int d = kWave / 2; d > 0; d >>= 1) {
-      const uint32_t lo_w = __shfl_down((uint32_t)v, d, kWave), hi_w = __shfl_down((uint32_t)(v >> 32), d, kWave);
-      v += (uint64_t)lo_w | ((uint64_t)hi_w << 32);
-      live_groups += __shfl_down(live_groups, d, kWave);
+      const uint32_t lo_w = __shfl_down((uint32_t)acc, d, kWave), hi_w = __shfl_down((uint32_t)(acc >> 32), d, kWave);
+      acc += (uint64_t)lo_w | ((uint64_t)hi_w << 32);
+      live += __shfl_down(live, d, kWave);
     }
+    if ((threadIdx.x & 63) == 0) {
+      red[threadIdx.x >> 6] = acc;
+      red[NWV + 1 + (threadIdx.x >> 6)] = live;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
-      range_base = v;
-      // how many groups hold an id at all: the backward's epilogue / finalize pick their sparse or dense form by it
-      if (range == ranges - 1) plan.counts[G] = live_groups + (uint32_t)plan.rtot[ranges + range];
+      uint64_t a = 0, l = 0;
+      for (int w = 0; w < NWV; ++w) {
+        a += red[w];
+        l += red[NWV + 1 + w];
+      }
+      red[NWV] = a;
+      red[2 * NWV + 1] = l;
     }
+    __syncthreads();
   }
-  __syncthreads();
-  const uint64_t base = range_base;
-  for (uint32_t i = threadIdx.x; i < span; i += kRangeThreads) {
-    const uint32_t g = g0 + i;
-    if (g < G) {
-      const uint64_t pre = base + plan.lpre[g];
+  const uint64_t base = red[NWV];
+  uint64_t carry = 0;
+  uint32_t live_here = 0;
+  for (uint32_t b0 = 0; b0 < span; b0 += kRangeThreads) {
+    const uint32_t i = b0 + threadIdx.x;
+    const bool on = i < span && g0 + i < G;
+    const uint32_t c = on ? plan.counts[g0 + i] : 0u;
+    uint64_t total;
+    const uint64_t pre = base + carry + block_exclusive<uint64_t, kRangeThreads>(pack_count(c), red, total);
+    if (on) {
       gfirst[i] = cursor[i] = (uint32_t)pre;
-      gcount[i] = plan.counts[g];
+      gcount[i] = c;
       gchunk[i] = (uint32_t)(pre >> 32);
-      plan.gpre[g] = pre;
+      plan.gpre[g0 + i] = pre;
     }
+    carry += total;
+    live_here += (uint32_t)__syncthreads_count(c != 0u);
   }
-  if (range == ranges - 1 && threadIdx.x == 0) plan.gpre[G] = base + plan.rtot[range];   // (live ids, chunks)
+  if (range == ranges - 1 && threadIdx.x == 0) {
+    plan.gpre[G] = base + carry;   // (live ids, chunks)
+    // how many groups hold an id at all: the backward's epilogue / finalize pick their sparse or dense form by it
+    plan.counts[G] = (uint32_t)red[2 * NWV + 1] + live_here;
+  }
   __syncthreads();
   const uint32_t n0 = plan.rstart[range], n1 = plan.rstart[range + 1];
   for (uint32_t b0 = n0 + threadIdx.x; b0 < n1; b0 += kRangeThreads * kSortBatch) {
@@ -450,7 +472,7 @@ __device__ __forceinline__ void place_range(const uint32_t range, const uint32_t
     }
 #pragma unroll
     for (int u = 0; u < kSortBatch; ++u) {
-      if (gl[u] == kNoGroup) continue;
+      if (gl[u] >= span) continue;   // (kNoGroup, or a word that is not of this range: never trust a table with an LDS address)
       const uint32_t dst = atomicAdd(&cursor[gl[u]], 1u);
       if (dst >= nnz) continue;   // as in the spread step: never trust a counter with an address
       plan.i2s[dst] = i2v[u];
@@ -470,8 +492,8 @@ __device__ __forceinline__ void place_range(const uint32_t range, const uint32_t
 __global__ __launch_bounds__(kRangeThreads) void fast3_place_kernel(uint32_t nnz, uint32_t max_chunks, uint32_t G, uint32_t shift,
                                                                     GroupPlan plan) {
   extern __shared__ uint32_t lds_s[];
-  __shared__ uint64_t range_base;
-  place_range(blockIdx.x, gridDim.x, G, shift, nnz, max_chunks, plan, lds_s, range_base);
+  __shared__ uint64_t red[2 * (kRangeThreads / kWave + 1)];
+  place_range(blockIdx.x, gridDim.x, G, shift, nnz, max_chunks, plan, lds_s, red);
 }
 
 // ---------------------------------------------------------------------------------
@@ -488,7 +510,7 @@ __global__ __launch_bounds__(kRangeThreads) void fast3_place_kernel(uint32_t nnz
 constexpr int kPrefixGroups = TTEMB_PREFIX_GROUPS;   // values of i0 per wavefront
 template <int Q0, int Q1, int Q2, int R1, int R2>
 __device__ __forceinline__ void prefix_unit(const float* __restrict__ G0, const float* __restrict__ G1, uint32_t p0,
-                                            const GroupPlan& plan, uint32_t i0_block, uint32_t i1, int lane) {
+                                            const GroupPlan& plan, uint32_t i0_block, uint32_t i1, int lane, uint32_t epoch) {
   using C = Cfg<Q0, Q1, Q2, R1, R2>;
   constexpr int GM = 16 / Q0;  // whole groups per 16-row MFMA tile (q0 = 5: three groups, the last tile row idles)
   const int hi = lane >> 4, lo = lane & 15;
@@ -496,7 +518,10 @@ __device__ __forceinline__ void prefix_unit(const float* __restrict__ G0, const 
   const uint32_t i0_end = i0_begin + kPrefixGroups < p0 ? i0_begin + kPrefixGroups : p0;
   // any work at all?  (one lane per i0 of the slice)
   const uint32_t my = i0_begin + lane;
-  const bool mine = lane < kPrefixGroups && my < i0_end && plan.counts[i1 * p0 + my] != 0;
+  // which groups hold an id: their counters when the grouping is complete (epoch 0), else the stamps the decode step of
+  // this call left (the unit then runs next to the spread step, before the counters exist)
+  const bool mine = lane < kPrefixGroups && my < i0_end &&
+                    (epoch != 0u ? plan.gstamp[i1 * p0 + my] == epoch : plan.counts[i1 * p0 + my] != 0u);
   const unsigned long long live = __ballot(mine);
   if (!live) return;
   const float* g1 = G1 + (size_t)i1 * C::ROW1;
@@ -539,29 +564,39 @@ __device__ __forceinline__ void prefix_unit(const float* __restrict__ G0, const 
 
 template <int Q0, int Q1, int Q2, int R1, int R2>
 __global__ __launch_bounds__(64) void fast3_prefix_kernel(const float* __restrict__ G0, const float* __restrict__ G1,
-                                                          uint32_t p0, GroupPlan plan) {
-  prefix_unit<Q0, Q1, Q2, R1, R2>(G0, G1, p0, plan, blockIdx.x, blockIdx.y, (int)threadIdx.x);
+                                                          uint32_t p0, uint32_t epoch, GroupPlan plan) {
+  prefix_unit<Q0, Q1, Q2, R1, R2>(G0, G1, p0, plan, blockIdx.x, blockIdx.y, (int)threadIdx.x, epoch);
 }
 
-// The last grouping step and the prefix products in one launch (both only need the group counts): workgroups
-// [0, ranges) place their range, the rest take kRangeThreads / 64 prefix units each -- two latency-bound kernels
-// share the machine instead of queueing.
+// Does the prefix unit fit the 128 registers of a 1024-thread workgroup next to the spread step?  At rank 32 the G1 row a
+// unit keeps as B operands is 64-80 registers: q = 4,5,5 / 5,5,4 / 4,4,8 spilled 20-72 bytes per lane there (q = 8,4,4 --
+// the papers100M shape -- has room).  Those shapes launch their prefix products between the decode and the spread step.
 template <int Q0, int Q1, int Q2, int R1, int R2>
-__global__ __launch_bounds__(kRangeThreads) void fast3_place_prefix_kernel(uint32_t ranges, uint32_t G, uint32_t shift,
-                                                                          uint32_t nnz, uint32_t max_chunks,
+struct PrefixRides {
+  static constexpr bool value = R1 < 32 || Q0 >= 8;
+};
+
+// The spread step and the prefix products in one launch (the products need the cores and the decode step's stamps, nothing
+// the grouping computes later): workgroups [0, slices) spread their slice, the rest take kSortThreads / 64 prefix units
+// each -- two latency-bound kernels share the machine instead of queueing.
+template <int Q0, int Q1, int Q2, int R1, int R2>
+__global__ __launch_bounds__(kSortThreads) void fast3_spread_prefix_kernel(uint32_t slices, uint32_t nnz, uint32_t per_slice,
+                                                                          uint32_t shift, uint32_t ranges, uint32_t epoch,
                                                                           const float* __restrict__ G0,
                                                                           const float* __restrict__ G1, uint32_t p0,
                                                                           uint32_t p1, GroupPlan plan) {
-  extern __shared__ uint32_t lds_s[];
-  __shared__ uint64_t range_base;
-  if (blockIdx.x < ranges) {
-    place_range(blockIdx.x, ranges, G, shift, nnz, max_chunks, plan, lds_s, range_base);
+  __shared__ uint32_t cursor[kMaxRanges];
+  __shared__ uint32_t part[2 * kSortThreads];
+  __shared__ uint32_t wave_sums[kSortThreads / kWave];
+  if (blockIdx.x < slices) {
+    spread_slice(blockIdx.x, slices, nnz, per_slice, shift, ranges, plan, cursor, part, wave_sums);
     return;
   }
   const uint32_t blocks0 = (p0 + kPrefixGroups - 1) / kPrefixGroups;
-  const uint32_t unit = (blockIdx.x - ranges) * (kRangeThreads / kWave) + (threadIdx.x >> 6);
+  const uint32_t unit = (blockIdx.x - slices) * (kSortThreads / kWave) + (threadIdx.x >> 6);
   if (unit >= blocks0 * p1) return;
-  prefix_unit<Q0, Q1, Q2, R1, R2>(G0, G1, p0, plan, unit % blocks0, unit / blocks0, (int)(threadIdx.x & 63));
+  if constexpr (PrefixRides<Q0, Q1, Q2, R1, R2>::value)
+    prefix_unit<Q0, Q1, Q2, R1, R2>(G0, G1, p0, plan, unit % blocks0, unit / blocks0, (int)(threadIdx.x & 63), epoch);
 }
 
 // ---------------------------------------------------------------------------------
@@ -841,6 +876,12 @@ static_assert(kFuseQuads % kFuseBatch == 0, "quads are handled in whole batches"
 // have registers for half as many slab quads again, which is what a wide row (r2 q2 = 128: two rows per register quad
 // across the lanes) needs to keep 140 slab rows in four wavefronts (q = 4,4,8 at rank 16, the arxiv shape of the scripts).
 constexpr int fuse_quads(int m2, int row2) { return (m2 <= 16 && row2 >= 128) ? kFuseQuads + kFuseBatch : kFuseQuads; }
+// Which (q, rank) shapes have a fused form at all (the rest of the rule -- p2 against the register quads, the CU's LDS --
+// depends on the table and is checked per call by fused_dg2()): rank <= 16 (at rank 32 operands + slab rows spill), and
+// at least two slab rows side by side in a wavefront (a row of r2 q2 > 128 floats takes more than half the lanes: one row
+// per register quad, and the kernel spilled 176-208 bytes per lane on the lifted 2-core shapes q = 8,16 / 10,10).
+// FUSE = true is instantiated for these shapes only.
+constexpr bool fuse_shape(int r2, int row2) { return r2 <= 16 && row2 % 4 == 0 && row2 / 4 <= kWave / 2; }
 
 template <int Q0, int Q1, int Q2, int R1, int R2, bool FUSE>
 __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / kFuseWaves : 1) void fast3_bwd_chunk_kernel(
@@ -1897,7 +1938,8 @@ bool fast3_fits(const DevShape& s, int64_t nnz, int64_t B) {
   const int64_t lim = int64_t(1) << 31;   // an offset of 2 GiB marks "no row" in the chain kernels (kOobBase)
   return B * s.D * 4 < lim && B < (int64_t(1) << 24) && (wide(s) || nnz * (int64_t)s.row_len[2] * 4 < lim) &&
          num_groups(s) * (int64_t)s.q[0] * s.q[1] * s.R[2] * 4 < lim && s.p[2] <= 4096 && s.p[1] < 65536 &&
-         num_groups(s) <= (int64_t)kMaxRanges * 4096;   // the grouping pass: <= 512 ranges of <= 4096 groups (64 KB of LDS)
+         num_groups(s) <= (int64_t)kMaxRanges * 4096 &&   // the grouping pass: <= 512 ranges of <= 4096 groups (64 KB of LDS),
+         nnz <= (int64_t)kMaxSlices * 0xffff;             // <= 1024 slices of < 65 536 ids (uint16 histogram table)
 }
 
 #ifndef TTEMB_ROWS_B
@@ -1927,29 +1969,9 @@ static bool shared_slab(const DevShape& s) { return (int64_t)s.p[2] * s.row_len[
 #define TTEMB_FWD_WGS 4
 #endif
 constexpr int kBwdWgsPerCu = TTEMB_BWD_WGS, kFwdWgsPerCu = TTEMB_FWD_WGS;
-constexpr size_t kCuLds = 160 * 1024;
-static int chain_cus() {   // CUs of the current device (256 on MI355X; also the answer when no device can be asked)
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-      cus = n;
-    else
-      cus = 256;
-  }
-  return cus;
-}
-static int allow_lds(const void* kernel, size_t lds, bool* lds_allowed) {
-  if (lds > kCuLds) return fail(TTEMB_E_UNSUPPORTED, "chain kernel needs %lld bytes of LDS per workgroup", (long long)lds);
-  if (lds > 64 * 1024 && !*lds_allowed) {
-    int rc = check_hip(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCuLds), "hipFuncSetAttribute");
-    if (rc) return rc;
-    *lds_allowed = true;
-  }
-  return TTEMB_OK;
-}
-static int chain_grid(const void* kernel, size_t lds, int wgs_per_cu, bool* lds_allowed, unsigned* grid) {
-  int rc = allow_lds(kernel, lds, lds_allowed);
+static int chain_cus() { return device_cus(); }
+static int chain_grid(const void* kernel, size_t lds, int wgs_per_cu, LdsGate* gate, unsigned* grid) {
+  int rc = allow_big_lds(kernel, lds, gate, "chain kernel");
   if (rc) return rc;
   int fit = (int)(kCuLds / (lds ? lds : 1));
   if (fit > wgs_per_cu) fit = wgs_per_cu;
@@ -1974,8 +1996,7 @@ static bool fused_dg2(const DevShape& s) {
   return false;
 #endif
   const int lpr = s.row_len[2] / 4;
-  if (lpr < 1 || lpr > kWave) return false;
-  if (s.R[2] > 16) return false;   // at rank 32 the fused kernel's registers (operands + slab rows) no longer fit two waves per SIMD
+  if (lpr < 1 || !fuse_shape(s.R[2], s.row_len[2])) return false;   // (the shapes FUSE = true is compiled for)
   const int gpw = kWave / lpr;
   const int fq = fuse_quads(s.q[0] * s.q[1], s.row_len[2]);
   if (s.p[2] > kFuseWaves * gpw * fq) return false;
@@ -2057,11 +2078,9 @@ static int64_t carve_workspace(const DevShape& s, int64_t nnz, bool bwd, bool pl
   if (need_grouping) {
     uint32_t* in[6];
     for (int i = 0; i < 6; ++i) in[i] = (uint32_t*)take(nnz * 4);
-    uint32_t* sh = (uint32_t*)take((int64_t)sort_slices(nnz) * sort_ranges(G) * 4);
+    uint16_t* sh = (uint16_t*)take((int64_t)sort_slices(nnz) * sort_ranges(G) * 2);
     uint32_t* rs = (uint32_t*)take((sort_ranges(G) + 1) * 4);
-    uint32_t* rc = (uint32_t*)take(sort_ranges(G) * 4);
-    uint64_t* lp = (uint64_t*)take(G * 8);
-    uint64_t* rt = (uint64_t*)take(sort_ranges(G) * 16);
+    uint32_t* gs = (uint32_t*)take(G * 4);
     if (pl) {
       pl->grp_in = in[0];
       pl->i2_in = in[1];
@@ -2071,9 +2090,7 @@ static int64_t carve_workspace(const DevShape& s, int64_t nnz, bool bwd, bool pl
       pl->vals_mid = in[5];
       pl->shist = sh;
       pl->rstart = rs;
-      pl->rcount = rc;
-      pl->lpre = lp;
-      pl->rtot = rt;
+      pl->gstamp = gs;
     }
   }
   if (wide(s)) {   // the lists of non-empty rows the compacted GEMMs walk (rebuilt from the plan's counts by every call)
@@ -2110,8 +2127,18 @@ int64_t fast3_workspace_bytes(const DevShape& s, int32_t op, int64_t nnz, int64_
 
 // fill plan->{i2s, vals, counts, gpre, ctab} from the ids
 static int run_prefix(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, hipStream_t st);
-static int run_place_prefix(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int64_t nnz, int ranges, int shift,
-                            hipStream_t st);
+static int run_spread_prefix(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int64_t nnz, int slices, uint32_t per_slice,
+                             int ranges, int shift, uint32_t epoch, hipStream_t st);
+
+// A word no earlier call of this process has used (0 is "no stamps"): the decode step marks the groups that hold an id with it.
+// Whatever else the stamp array holds -- a fresh allocation, another table's stamps, those of the same call replayed from a
+// captured graph -- can at worst make the prefix kernel compute a product for a group without ids.
+static uint32_t next_epoch() {
+  static std::atomic<uint32_t> counter{0};
+  uint32_t e = counter.fetch_add(1u, std::memory_order_relaxed) + 1u;
+  if (e == 0u) e = counter.fetch_add(1u, std::memory_order_relaxed) + 1u;
+  return e;
+}
 
 static int group_ids(const DevShape& s, const CorePtrs& cores, const int64_t* indices, const int64_t* rowidx,
                      const int64_t* offsets, int64_t nnz, const int32_t* nnz_dev, int64_t B, float* zero_out,
@@ -2122,26 +2149,25 @@ static int group_ids(const DevShape& s, const CorePtrs& cores, const int64_t* in
   const uint32_t per_slice = (uint32_t)((nnz + slices - 1) / slices);
   const size_t span = (size_t)1 << shift;
   if (ranges > kMaxRanges || span * 16 > 64 * 1024) return fail(TTEMB_E_UNSUPPORTED, "too many (i0, i1) groups for the grouping pass");
-  int rc = launch_zero(plan->rcount, (size_t)ranges * 4, st, "zero range counters");   // never hipMemsetAsync: see launch_zero
-  if (rc) return rc;
+  if (per_slice > 0xffffu) return fail(TTEMB_E_UNSUPPORTED, "too many ids for the grouping pass (a slice holds < 65 536)");
+  const uint32_t epoch = next_epoch();
   hipLaunchKernelGGL(fast3_decode_kernel, dim3((unsigned)slices), dim3(kSortThreads), 0, st, indices, rowidx, offsets,
                      (uint32_t)nnz, per_slice, nnz_dev, B, s.D, zero_out, sentinel, (uint32_t)s.p[0], (uint32_t)s.p[1],
-                     (uint32_t)s.p[2], (uint32_t)shift, (uint32_t)ranges, *plan);
-  rc = check_hip(hipGetLastError(), "fast3_decode_kernel");
+                     (uint32_t)s.p[2], (uint32_t)shift, (uint32_t)ranges, (uint32_t)G, epoch, *plan);
+  int rc = check_hip(hipGetLastError(), "fast3_decode_kernel");
   if (rc) return rc;
-  hipLaunchKernelGGL(fast3_spread_kernel, dim3((unsigned)slices), dim3(kSortThreads), 0, st, (uint32_t)nnz, per_slice,
-                     (uint32_t)shift, (uint32_t)ranges, *plan);
-  rc = check_hip(hipGetLastError(), "fast3_spread_kernel");
+  if (with_prefix && !wide(s)) {
+    rc = run_spread_prefix(s, cores, *plan, nnz, slices, per_slice, ranges, shift, epoch, st);
+  } else {
+    hipLaunchKernelGGL(fast3_spread_kernel, dim3((unsigned)slices), dim3(kSortThreads), 0, st, (uint32_t)nnz, per_slice,
+                       (uint32_t)shift, (uint32_t)ranges, *plan);
+    rc = check_hip(hipGetLastError(), "fast3_spread_kernel");
+  }
   if (rc) return rc;
-  hipLaunchKernelGGL(fast3_count_kernel, dim3((unsigned)ranges), dim3(kRangeThreads), span * 4, st, (uint32_t)G, (uint32_t)shift,
-                     *plan);
-  rc = check_hip(hipGetLastError(), "fast3_count_kernel");
-  if (rc) return rc;
-  if (with_prefix && !wide(s)) return run_place_prefix(s, cores, *plan, nnz, ranges, shift, st);
   hipLaunchKernelGGL(fast3_place_kernel, dim3((unsigned)ranges), dim3(kRangeThreads), span * 16, st, (uint32_t)nnz,
                      (uint32_t)max_chunks(s, nnz), (uint32_t)G, (uint32_t)shift, *plan);
   rc = check_hip(hipGetLastError(), "fast3_place_kernel");
-  if (rc == TTEMB_OK && with_prefix) rc = run_prefix(s, cores, *plan, st);   // wide ranks: the prefix products are a GEMM of their own
+  if (rc == TTEMB_OK && with_prefix && wide(s)) rc = run_prefix(s, cores, *plan, st);   // wide ranks: the prefix products are a GEMM of their own
   return rc;
 }
 
@@ -2175,7 +2201,7 @@ template <int Q0, int Q1, int Q2, int R1, int R2>
 static int run_prefix_t(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, hipStream_t st) {
   hipLaunchKernelGGL((fast3_prefix_kernel<Q0, Q1, Q2, R1, R2>),
                      dim3((unsigned)((s.p[0] + kPrefixGroups - 1) / kPrefixGroups), (unsigned)s.p[1]), dim3(64), 0, st,
-                     cores.c[0], cores.c[1], (uint32_t)s.p[0], plan);
+                     cores.c[0], cores.c[1], (uint32_t)s.p[0], 0u, plan);   // (epoch 0: on the counters of a complete grouping)
   return check_hip(hipGetLastError(), "fast3_prefix_kernel");
 }
 
@@ -2229,20 +2255,28 @@ static int run_prefix(const DevShape& s, const CorePtrs& cores, const GroupPlan&
 }
 
 template <int Q0, int Q1, int Q2, int R1, int R2>
-static int run_place_prefix_t(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int64_t nnz, int ranges, int shift,
-                              hipStream_t st) {
-  const unsigned units = (unsigned)((s.p[0] + kPrefixGroups - 1) / kPrefixGroups) * (unsigned)s.p[1];
-  const unsigned per_wg = kRangeThreads / kWave;
-  hipLaunchKernelGGL((fast3_place_prefix_kernel<Q0, Q1, Q2, R1, R2>), dim3((unsigned)ranges + (units + per_wg - 1) / per_wg),
-                     dim3(kRangeThreads), ((size_t)16 << shift), st, (uint32_t)ranges, (uint32_t)num_groups(s), (uint32_t)shift,
-                     (uint32_t)nnz, (uint32_t)max_chunks(s, nnz), cores.c[0], cores.c[1], (uint32_t)s.p[0], (uint32_t)s.p[1], plan);
-  return check_hip(hipGetLastError(), "fast3_place_prefix_kernel");
+static int run_spread_prefix_t(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int64_t nnz, int slices,
+                               uint32_t per_slice, int ranges, int shift, uint32_t epoch, hipStream_t st) {
+  unsigned units = (unsigned)((s.p[0] + kPrefixGroups - 1) / kPrefixGroups) * (unsigned)s.p[1];
+  const unsigned per_wg = kSortThreads / kWave;
+  if constexpr (!PrefixRides<Q0, Q1, Q2, R1, R2>::value) {   // a launch of its own, on this call's stamps
+    hipLaunchKernelGGL((fast3_prefix_kernel<Q0, Q1, Q2, R1, R2>),
+                       dim3((unsigned)((s.p[0] + kPrefixGroups - 1) / kPrefixGroups), (unsigned)s.p[1]), dim3(64), 0, st,
+                       cores.c[0], cores.c[1], (uint32_t)s.p[0], epoch, plan);
+    int rc = check_hip(hipGetLastError(), "fast3_prefix_kernel");
+    if (rc) return rc;
+    units = 0;
+  }
+  hipLaunchKernelGGL((fast3_spread_prefix_kernel<Q0, Q1, Q2, R1, R2>), dim3((unsigned)slices + (units + per_wg - 1) / per_wg),
+                     dim3(kSortThreads), 0, st, (uint32_t)slices, (uint32_t)nnz, per_slice, (uint32_t)shift, (uint32_t)ranges, epoch,
+                     cores.c[0], cores.c[1], (uint32_t)s.p[0], (uint32_t)s.p[1], plan);
+  return check_hip(hipGetLastError(), "fast3_spread_prefix_kernel");
 }
 
-static int run_place_prefix(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int64_t nnz, int ranges, int shift,
-                            hipStream_t st) {
+static int run_spread_prefix(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int64_t nnz, int slices, uint32_t per_slice,
+                             int ranges, int shift, uint32_t epoch, hipStream_t st) {
   if (classify(s)) {
-#define TTEMB_X(a, b, c, d, e) if (shape_is(s, a, b, c, d, e)) return run_place_prefix_t<a, b, c, d, e>(s, cores, plan, nnz, ranges, shift, st);
+#define TTEMB_X(a, b, c, d, e) if (shape_is(s, a, b, c, d, e)) return run_spread_prefix_t<a, b, c, d, e>(s, cores, plan, nnz, slices, per_slice, ranges, shift, epoch, st);
     TTEMB_FAST3_SHAPES(TTEMB_X)
 #undef TTEMB_X
   }
@@ -2261,7 +2295,7 @@ static int run_forward(const DevShape& s, const CorePtrs& cores, const GroupPlan
   if constexpr (DirectCfg<Q0, Q1, Q2, R1, R2>::ok) return run_forward_direct<Q0, Q1, Q2, R1, R2>(s, cores, plan, nnz, B, output, st);
 #endif
   const size_t lds = (size_t)kChainWaves * C::WAVE_FLOATS * sizeof(float);
-  static bool lds_ok = false;
+  static LdsGate lds_ok;
   unsigned grid = 0;
   int rc = chain_grid(reinterpret_cast<const void*>(fast3_forward_kernel<Q0, Q1, Q2, R1, R2>), lds, kFwdWgsPerCu, &lds_ok, &grid);
   if (rc) return rc;
@@ -2389,23 +2423,29 @@ static int run_backward(const DevShape& s, const CorePtrs& cores, const GroupPla
   profile_begin(1, st);
   int rc;
   constexpr size_t wave_lds = (size_t)(C::PB_FLOATS + C::BB2_FLOATS + C::OB_FLOATS) * sizeof(float);
-  const bool fused = fused_dg2(s);
+  constexpr bool kCanFuse = fuse_shape(R2, C::ROW2);
+  const bool fused = kCanFuse && fused_dg2(s);
+  if constexpr (!kCanFuse) {
+    if (fused_dg2(s)) return fail(TTEMB_E_HIP, "internal: fused_dg2() and fuse_shape() out of step");
+  }
   if (fused) {   // chunk products and the dG2 reduction in one launch
     if (wave_lds != bwd_wave_lds_floats(s) * sizeof(float)) return fail(TTEMB_E_HIP, "internal: LDS size formula out of step");
     const size_t lds = kFuseWaves * (wave_lds + kChunk * C::ROW2 * sizeof(float)) +
                        (size_t)(C::ROW2 + kFuseWaves * (1 + 32 * kFuseSub) + 3 + kFuseWaves * (kWave / (C::ROW2 / 4)) * fuse_quads(C::M2, C::ROW2)) * sizeof(uint32_t);
-    static bool lds_ok = false;
-    rc = allow_lds(reinterpret_cast<const void*>(fast3_bwd_chunk_kernel<Q0, Q1, Q2, R1, R2, true>), lds, &lds_ok);
-    if (rc) return rc;
-    profile_begin(2, st);
-    hipLaunchKernelGGL((fast3_bwd_chunk_kernel<Q0, Q1, Q2, R1, R2, true>), dim3((unsigned)fused_tiles(s, nnz)), dim3(kFuseWaves * 64),
-                       lds, st, cores.c[2], (uint32_t)G, (uint32_t)s.p[2], (uint32_t)nnz, d_output, (uint32_t)(B * s.D * 4), plan);
-    profile_end(2, st);
-    rc = check_hip(hipGetLastError(), "fast3_bwd_chunk_kernel (fused)");
-    if (rc) return rc;
+    if constexpr (kCanFuse) {
+      static LdsGate lds_ok;
+      rc = allow_big_lds(reinterpret_cast<const void*>(fast3_bwd_chunk_kernel<Q0, Q1, Q2, R1, R2, true>), lds, &lds_ok, "fused backward chunk kernel");
+      if (rc) return rc;
+      profile_begin(2, st);
+      hipLaunchKernelGGL((fast3_bwd_chunk_kernel<Q0, Q1, Q2, R1, R2, true>), dim3((unsigned)fused_tiles(s, nnz)), dim3(kFuseWaves * 64),
+                         lds, st, cores.c[2], (uint32_t)G, (uint32_t)s.p[2], (uint32_t)nnz, d_output, (uint32_t)(B * s.D * 4), plan);
+      profile_end(2, st);
+      rc = check_hip(hipGetLastError(), "fast3_bwd_chunk_kernel (fused)");
+      if (rc) return rc;
+    }
   } else {
     const size_t lds = kChainWaves * wave_lds;
-    static bool lds_ok = false;
+    static LdsGate lds_ok;
     unsigned grid = 0;
     rc = chain_grid(reinterpret_cast<const void*>(fast3_bwd_chunk_kernel<Q0, Q1, Q2, R1, R2, false>), lds, kBwdWgsPerCu, &lds_ok, &grid);
     if (rc) return rc;

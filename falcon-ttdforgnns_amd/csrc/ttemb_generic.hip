@@ -10,18 +10,6 @@ namespace ttemb {
 
 static inline int round4(int x) { return (x + 3) & ~3; }
 
-// gfx950 has 160 KB of LDS per CU; a launch above the default 64 KB of dynamic LDS has to be allowed per kernel
-// (q = 5,5,4 at ranks 256,256 -- a shape run_script.sh:250-268 trains -- needs 80 KB in the backward).
-constexpr int64_t kLdsDefault = 64 * 1024, kLdsDevice = 160 * 1024;
-static int allow_lds(const void* kernel, int64_t bytes, int64_t* allowed, const char* what) {
-  if (bytes <= kLdsDefault || bytes <= *allowed) return TTEMB_OK;
-  if (bytes > kLdsDevice)
-    return fail(TTEMB_E_UNSUPPORTED, "%s needs %lld bytes of LDS per wavefront, the CU has %lld", what, (long long)bytes,
-                (long long)kLdsDevice);
-  int rc = check_hip(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsDevice), what);
-  if (rc == TTEMB_OK) *allowed = kLdsDevice;
-  return rc;
-}
 
 int64_t generic_fwd_lds_bytes(const DevShape& s) {
   return 2ll * round4(s.part_max) * sizeof(float);
@@ -104,8 +92,8 @@ int launch_forward_generic(const DevShape& s, const CorePtrs& cores, const int64
                            const int32_t* nnz_dev, float* output, hipStream_t st) {
   if (nnz <= 0) return TTEMB_OK;
   const int64_t lds = generic_fwd_lds_bytes(s);
-  static int64_t allowed = kLdsDefault;
-  int rc = allow_lds(reinterpret_cast<const void*>(fwd_generic_kernel), lds, &allowed, "generic forward (partial products)");
+  static LdsGate gate;   // (q = 5,5,4 at ranks 256,256 -- a shape run_script.sh:250-268 trains -- needs 80 KB in the backward)
+  int rc = allow_big_lds(reinterpret_cast<const void*>(fwd_generic_kernel), (size_t)lds, &gate, "generic forward (partial products)");
   if (rc) return rc;
   const int64_t grid = nnz < 262144 ? nnz : 262144;
   profile_begin(0, st);
@@ -206,8 +194,8 @@ int launch_backward_generic(const DevShape& s, const CorePtrs& cores, const int6
                             const int32_t* nnz_dev, const float* d_output, const CorePtrsMut& d_cores, hipStream_t st) {
   if (nnz <= 0) return TTEMB_OK;
   const int64_t lds = generic_bwd_lds_bytes(s);
-  static int64_t allowed = kLdsDefault;
-  int rc = allow_lds(reinterpret_cast<const void*>(bwd_generic_kernel), lds, &allowed, "generic backward (partial products)");
+  static LdsGate gate;
+  int rc = allow_big_lds(reinterpret_cast<const void*>(bwd_generic_kernel), (size_t)lds, &gate, "generic backward (partial products)");
   if (rc) return rc;
   const int64_t grid = nnz < 262144 ? nnz : 262144;
   profile_begin(1, st);

@@ -21,6 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TTEMB_LIB") or os.path.join(_HERE, "lib", "libttemb_hip.so")
 
 MAX_CORES = 4
+ABI_VERSION = 2
 OP_FORWARD, OP_BACKWARD, OP_PREPROCESS, OP_CACHE_POPULATE = 0, 1, 2, 3
 PATH_AUTO, PATH_GENERIC, PATH_FAST3, PATH_PER_BAG = 0, 1, 2, 3
 
@@ -30,7 +31,7 @@ EXPORTED_SYMBOLS = (
     "ttemb_profile_enable", "ttemb_profile_read",
     "ttemb_forward", "ttemb_forward_group", "ttemb_forward_lookup", "ttemb_backward_dense", "ttemb_backward_sgd", "ttemb_backward_adagrad",
     "ttemb_sgd_step", "ttemb_adagrad_step", "ttemb_cache_update", "ttemb_cache_update_one_sweep", "ttemb_cache_populate",
-    "ttemb_preprocess", "ttemb_cache_forward", "ttemb_cache_backward_sgd",
+    "ttemb_preprocess", "ttemb_preprocess_update", "ttemb_cache_forward", "ttemb_cache_backward_sgd",
     "ttemb_cache_backward_dense", "ttemb_cache_backward_rowwise_adagrad",
 )
 
@@ -87,6 +88,7 @@ def _load() -> ctypes.CDLL:
     lib.ttemb_cache_update_one_sweep.argtypes = [vp, i64, vp, vp, i64, vp]
     lib.ttemb_cache_populate.argtypes = [shp, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp]
     lib.ttemb_preprocess.argtypes = [vp, vp, i64, i64, i32, vp, vp, i64, vp, vp, vp, vp, vp, i32, vp, i64, vp]
+    lib.ttemb_preprocess_update.argtypes = [vp, vp, i64, i64, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp]
     lib.ttemb_cache_forward.argtypes = [vp, vp, vp, i64, vp, i64, vp, i64, vp, vp]
     lib.ttemb_cache_backward_sgd.argtypes = [vp, vp, i64, vp, i64, vp, i64, f32, vp, vp, vp]
     lib.ttemb_cache_backward_dense.argtypes = [vp, vp, i64, vp, i64, vp, i64, i64, vp, vp, vp]
@@ -95,7 +97,7 @@ def _load() -> ctypes.CDLL:
         fn = getattr(lib, name)
         if name not in ("ttemb_last_error", "ttemb_workspace_bytes", "ttemb_plan_bytes"):
             fn.restype = ctypes.c_int
-    if lib.ttemb_abi_version() != 1:
+    if lib.ttemb_abi_version() != ABI_VERSION:
         raise ImportError("libttemb_hip.so ABI version mismatch")
     return lib
 
@@ -324,14 +326,24 @@ def cache_populate(shape: Shape, cores, hashtbl, cache_freq, cache_state, cache_
 
 
 def preprocess(indices, offsets, B: int, warmup: bool, hashtbl, cache_state, indices_out, rowidx_out,
-               cache_loc_out, nnz_tt_dev, ws: Workspace, dup_stamp=None, epoch: int = 0) -> None:
-    """``dup_stamp`` (int32[C], zeros at first) + a non-zero ``epoch``: ``nnz_tt_dev`` must hold two int32 and its
-    second word tells the cache backward whether a cache row occurs twice in this call."""
+               cache_loc_out, nnz_tt_dev, ws: Workspace, dup_stamp=None, epoch: int = 0, cache_freq=None) -> None:
+    """``dup_stamp`` (int32[C] of scratch): ``nnz_tt_dev`` must hold two int32 and its second word tells the cache
+    backward whether a cache row occurs twice in this call.  ``cache_freq``: the LFU update of the same ids rides in
+    the probe pass (``ttemb_preprocess_update``; live cache only)."""
     dev = indices.device
     nnz = indices.numel()
     H = 0 if hashtbl is None else hashtbl.numel()
     need = 0 if (warmup or H == 0) else workspace_bytes(None, OP_PREPROCESS, nnz, B)
     w = ws.get(need, dev)
+    if cache_freq is not None:
+        if warmup or H == 0:
+            raise RuntimeError("the fused probe pass serves a live cache only")
+        with _on_device(dev):
+            _check(LIB.ttemb_preprocess_update(_ptr(indices), _ptr(offsets), nnz, B, _ptr(hashtbl), _ptr(cache_freq),
+                                               _ptr(cache_state), H, _ptr(indices_out), _ptr(rowidx_out),
+                                               _ptr(cache_loc_out), _ptr(nnz_tt_dev), _ptr(dup_stamp), _ptr(w), w.numel(),
+                                               _stream(indices)))
+        return
     with _on_device(dev):
         _check(LIB.ttemb_preprocess(_ptr(indices), _ptr(offsets), nnz, B, 1 if warmup else 0, _ptr(hashtbl),
                                     _ptr(cache_state), H, _ptr(indices_out), _ptr(rowidx_out),

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define TTEMB_ABI_VERSION 1
+#define TTEMB_ABI_VERSION 2
 #define TTEMB_MAX_CORES 4
 
 enum {
@@ -206,15 +206,26 @@ int ttemb_cache_populate(const ttemb_shape_t* shape, const float* const* cores,
  * backwards (the CUB DevicePartition::Flagged order); *nnz_tt_dev = #TT ids.
  * Does NOT synchronise: the count stays on the device (pass it to the other entry
  * points as nnz_dev, or copy it back yourself).
- * `dup_stamp` (nullable; int32[C], zero-filled once by the caller and then owned by these calls) and `epoch`
- * (non-zero, different from the epochs of the caller's recent calls) turn on duplicate detection among the
- * cached ids: nnz_tt_dev must then hold TWO int32 and nnz_tt_dev[1] becomes 1 when some cache row is met more
- * than once in this call, else 0 -- the word ttemb_cache_backward_sgd / _dense take as `dup_dev`. */
+ * `dup_stamp` (nullable; int32[C] of scratch, any content) turns on duplicate detection among the cached ids:
+ * nnz_tt_dev must then hold TWO int32 and nnz_tt_dev[1] becomes 1 when some cache row is met more than once in
+ * this call, else 0 -- the word ttemb_cache_backward_sgd / _dense take as `dup_dev`.  (Every cached id stamps its
+ * row with its position, the partition step reads the stamps back.)  `epoch` is ignored (ABI 1 needed it). */
 int ttemb_preprocess(const int64_t* indices, const int64_t* offsets, int64_t nnz, int64_t B,
                      int32_t warmup, const int64_t* hashtbl, const int32_t* cache_state,
                      int64_t H, int64_t* indices_out, int64_t* rowidx_out,
                      int32_t* cache_loc_out, int32_t* nnz_tt_dev, int32_t* dup_stamp, int32_t epoch,
                      void* workspace, int64_t workspace_bytes, void* stream);
+
+/* update_cache_state + preprocess_indices_sync in ONE probe pass -- what TTEmbeddingBag.forward does with a live cache
+ * (tt_embeddings_ops.py:836-870 calls the two back to back on the same ids, and both visit the same <= 3 slots per id).
+ * Same hashtbl / cache_freq / outputs as ttemb_cache_update followed by ttemb_preprocess(warmup = 0): the find-first
+ * update never moves or evicts a key, so an id resolves to the same slot before and after its batch was counted.
+ * (A caller that needs the reference's one-sweep insert keeps the two calls apart.) */
+int ttemb_preprocess_update(const int64_t* indices, const int64_t* offsets, int64_t nnz, int64_t B,
+                            int64_t* hashtbl, int64_t* cache_freq, const int32_t* cache_state, int64_t H,
+                            int64_t* indices_out, int64_t* rowidx_out, int32_t* cache_loc_out,
+                            int32_t* nnz_tt_dev, int32_t* dup_stamp, void* workspace, int64_t workspace_bytes,
+                            void* stream);
 
 /* cache_forward (tt_embeddings.cpp:151, tt_embeddings_cuda.cu:1509-1583):
  * output[rowidx[n]] += cache_weight[cache_loc[n]] for n in [start, nnz).  `start` is

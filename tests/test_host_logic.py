@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(nat.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ttemb_abi_version() == 1
+    assert lib.ttemb_abi_version() == 2
 
 
 def test_abi_argument_validation_without_gpu():

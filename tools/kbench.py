@@ -71,12 +71,13 @@ def main():
         out = torch.empty(N, D, device="cuda")
         d_out = (torch.rand(N, D, device="cuda") - 0.5) * 0.1
         grads = [torch.empty_like(c) for c in cores]
-        f, b, c = [], [], []
+        f, b, c, g = [], [], [], []
         for i in range(a.iters + 3):
             if a.what in ("both", "fwd"):
                 nat.forward(shape, cores, idx, rowidx, offs, N, None, N, out, ws)
                 if i >= 3:
                     f.append(nat.profile_read(0))
+                    g.append(nat.profile_read(3))
             if a.what in ("both", "bwd"):
                 nat.backward_dense(shape, cores, idx, rowidx, N, None, N, d_out, grads, ws, None, offs)
                 if i >= 3:
@@ -85,7 +86,7 @@ def main():
         torch.cuda.synchronize()
         msg = f"{a.cfg} {a.dist} N={N}:"
         if f:
-            msg += f" fwd {np.mean(f)*1e3:8.1f} us ({N/np.mean(f)/1e6:8.2f} G lookups/s)"
+            msg += f" grouping {np.mean(g)*1e3:6.1f} us fwd {np.mean(f)*1e3:8.1f} us ({N/np.mean(f)/1e6:8.2f} G lookups/s)"
         if b:
             msg += f" bwd {np.mean(b)*1e3:8.1f} us ({N/np.mean(b)/1e6:8.2f} G lookups/s) [chunk kernel {np.mean(c)*1e3:7.1f} us]"
         print(msg, flush=True)

@@ -6,6 +6,6 @@ name=$1; shift
 cd "$(dirname "$0")/../falcon-ttdforgnns_amd/csrc"
 out=/tmp/ttemb_var/$name
 mkdir -p $out
-make -s -j4 OUTDIR=$out CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -mllvm -amdgpu-mfma-vgpr-form=1 -Wall -Wno-unused-function $*"
+make -s -j4 OUTDIR=$out EXTRA="$*"
 cp $out/libttemb_hip.so ../lib/libttemb_$name.so
 echo "built lib/libttemb_$name.so ($*)"
