@@ -311,11 +311,14 @@ def main():
                 cap(ids_s).backward(d_s)
             torch.cuda.synchronize()
             dtc = (time.perf_counter() - t1) / 200
-            small = {"ids": 2048, "us_per_step": round(min(dt, dtg) * 1e6, 1), "lookups_per_s": round(2048 / min(dt, dtg), 1),
-                     "eager_us_per_step": round(dt * 1e6, 1), "whole_step_graph_replay_us": round(dtg * 1e6, 1),
+            # the headline of this leg is the EAGER figure: the reference's drivers run the layer unchanged, i.e. eager;
+            # the captured forms are reported next to it
+            small = {"ids": 2048, "us_per_step": round(dt * 1e6, 1), "lookups_per_s": round(2048 / dt, 1),
+                     "whole_step_graph_replay_us": round(dtg * 1e6, 1),
+                     "whole_step_graph_lookups_per_s": round(2048 / dtg, 1),
                      "capture_api_us_per_step": round(dtc * 1e6, 1),
                      "what": "fwd + bwd + SGD on 2048 unique ids through the class (per-bag MFMA kernels: 4 launches); "
-                             "us_per_step = the faster of eager and whole-step graph replay"}
+                             "us_per_step = eager; whole_step_graph_replay_us = the same step under one torch.cuda.graph"}
         # the same step on a frontier with METIS-like id locality (2048 windows of 200 consecutive ids:
         # what `--partition 125` reordering produces, SURVEY.md §8d cfg-B3), reported next to the uniform one
         local = None
@@ -381,22 +384,29 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             from oracle import cpu_einsum
             n_cpu = 65536
-            r = cpu_einsum.time_baseline(P, Q, [1] + RANKS + [1], n_cpu, N_EMB, seed=1234, budget_s=12.0)
-            cpu = {"value": round(r["lookups_per_s"], 1), "unit": "lookups/s", "cores": r["threads"],
+            # the port does not scale with threads (one thread is within 10 % of all of them, and past ~8 threads small
+            # batches get slower): the baseline is the BEST of {1, 8, all} threads, the thread count is reported
+            all_thr = os.cpu_count() or 1
+            tries = {}
+            for thr in sorted({1, 8, all_thr}):
+                tries[thr] = cpu_einsum.time_baseline(P, Q, [1] + RANKS + [1], n_cpu, N_EMB, seed=1234, budget_s=6.0, threads=thr)
+            best_thr = max(tries, key=lambda k: tries[k]["lookups_per_s"])
+            r = tries[best_thr]
+            cpu = {"value": round(r["lookups_per_s"], 1), "unit": "lookups/s", "cores": best_thr,
                    "kind": "port",
+                   "by_threads": {str(k): round(v["lookups_per_s"], 1) for k, v in tries.items()},
                    "sample": f"{r['iters']} fwd+bwd+SGD steps of {n_cpu} unique uniform ids "
-                             f"(torch index_select+einsum, fp32, {r['seconds']:.1f} s)"}
+                             f"(torch index_select+einsum, fp32, {r['seconds']:.1f} s at {best_thr} threads; "
+                             f"best of 1 / 8 / {all_thr} threads, ~6 s each)"}
             # the metric's literal regime: N = 2048, at 1 / 8 / all host threads (the best is the baseline to beat), and
             # the 65 536-id sample on one thread
-            all_thr = r["threads"]
             by_thr = {}
             for thr in sorted({1, 8, all_thr}):
                 rr = cpu_einsum.time_baseline(P, Q, [1] + RANKS + [1], 2048, N_EMB, seed=1234, budget_s=2.5, threads=thr)
                 by_thr[str(thr)] = round(rr["lookups_per_s"], 1)
-            r1 = cpu_einsum.time_baseline(P, Q, [1] + RANKS + [1], n_cpu, N_EMB, seed=1234, budget_s=4.0, threads=1)
             torch.set_num_threads(all_thr)
             best = max(by_thr.values())
-            cpu["one_thread_value"] = round(r1["lookups_per_s"], 1)
+            cpu["one_thread_value"] = round(tries[1]["lookups_per_s"], 1)
             # BASELINE.json configs[0] (the reference's own CPU-runnable case): ogbn-arxiv shapes, batch 256, einsum on the
             # host.  The product has no CPU path (a CPU fallback would void parity), so this leg exists on the baseline
             # side only; its GPU counterpart is matrix["arxiv_r8_256"].

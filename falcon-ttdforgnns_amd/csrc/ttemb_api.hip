@@ -120,19 +120,23 @@ static int64_t grad_scratch_bytes(const DevShape& s) {
   return b;
 }
 
-static bool use_fast3(const DevShape& s, int64_t nnz, int64_t B) {
+// have_offsets: the call carries its bag boundaries (size queries assume so) -- what a call past one 32-bit row window needs
+// to run on the grouped path, piece by piece
+static bool use_fast3(const DevShape& s, int64_t nnz, int64_t B, bool have_offsets = true) {
   const int path = current_path();
   if (path == TTEMB_PATH_GENERIC || path == TTEMB_PATH_PER_BAG || !fast3_supported(s)) return false;
-  if (!fast3_fits(s, nnz, B)) return false;  // the fast kernels address their tables with 32-bit byte offsets
+  if (!fast3_fits(s, nnz, B) && !(have_offsets && fast3_fits_in_pieces(s, nnz, B))) return false;
   return path == TTEMB_PATH_FAST3 || fast3_pays(s, nnz);
 }
+// the fused optimiser step rides in the grouped backward's last kernel when the call is one piece
+static bool one_piece(const DevShape& s, int64_t nnz, int64_t B) { return fast3_fits(s, nnz, B); }
 
 // small batches of an instantiated 3-core shape whose ids come with their bag boundaries: one wavefront per bag, MFMA per
 // id (ttemb_small3.inc) instead of the wave-per-id scalar kernels
 static bool use_small3(const DevShape& s, int64_t nnz, int64_t B, const int64_t* rowidx, const int64_t* offsets) {
   const int path = current_path();
   return (path == TTEMB_PATH_AUTO || path == TTEMB_PATH_PER_BAG) && rowidx == nullptr && offsets != nullptr && small3_supported(s) &&
-         !use_fast3(s, nnz, B);
+         !use_fast3(s, nnz, B, offsets != nullptr);
 }
 
 // ---------------------------------------------------------------------------------
@@ -146,6 +150,7 @@ static bool use_small3(const DevShape& s, int64_t nnz, int64_t B, const int64_t*
 // ---------------------------------------------------------------------------------
 struct Merged4 {
   bool on;
+  bool per_bag;         // the 3-core view runs on the per-bag kernels (no grouped shape fits / the batch is small)
   int a;                // the merged pair: cores a and a + 1 (0: the first two, 2: the last two)
   DevShape s3;          // the 3-core view
   int64_t v_bytes;      // bytes of V (and of dV), 256-aligned
@@ -215,13 +220,22 @@ static bool view_lifted2(const DevShape& s, DevShape* out) {
   return true;
 }
 
-static Merged4 merge_first_two(const DevShape& s, int64_t nnz, int64_t B) {
+// per_bag_ok: the call could run on the per-bag kernels (ids + offsets, no row index; sizing queries pass true): a 2- or
+// 4-core table whose 3-core view has no grouped shape, or whose batch is below the grouped path's crossover, then rides on
+// the per-bag MFMA kernels (templated or run-time shape) through the same virtual core instead of the scalar kernels.
+static Merged4 merge_first_two(const DevShape& s, int64_t nnz, int64_t B, bool per_bag_ok = false, bool have_offsets = true) {
   Merged4 m;
   memset(&m, 0, sizeof(m));
-  if (s.T == 2 && current_path() != TTEMB_PATH_GENERIC) {
+  const int path = current_path();
+  if (path == TTEMB_PATH_GENERIC) return m;
+  per_bag_ok = per_bag_ok && (path == TTEMB_PATH_AUTO || path == TTEMB_PATH_PER_BAG);
+  if (s.T == 2) {
     DevShape d;
-    if (view_lifted2(s, &d) && use_fast3(d, nnz, B)) {
+    if (!view_lifted2(s, &d)) return m;
+    const bool f3 = use_fast3(d, nnz, B, have_offsets);
+    if (f3 || (per_bag_ok && small3_supported(d))) {
       m.on = true;
+      m.per_bag = !f3;
       m.a = -1;
       m.s3 = d;
       m.K = s.R[1];
@@ -229,12 +243,10 @@ static Merged4 merge_first_two(const DevShape& s, int64_t nnz, int64_t B) {
     }
     return m;
   }
-  if (s.T != 4 || current_path() == TTEMB_PATH_GENERIC) return m;
-  for (int a = 0; a <= 2; a += 2) {
-    DevShape d;
-    if (!view3(s, a, &d) || !use_fast3(d, nnz, B)) continue;
-    if (a == 2 && (long long)d.p[2] * d.row_len[2] * 4 > (4ll << 20)) continue;   // virtual last core: at most 4 MB (its slabs)
+  if (s.T != 4) return m;
+  auto fill = [&](int a, const DevShape& d, bool per_bag) {
     m.on = true;
+    m.per_bag = per_bag;
     m.a = a;
     m.s3 = d;
     m.pa = s.p[a]; m.pb = s.p[a + 1];
@@ -242,7 +254,17 @@ static Merged4 merge_first_two(const DevShape& s, int64_t nnz, int64_t B) {
     m.K = s.R[a + 1];
     m.n = s.q[a + 1] * s.R[a + 2];     // Bm[ib] is R_{a+1} x (q_{a+1} R_{a+2})
     m.v_bytes = align256((long long)m.pa * m.pb * m.rows * m.n * 4);
+  };
+  for (int a = 0; a <= 2; a += 2) {
+    DevShape d;
+    if (!view3(s, a, &d) || !use_fast3(d, nnz, B, have_offsets)) continue;
+    if (a == 2 && (long long)d.p[2] * d.row_len[2] * 4 > (4ll << 20)) continue;   // virtual last core: at most 4 MB (its slabs)
+    fill(a, d, false);
     return m;
+  }
+  if (per_bag_ok) {   // first pair merged: the per-id operand stays the last core
+    DevShape d;
+    if (view3(s, 0, &d) && small3_supported(d) && (long long)s.p[0] * s.p[1] * d.row_len[0] * 4 <= (256ll << 20)) fill(0, d, true);
   }
   return m;
 }
@@ -508,11 +530,11 @@ static int backward_into(const DevShape& ds, const CorePtrs& cp, const int64_t* 
                          const int64_t* rowidx, const int64_t* offsets, int64_t nnz, const int32_t* nnz_dev, int64_t B,
                          const float* d_output, const CorePtrsMut& dst, void* ws, int64_t ws_bytes,
                          const void* plan, int64_t plan_bytes, hipStream_t st, const FusedUpdate* update = nullptr) {
-  if (use_fast3(ds, nnz, B))
+  if (use_fast3(ds, nnz, B, offsets != nullptr))
     return launch_backward_fast3(ds, cp, indices, rowidx, offsets, nnz, nnz_dev, B, d_output, dst, ws, ws_bytes, plan,
                                  plan_bytes, st, update);
-  const Merged4 m4 = merge_first_two(ds, nnz, B);
-  if (m4.on) {   // 4 cores: the grouped 3-core backward on (V, G2, G3), then dV back onto G0 and G1
+  const Merged4 m4 = merge_first_two(ds, nnz, B, rowidx == nullptr && offsets != nullptr, offsets != nullptr);
+  if (m4.on) {   // 4 cores: the 3-core backward on (V, G2, G3), then dV back onto G0 and G1
     if (ws == nullptr || ws_bytes < 2 * m4.v_bytes) return fail(TTEMB_E_WORKSPACE, "backward needs room for the merged core");
     float* V = reinterpret_cast<float*>(ws);
     float* dV = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + m4.v_bytes);
@@ -525,8 +547,14 @@ static int backward_into(const DevShape& ds, const CorePtrs& cp, const int64_t* 
     if (m4.a < 0) { d3.c[0] = dst.c[0]; d3.c[1] = dV; d3.c[2] = dst.c[1]; }   // (the identity's gradient is dropped)
     else if (m4.a == 0) { d3.c[0] = dV; d3.c[1] = dst.c[2]; d3.c[2] = dst.c[3]; }
     else           { d3.c[0] = dst.c[0]; d3.c[1] = dst.c[1]; d3.c[2] = dV; }
-    rc = launch_backward_fast3(m4.s3, c3, indices, rowidx, offsets, nnz, nnz_dev, B, d_output, d3,
-                               reinterpret_cast<char*>(ws) + 2 * m4.v_bytes, ws_bytes - 2 * m4.v_bytes, plan, plan_bytes, st, nullptr);
+    if (m4.per_bag) {   // the per-bag kernels ADD into the gradients: clear them (the real cores, then dV)
+      rc = launch_zero_cores(ds, dst, st);
+      if (rc == TTEMB_OK) rc = launch_zero(dV, (size_t)m4.v_bytes, st, "zero dV");
+      if (rc == TTEMB_OK) rc = launch_backward_small3(m4.s3, c3, indices, offsets, nnz, nnz_dev, B, d_output, d3, st);
+    } else {
+      rc = launch_backward_fast3(m4.s3, c3, indices, rowidx, offsets, nnz, nnz_dev, B, d_output, d3,
+                                 reinterpret_cast<char*>(ws) + 2 * m4.v_bytes, ws_bytes - 2 * m4.v_bytes, plan, plan_bytes, st, nullptr);
+    }
     if (rc || m4.a < 0) return rc;
     hipLaunchKernelGGL(split_pair_kernel, dim3((unsigned)(m4.pa + m4.pb), (unsigned)m4.K), dim3(256), 0, st, cp.c[m4.a], cp.c[m4.a + 1], dV, m4.pa,
                        m4.pb, m4.rows, m4.K, m4.n, dst.c[m4.a], dst.c[m4.a + 1]);
@@ -556,6 +584,11 @@ int ttemb_set_path(int32_t path) {
   return TTEMB_OK;
 }
 
+int ttemb_set_piece_limits(int64_t rows, int64_t ids) {
+  fast3_set_piece_limits(rows, ids);
+  return TTEMB_OK;
+}
+
 int ttemb_profile_enable(int32_t on) {
   g_prof_on.store(on != 0);
   return TTEMB_OK;
@@ -576,13 +609,13 @@ int64_t ttemb_workspace_bytes(const ttemb_shape_t* shape, int32_t op, int64_t nn
   int rc = make_dev_shape(shape, &ds);
   if (rc) return rc;
   const bool f3 = use_fast3(ds, op == TTEMB_OP_CACHE_POPULATE ? B : nnz, B);
-  const Merged4 m4 = op == TTEMB_OP_CACHE_POPULATE ? Merged4{} : merge_first_two(ds, nnz, B);
+  const Merged4 m4 = op == TTEMB_OP_CACHE_POPULATE ? Merged4{} : merge_first_two(ds, nnz, B, true);
   switch (op) {
     case TTEMB_OP_FORWARD:
-      if (m4.on) return align256(nnz * 8) + m4.v_bytes + fast3_workspace_bytes(m4.s3, op, nnz, B);
+      if (m4.on) return align256(nnz * 8) + m4.v_bytes + (m4.per_bag ? 0 : fast3_workspace_bytes(m4.s3, op, nnz, B));
       return align256(nnz * 8) + (f3 ? fast3_workspace_bytes(ds, op, nnz, B) : 0);
     case TTEMB_OP_BACKWARD:
-      if (m4.on) return grad_scratch_bytes(ds) + align256(nnz * 8) + 2 * m4.v_bytes + fast3_workspace_bytes(m4.s3, op, nnz, B);
+      if (m4.on) return grad_scratch_bytes(ds) + align256(nnz * 8) + 2 * m4.v_bytes + (m4.per_bag ? 0 : fast3_workspace_bytes(m4.s3, op, nnz, B));
       return grad_scratch_bytes(ds) + align256(nnz * 8) + (f3 ? fast3_workspace_bytes(ds, op, nnz, B) : 0);
     case TTEMB_OP_CACHE_POPULATE: {
       const int64_t sort = populate_workspace_bytes(nnz);
@@ -594,14 +627,35 @@ int64_t ttemb_workspace_bytes(const ttemb_shape_t* shape, int32_t op, int64_t nn
   }
 }
 
+int ttemb_kernel_family(const ttemb_shape_t* shape, int64_t nnz, int64_t B, int32_t ids_with_offsets) {
+  DevShape ds;
+  int rc = make_dev_shape(shape, &ds);
+  if (rc) return rc;
+  if (nnz < 0 || B < 0) return fail(TTEMB_E_BADARG, "negative size");
+  auto family3 = [](const DevShape& s, bool grouped) {
+    if (grouped) return fast3_wide(s) ? TTEMB_FAMILY_GROUPED_WIDE : TTEMB_FAMILY_GROUPED;
+    return small3_templated_shape(s) ? TTEMB_FAMILY_PER_BAG : TTEMB_FAMILY_PER_BAG_RT;
+  };
+  // (without the bag boundaries a call past one row window cannot be cut into pieces)
+  if (use_fast3(ds, nnz, B, ids_with_offsets != 0)) return family3(ds, true);
+  const Merged4 m4 = merge_first_two(ds, nnz, B, ids_with_offsets != 0, ids_with_offsets != 0);
+  if (m4.on) return family3(m4.s3, !m4.per_bag) | TTEMB_FAMILY_MERGED;
+  // use_small3 with stand-in pointers: only their null-ness is looked at
+  const int64_t* none = nullptr;
+  const int64_t* some = reinterpret_cast<const int64_t*>(&ds);
+  if (use_small3(ds, nnz, B, ids_with_offsets ? none : some, ids_with_offsets ? some : none)) return family3(ds, false);
+  return TTEMB_FAMILY_SCALAR;
+}
+
 int64_t ttemb_plan_bytes(const ttemb_shape_t* shape, int64_t nnz) {
   DevShape ds;
   int rc = make_dev_shape(shape, &ds);
   if (rc) return rc;
   if (nnz < 0) return fail(TTEMB_E_BADARG, "negative size");
-  if (use_fast3(ds, nnz, 0)) return fast3_plan_bytes(ds, nnz);
+  // (a call that runs in pieces keeps no plan -- a plan describes one piece --; neither does a per-bag view)
+  if (use_fast3(ds, nnz, 0)) return fast3_fits(ds, nnz, 0) ? fast3_plan_bytes(ds, nnz) : 0;
   const Merged4 m4 = merge_first_two(ds, nnz, 0);
-  return m4.on ? fast3_plan_bytes(m4.s3, nnz) : 0;
+  return m4.on && fast3_fits(m4.s3, nnz, 0) ? fast3_plan_bytes(m4.s3, nnz) : 0;
 }
 
 }  // extern "C"
@@ -622,8 +676,9 @@ static int forward_phase(int phase, const ttemb_shape_t* shape, const float* con
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   CorePtrs cp;
   for (int t = 0; t < TTEMB_MAX_CORES; ++t) cp.c[t] = t < ds.T ? cores[t] : nullptr;
-  const Merged4 m4 = nnz > 0 ? merge_first_two(ds, nnz, B) : Merged4{};
-  if (m4.on) {   // 4 cores through the grouped 3-core kernels on (V = G0.G1, G2, G3); workspace: [row slot | V | 3-core]
+  const Merged4 m4 = nnz > 0 ? merge_first_two(ds, nnz, B, rowidx == nullptr && offsets != nullptr, offsets != nullptr) : Merged4{};
+  if (m4.on && m4.per_bag && phase == 1) return TTEMB_OK;   // the per-bag kernels have no id-only half
+  if (m4.on) {   // 4 cores through the 3-core kernels on (V = G0.G1, G2, G3); workspace: [row slot | V | 3-core]
     char* w4 = reinterpret_cast<char*>(workspace);
     const int64_t head = align256(nnz * 8);
     if (w4 == nullptr || workspace_bytes < head + m4.v_bytes) return fail(TTEMB_E_WORKSPACE, "forward needs room for the merged core");
@@ -635,6 +690,8 @@ static int forward_phase(int phase, const ttemb_shape_t* shape, const float* con
       rc = build_merged_core(m4, cp, V, st);
       if (rc) return rc;
     }
+    if (m4.per_bag)   // one launch, every output row written once
+      return launch_forward_small3(m4.s3, c3, indices, offsets, nnz, nnz_dev, B, output, st);
     if (phase != 2 && offsets == nullptr) {
       rc = launch_zero(output, (size_t)B * ds.D * 4, st, "zero output");
       if (rc) return rc;
@@ -642,7 +699,7 @@ static int forward_phase(int phase, const ttemb_shape_t* shape, const float* con
     return launch_forward_fast3(m4.s3, c3, indices, rowidx, offsets, nnz, nnz_dev, B, output, offsets != nullptr,
                                 w4 + head + m4.v_bytes, workspace_bytes - head - m4.v_bytes, plan, plan_bytes, phase, st);
   }
-  const bool f3 = nnz > 0 && use_fast3(ds, nnz, B);
+  const bool f3 = nnz > 0 && use_fast3(ds, nnz, B, offsets != nullptr);
   if (phase == 1 && !f3) return TTEMB_OK;   // the generic kernels have no id-only half: phase 2 is their whole forward
   if (phase == 2 && f3) {
     return launch_forward_fast3(ds, cp, indices, rowidx, offsets, nnz, nnz_dev, B, output, offsets != nullptr, workspace,
@@ -723,7 +780,7 @@ int ttemb_backward_dense(const ttemb_shape_t* shape, const float* const* cores,
   char* ws = reinterpret_cast<char*>(workspace);
   int64_t rest = workspace_bytes > skip ? workspace_bytes - skip : 0;
   ws = ws ? ws + skip : nullptr;
-  rc = resolve_rowidx(&rowidx, offsets, nnz, B, &ws, &rest, st, use_fast3(ds, nnz, B));
+  rc = resolve_rowidx(&rowidx, offsets, nnz, B, &ws, &rest, st, use_fast3(ds, nnz, B, offsets != nullptr));
   if (rc) return rc;
   return backward_into(ds, cp, indices, rowidx, offsets, nnz, nnz_dev, B, d_output, dp, ws, rest, plan, plan_bytes, st);
 }
@@ -758,9 +815,10 @@ static int fused_backward(const ttemb_shape_t* shape, float* const* cores, float
   }
   char* rest_ws = ws + off;
   int64_t rest = workspace_bytes - off;
-  rc = resolve_rowidx(&rowidx, offsets, nnz, B, &rest_ws, &rest, st, use_fast3(ds, nnz, B));
+  rc = resolve_rowidx(&rowidx, offsets, nnz, B, &rest_ws, &rest, st, use_fast3(ds, nnz, B, offsets != nullptr));
   if (rc) return rc;
-  const bool f3 = use_fast3(ds, nnz, B);
+  // the grouped path of a one-piece call applies the step inside its last kernel; every other route writes gradients, then steps
+  const bool f3 = use_fast3(ds, nnz, B, offsets != nullptr) && one_piece(ds, nnz, B);
   bool aligned4 = true;
   FusedUpdate upd;
   memset(&upd, 0, sizeof(upd));

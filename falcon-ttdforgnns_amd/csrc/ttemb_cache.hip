@@ -384,7 +384,10 @@ __device__ __forceinline__ int64_t live_start(int64_t start, const int32_t* star
 // lanes busy ran at 2 TB/s: a chain of four dependent loads per id).
 // single-id bags: plain store when the caller vouches (offsets) that no TT id shares the row, read-modify-write when
 // only the cached part is known to be alone in it; else float atomics.
-constexpr int kIdsPerWave = 32;   // two steps of 16 ids
+#ifndef TTEMB_CACHE_IDS
+#define TTEMB_CACHE_IDS 32
+#endif
+constexpr int kIdsPerWave = TTEMB_CACHE_IDS;   // steps of 16 ids
 
 __global__ __launch_bounds__(256) void cache_forward_kernel(const int32_t* __restrict__ loc,
                                                             const int64_t* __restrict__ rowidx,

@@ -68,7 +68,9 @@ int launch_zero_cores(const DevShape& s, const CorePtrsMut& d_cores, hipStream_t
 // fast 3-core path (ttemb_fast3.hip)
 bool fast3_supported(const DevShape& s);
 bool fast3_pays(const DevShape& s, int64_t nnz);
-bool fast3_fits(const DevShape& s, int64_t nnz, int64_t B);  // enough ids per group for the grouped path to win
+bool fast3_fits(const DevShape& s, int64_t nnz, int64_t B);   // the call fits one 32-bit row window / one grouping pass
+bool fast3_fits_in_pieces(const DevShape& s, int64_t nnz, int64_t B);   // ... or runs as several pieces (needs `offsets`)
+void fast3_set_piece_limits(int64_t rows, int64_t ids);                  // diagnostic: smaller pieces than the hardware's
 int64_t fast3_workspace_bytes(const DevShape& s, int32_t op, int64_t nnz, int64_t B);
 int64_t fast3_plan_bytes(const DevShape& s, int64_t nnz);
 // phase: 0 = whole forward, 1 = id-only half (grouping into `plan`), 2 = lookup on a plan grouped by phase 1.
@@ -92,7 +94,10 @@ int launch_backward_fast3(const DevShape& s, const CorePtrs& cores, const int64_
 
 // small batches of a 3-core table (ttemb_small3.inc): one wavefront per bag, MFMA per id, no grouping; `offsets` required.
 // The backward ADDS into d_cores (zeroed by the caller) with float atomics.
-bool small3_supported(const DevShape& s);
+bool small3_supported(const DevShape& s);   // (includes the run-time-shape kernels of ttemb_rt3.inc)
+bool rt3_supported(const DevShape& s);
+bool small3_templated_shape(const DevShape& s);   // a per-bag shape with an instantiated template
+bool fast3_wide(const DevShape& s);               // a shape of the wide-rank grouped chain
 bool small3_only(const DevShape& s);   // a rank-sweep shape only these kernels are instantiated for
 int launch_forward_small3(const DevShape& s, const CorePtrs& cores, const int64_t* indices, const int64_t* offsets, int64_t nnz,
                           const int32_t* nnz_dev, int64_t B, float* output, hipStream_t st);

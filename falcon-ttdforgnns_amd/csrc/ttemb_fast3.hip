@@ -129,24 +129,26 @@ __device__ __forceinline__ uint4 load_desc(desc_ptr tab, uint32_t c, uint32_t nc
 // ---------------------------------------------------------------------------------
 // Grouping pass: a two-digit counting sort of the live ids by group' = i1 * p0 + i0, cut into chunks.
 //   value = output row | kMultiBit when the bag holds several ids.
-// ids of one (i0, i1) group end up adjacent, consecutive groups share i1.  THREE launches, no device-wide scan, no
-// counter that has to be cleared before the call (round 2: five launches, one of them a 4.5 us zero-fill of a few KB).
+// ids of one (i0, i1) group end up adjacent, consecutive groups share i1.  THREE launches, no device-wide scan, no global
+// atomic per id (one returning atomic per id capped the first version at ~16 G ids/s = 25 us; fire-and-forget ones run at
+// the same ~16 G/s), and nothing that has to be cleared before the call (round 2: five launches, one of them a 4.5 us
+// zero-fill of a few KB): every counter and flag the launches share is TAGGED with the call's epoch, a number kept on the
+// device (so that a replayed HIP graph counts on) -- a word with another tag reads as "not written yet".
 // The group space is cut into ranges of 2^shift groups (first digit), the id list into slices:
-//   decode   every id -> (group, i2, row | multi); LDS histogram of the slice over the ranges, stored as the slice's row
-//            of a [slices][ranges] table (plain stores); the group is stamped with the call's epoch ("holds an id");
-//            the per-group counters are cleared for the next launch                                  [one workgroup per slice]
-//   spread   every id moves to its range (ranges in order, slices in order inside a range): cursor[range] = column sums
-//            of the histogram table (110 KB, L2), one returning LDS atomic per id; one fire-and-forget global atomic
-//            per id counts its group.  The prefix products of the stamped groups ride in this launch
-//            (they depend on nothing the grouping computes)                                          [one workgroup per slice]
-//   place    first position / first chunk of every group from the group counters (sum over the groups before the range
-//            + a scan inside it); every id takes its final position with one returning LDS atomic; the id that opens
-//            a chunk writes its descriptor                                                           [one workgroup per range]
+//   decode   every id -> (group, i2, row | multi); LDS histogram of the slice over the ranges; the slice's place inside
+//            every range from one returning atomic per (slice, range) on the epoch-tagged range counters; the group is
+//            stamped with the epoch ("holds an id")                                                  [one workgroup per slice]
+//   spread   every id moves to its range (ranges in order, slices in arrival order inside a range): cursor[range] from a
+//            scan of the range counters + the slice's place, one returning LDS atomic per id.  The prefix products of the
+//            stamped groups ride in this launch (they depend on nothing the grouping computes)       [one workgroup per slice]
+//   place    LDS histogram of a range's ids over its groups + scan (ids per group, starts inside the range), every id to its
+//            final position with one returning LDS atomic, THEN a look back at the chunk totals the ranges before this one
+//            published (epoch-tagged), then the chunk descriptors                                    [one workgroup per range]
 // A chunk is <= 16 consecutive ids of one group; its 16-byte descriptor {position, group, length | flags, first
 // chunk of the next group} is all the chain kernels need to walk the grouped ids -- they read descriptors with
 // scalar loads and never decode a key, compare neighbours or shuffle.  The order of ids inside a group is slice
-// order, then arrival order inside a slice: every consumer is insensitive to it except for fp32 summation order in the
-// backward.
+// arrival order, then arrival order inside a slice: every consumer is insensitive to it except for fp32 summation order in
+// the backward.
 // ---------------------------------------------------------------------------------
 constexpr int kSortThreads = 1024;       // decode / spread: one workgroup per slice of the id list
 #ifndef TTEMB_RANGE_THREADS
@@ -161,19 +163,43 @@ constexpr int kMaxSlices = 1024;
 constexpr int kMaxRanges = 512;               // ranges of the group space (a power-of-two number of groups each)
 constexpr int kSortBatch = 8;                 // ids per thread whose loads are in flight together
 constexpr uint32_t kFirstBit = 0x100u, kLastBit = 0x200u;   // flags next to a chunk's length
+constexpr uint64_t kEpochMask38 = (1ull << 38) - 1ull;      // epoch tag of the range counters: 38 bits above a 26-bit id count
 constexpr uint32_t kNoGroup = 0xffffffffu;
 
+// A call whose output (or d_output) tensor does not fit one 32-bit window of byte offsets -- 2^24 rows or 2 GiB, what the
+// chain kernels address through buffer descriptors -- or whose ids exceed what one grouping pass takes, runs as a sequence
+// of PIECES: consecutive stretches of the id list, each grouped and looked up by the ordinary launches with rows counted
+// from the piece's first bag (the reference chunks any call by batch_count, tt_embeddings_cuda.cu:1011-1027; SAGE.inference
+// looks up all 111 M nodes of papers100M in one call, gnn_model.py:220-253).  The piece boundaries depend on `offsets`,
+// which live on the device: they are computed THERE (plan_pieces_kernel), launches are sized for the largest possible
+// piece, and a piece that turns out empty costs its launches and nothing else -- no host synchronisation.
+struct Piece {
+  long long pos0;           // first position of the id list
+  long long count;          // ids of the piece (0: an unused slot of the table)
+  long long rowbase;        // the bag of position pos0: rows are stored relative to it (< piece_rows by construction)
+  long long zero0, zero1;   // bags whose output rows this piece clears when their length is not 1
+  long long window_bytes;   // bytes of the [B][D] tensor from row `rowbase` on that the piece may address (< 2 GiB)
+};
+
 struct GroupPlan {           // device pointers into the caller's plan buffer / workspace
+  const Piece* piece;        // null: the call is one piece (positions from 0, rows from 0)
   uint32_t* grp_in;          // [nnz] ungrouped: group of the id (kNoGroup past the live count)
   uint32_t* i2_in;           // [nnz] ungrouped: last index digit
   uint32_t* vals_in;         // [nnz] ungrouped: output row | kMultiBit
   uint32_t* grp_mid;         // [nnz] the same three, ordered by range
   uint32_t* i2_mid;
   uint32_t* vals_mid;
-  uint16_t* shist;           // [slices][ranges] ids of slice s that fall into range r (a slice holds < 65 536 ids)
+  uint32_t* shist;           // [slices][ranges] place of slice s inside range r (arrival order of the slices)
+  uint64_t* rcount;          // [ranges] (epoch << 26 | ids of the range so far): the tag makes a counter of an earlier call -- or
+                             //     whatever the memory held -- read as zero, so nothing has to be cleared between calls
   uint32_t* rstart;          // [ranges + 1] first position of every range in the range-ordered arrays
-  uint32_t* gstamp;          // [G] epoch of the last call that saw an id of the group (a stale or foreign word only ever
-                             //     adds a prefix product nobody reads: it needs no clearing and no initial state)
+  uint32_t* gstamp;          // [G] epoch (low word) of the last call that saw an id of the group (a stale or foreign word only
+                             //     ever adds a prefix product nobody reads: it needs no clearing and no initial state)
+  uint64_t* epochs;          // [2] the grouping pass's call counter, kept ON THE DEVICE so that a replayed HIP graph counts on:
+                             //     [0] the last finished call (read by decode / spread, written by place),
+                             //     [1] the running call (written by spread, read by place).  Any start value will do.
+  uint64_t* rpub;            // [2 * ranges] (epoch << 24 | chunks of the range), then (epoch << 24 | its non-empty groups):
+                             //     what a place workgroup publishes for the ranges after it
   uint32_t* i2s;             // [nnz] grouped: last index digit of the id
   uint32_t* vals;            // [nnz] grouped: output row | kMultiBit
   uint32_t* counts;          // [G+1] ids per group; entry G = number of groups that hold an id
@@ -228,20 +254,24 @@ __global__ __launch_bounds__(kSortThreads) void fast3_decode_kernel(
     const int64_t* __restrict__ indices, const int64_t* __restrict__ rowidx,
     const int64_t* __restrict__ offsets, uint32_t nnz, uint32_t per_slice,
     const int32_t* __restrict__ nnz_dev, int64_t B, int D, float* __restrict__ zero_out, uint32_t sentinel,
-    uint32_t p0, uint32_t p1, uint32_t p2, uint32_t shift, uint32_t ranges, uint32_t G, uint32_t epoch, GroupPlan plan) {
+    uint32_t p0, uint32_t p1, uint32_t p2, uint32_t shift, uint32_t ranges, GroupPlan plan) {
   __shared__ uint32_t hist[kMaxRanges];
   for (uint32_t i = threadIdx.x; i < ranges; i += kSortThreads) hist[i] = 0u;
-  // the per-group counters the spread step adds into (the launch after this one): every slice clears a share
-  for (uint32_t g = blockIdx.x * kSortThreads + threadIdx.x; g <= G; g += gridDim.x * kSortThreads) plan.counts[g] = 0u;
+  const uint32_t epoch = (uint32_t)(plan.epochs[0] + 1ull);   // this call's number (nobody writes the word during this launch)
   __syncthreads();
-  const int64_t cnt = live_count(nnz, nnz_dev);
+  // a piece of a larger call: positions pos0 ..., rows relative to the piece's first bag, its own share of the bags to clear
+  const Piece* pc = plan.piece;
+  const int64_t pos0 = pc ? pc->pos0 : 0, rowbase = pc ? pc->rowbase : 0;
+  const int64_t cnt = pc ? pc->count : live_count(nnz, nnz_dev);
+  const int64_t cnt_all = pos0 + cnt;   // (end of the live ids as a position of the whole list: what bag_is_single compares with)
   const uint32_t s0 = blockIdx.x * per_slice;
   // every slice also owns a share of the bags: rows whose bag does not hold exactly one id are zeroed here (the
   // forward stores one-id bags and accumulates into the others; zero_out is null in the backward)
   if (zero_out != nullptr) {
-    const int64_t per_b = (B + gridDim.x - 1) / gridDim.x;
-    const int64_t b1 = (blockIdx.x + 1) * per_b < B ? (blockIdx.x + 1) * per_b : B;
-    for (int64_t b = blockIdx.x * per_b + threadIdx.x; b < b1; b += kSortThreads)
+    const int64_t z0 = pc ? pc->zero0 : 0, z1 = pc ? pc->zero1 : B;
+    const int64_t per_b = (z1 - z0 + gridDim.x - 1) / gridDim.x;
+    const int64_t b1 = z0 + (blockIdx.x + 1) * per_b < z1 ? z0 + (blockIdx.x + 1) * per_b : z1;
+    for (int64_t b = z0 + blockIdx.x * per_b + threadIdx.x; b < b1; b += kSortThreads)
       if (offsets[b + 1] - offsets[b] != 1) {
         float4* o = reinterpret_cast<float4*>(zero_out + b * D);
         for (int c = 0; c * 4 < D; ++c) o[c] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -254,12 +284,13 @@ __global__ __launch_bounds__(kSortThreads) void fast3_decode_kernel(
 #pragma unroll
     for (int u = 0; u < UD; ++u) {
       const uint32_t n = base + u * kSortThreads;
+      const int64_t g = pos0 + n;   // position in the whole id list
       const bool on = n < s1 && (int64_t)n < cnt;
-      idv[u] = on ? indices[n] : 0;
-      rv[u] = on && rowidx != nullptr ? rowidx[n] : -1;
-      const bool direct = on && rowidx == nullptr && (int64_t)n < B;   // candidate for "bag n holds exactly id n"
-      o0[u] = direct ? offsets[n] : -1;
-      o1[u] = direct ? offsets[n + 1] : -1;
+      idv[u] = on ? indices[g] : 0;
+      rv[u] = on && rowidx != nullptr ? rowidx[g] : -1;
+      const bool direct = on && rowidx == nullptr && g < B;   // candidate for "bag g holds exactly id g"
+      o0[u] = direct ? offsets[g] : -1;
+      o1[u] = direct ? offsets[g + 1] : -1;
     }
 #pragma unroll
     for (int u = 0; u < UD; ++u) {
@@ -271,23 +302,25 @@ __global__ __launch_bounds__(kSortThreads) void fast3_decode_kernel(
       }
       int64_t id = idv[u];
       id = id < 0 ? 0 : (id >= (int64_t)sentinel ? (int64_t)sentinel - 1 : id);
+      const int64_t g = pos0 + n;
       int64_t row;
       bool multi;
       if (rowidx != nullptr) {
         row = rv[u];
-        multi = !bag_is_single(rowidx, offsets, n, cnt, row);
-      } else if (o0[u] >= 0 && o0[u] <= (int64_t)n && (int64_t)n < o1[u]) {
-        row = n;  // the usual case (every bag holds one id) costs two coalesced reads
+        multi = !bag_is_single(rowidx, offsets, g, cnt_all, row);
+      } else if (o0[u] >= 0 && o0[u] <= g && g < o1[u]) {
+        row = g;  // the usual case (every bag holds one id) costs two coalesced reads
         multi = o1[u] - o0[u] != 1;
-      } else {    // bag of position n: the last b with offsets[b] <= n  (tt_embeddings_cuda.cu:1349-1365)
-        int64_t lo = 0, hi = B;  // invariant: offsets[lo] <= n < offsets[hi]
+      } else {    // bag of position g: the last b with offsets[b] <= g  (tt_embeddings_cuda.cu:1349-1365)
+        int64_t lo = 0, hi = B;  // invariant: offsets[lo] <= g < offsets[hi]
         while (hi - lo > 1) {
           const int64_t mid = (lo + hi) >> 1;
-          if (offsets[mid] <= (int64_t)n) lo = mid; else hi = mid;
+          if (offsets[mid] <= g) lo = mid; else hi = mid;
         }
         row = lo;
         multi = offsets[row + 1] - offsets[row] != 1;
       }
+      row -= rowbase;   // (0 for a one-piece call; < 2^24 and < 2 GiB / (4 D) inside a piece, by the piece table's construction)
       const uint32_t uu = (uint32_t)id;
       const uint32_t i0 = uu / (p1 * p2);
       const uint32_t rem = uu - i0 * (p1 * p2);
@@ -301,52 +334,52 @@ __global__ __launch_bounds__(kSortThreads) void fast3_decode_kernel(
     }
   }
   __syncthreads();
-  // the slice's row of the histogram table (plain stores: the spread step sums columns)
-  uint16_t* dst = plan.shist + (size_t)blockIdx.x * ranges;
-  for (uint32_t i = threadIdx.x; i < ranges; i += kSortThreads) dst[i] = (uint16_t)hist[i];
-}
-
-// One slice of the spread step.  cursor[r] = ids of the ranges before r + ids of the slices before this one in r: both are
-// column sums of the [slices][ranges] histogram table, which every workgroup forms for itself (<= 1024 x 512 uint16: 110 KB
-// at 409 600 ids on the products table, L2-resident; ~1.5 us per workgroup against the launch + the returning global
-// atomics of a shared counter array that would also have to be cleared per call).
-__device__ __forceinline__ void spread_slice(uint32_t s, uint32_t slices, uint32_t nnz, uint32_t per_slice, uint32_t shift,
-                                             uint32_t ranges, const GroupPlan& plan, uint32_t* cursor, uint32_t* part,
-                                             uint32_t* wave_sums) {
-  // rp = ranges rounded up to a power of two (>= 64); thread t sums column t % rp over the slices t / rp, t / rp + L, ...
-  uint32_t rp = 64;
-  while (rp < ranges) rp <<= 1;
-  const uint32_t L = kSortThreads / rp, r = threadIdx.x & (rp - 1), k = threadIdx.x / rp;
-  uint32_t before = 0, total = 0;
-  if (r < ranges) {
-    constexpr int U = 8;   // loads in flight per thread
-    for (uint32_t s2 = k; s2 < slices; s2 += L * U) {
-      uint32_t v[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) v[u] = s2 + u * L < slices ? (uint32_t)plan.shist[(size_t)(s2 + u * L) * ranges + r] : 0u;
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        total += v[u];
-        before += s2 + u * L < s ? v[u] : 0u;
+  // this slice's place inside every range: arrival order of the slices, ONE returning atomic per slice and range on a
+  // counter tagged with the call's epoch.  The place step of the call before (same workspace layout) left every counter at
+  // (this call's tag | 0), so the add returns the place at once.  A counter with another tag -- the first call on this
+  // memory, a layout that moved -- is taken over instead: look, then compare-and-swap to (tag | own count) or, once the
+  // tag is there, add.  (The blind add that found the wrong tag changed a word that held nothing of value; the tag cannot
+  // change back during the launch, so an add after a matching look is safe, and a lost swap just looks again.)
+  const uint64_t tag = ((plan.epochs[0] + 1ull) & kEpochMask38) << 26;
+  uint32_t* dst = plan.shist + (size_t)blockIdx.x * ranges;
+  for (uint32_t i = threadIdx.x; i < ranges; i += kSortThreads) {
+    unsigned long long* ctr = reinterpret_cast<unsigned long long*>(&plan.rcount[i]);
+    unsigned long long old = atomicAdd(ctr, (unsigned long long)hist[i]);
+    uint32_t place = (uint32_t)(old & 0x3ffffffull);
+    if ((old & ~0x3ffffffull) != tag) {
+      for (;;) {
+        old = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((old & ~0x3ffffffull) == tag) {
+          place = (uint32_t)(atomicAdd(ctr, (unsigned long long)hist[i]) & 0x3ffffffull);
+          break;
+        }
+        if (atomicCAS(ctr, old, tag | hist[i]) == old) {
+          place = 0;   // the first slice of this call in the range
+          break;
+        }
       }
     }
+    dst[i] = place;
   }
-  part[threadIdx.x] = before;
-  part[kSortThreads + threadIdx.x] = total;
-  __syncthreads();
-  uint32_t bef = 0, tot = 0;
-  if (threadIdx.x < ranges)
-    for (uint32_t j = 0; j < L; ++j) {
-      bef += part[j * rp + threadIdx.x];
-      tot += part[kSortThreads + j * rp + threadIdx.x];
-    }
+}
+
+// One slice of the spread step.  cursor[r] = ids of the ranges before r (a scan of the range counters the decode step left)
+// + this slice's place inside r.
+__device__ __forceinline__ void spread_slice(uint32_t s, uint32_t slices, uint32_t nnz, uint32_t per_slice, uint32_t shift,
+                                             uint32_t ranges, const GroupPlan& plan, uint32_t* cursor, uint32_t* wave_sums) {
+  // (every slice added to every counter of this call -- zeros included -- so all of them carry this call's tag)
+  const uint32_t tot = threadIdx.x < ranges ? (uint32_t)(plan.rcount[threadIdx.x] & 0x3ffffffull) : 0u;
+  const uint32_t bef = threadIdx.x < ranges ? plan.shist[(size_t)s * ranges + threadIdx.x] : 0u;
   uint32_t all;
   const uint32_t excl = block_exclusive<uint32_t, kSortThreads>(tot, wave_sums, all);
   if (threadIdx.x < ranges) {
     cursor[threadIdx.x] = excl + bef;
     if (s == 0) plan.rstart[threadIdx.x] = excl;
   }
-  if (s == 0 && threadIdx.x == 0) plan.rstart[ranges] = all;
+  if (s == 0 && threadIdx.x == 0) {
+    plan.rstart[ranges] = all;
+    plan.epochs[1] = plan.epochs[0] + 1ull;   // the running call's number, for the place step
+  }
   __syncthreads();
   const uint32_t s0 = s * per_slice;
   const uint32_t s1 = s0 + per_slice < nnz ? s0 + per_slice : nnz;
@@ -367,7 +400,6 @@ __device__ __forceinline__ void spread_slice(uint32_t s, uint32_t slices, uint32
 #pragma unroll
     for (int u = 0; u < kSortBatch; ++u) {
       if (g[u] == kNoGroup) continue;
-      atomicAdd(&plan.counts[g[u]], 1u);   // result unused: a fire-and-forget global atomic (cleared by the decode step)
       const uint32_t dst = atomicAdd(&cursor[g[u] >> shift], 1u);
       if (dst >= nnz) continue;   // cannot happen with a consistent table; a bad counter must not become a wild store
       plan.grp_mid[dst] = g[u];
@@ -380,18 +412,28 @@ __device__ __forceinline__ void spread_slice(uint32_t s, uint32_t slices, uint32
 __global__ __launch_bounds__(kSortThreads) void fast3_spread_kernel(uint32_t nnz, uint32_t per_slice, uint32_t shift,
                                                                    uint32_t ranges, GroupPlan plan) {
   __shared__ uint32_t cursor[kMaxRanges];
-  __shared__ uint32_t part[2 * kSortThreads];
   __shared__ uint32_t wave_sums[kSortThreads / kWave];
-  spread_slice(blockIdx.x, gridDim.x, nnz, per_slice, shift, ranges, plan, cursor, part, wave_sums);
+  spread_slice(blockIdx.x, gridDim.x, nnz, per_slice, shift, ranges, plan, cursor, wave_sums);
 }
 
-// The place step of one range.  Group counters are complete (spread step); the range's first position / first chunk is the
-// sum of (ids | chunks << 32) over every group before it -- up to G words (70 KB on the products table) read by each of
-// the <= 512 workgroups, instead of a separate count launch and its range totals.
+// The place step of one range: count, place and describe in ONE launch.
+//   1. LDS histogram of the range's ids over its groups, scan -> ids per group (plan.counts), first position / first
+//      chunk of every group INSIDE the range; the range's totals (chunks, non-empty groups) are PUBLISHED, tagged with the
+//      call's epoch, for the ranges after it;
+//   2. every id takes its final position with one returning LDS atomic (positions need nothing from other ranges: the
+//      range's first position is a column sum the spread step already formed);
+//   3. only now the workgroup looks back: it sums what the ranges before it published -- long done by then, the scatter
+//      of step 2 sits between a workgroup's own publication and its first look (a separate count launch in front of the
+//      place launch cost ~5 us + the launch gap; a look-back BEFORE the scatter waited for the slowest histogram);
+//   4. chunk descriptors and group starts, one thread per group (a chunk's descriptor depends on its group's numbers only).
+// Workgroups are dispatched in index order and wait only for lower indices, so the wait cannot starve what it waits for;
+// it is bounded all the same (a wait that runs out leaves a wrong chunk table, never a hung device).
+constexpr uint64_t kEpochMask = (1ull << 40) - 1ull;
+static_assert(kMaxRanges <= kRangeThreads, "the look-back reads one published word per thread");
 __device__ __forceinline__ void place_range(const uint32_t range, const uint32_t ranges, uint32_t G, uint32_t shift,
                                             uint32_t nnz, uint32_t max_chunks, const GroupPlan& plan, uint32_t* lds_s,
                                             uint64_t* red) {
-  // lds_s: [span] cursor | [span] first position | [span] count | [span] first chunk;  red: [kRangeThreads / 64 + 1] x 2
+  // lds_s: [span] cursor | [span] first position | [span] count | [span] first chunk (inside the range)
   const uint32_t span = 1u << shift;
   const uint32_t g0 = range << shift;
   uint32_t* cursor = lds_s;
@@ -399,67 +441,46 @@ __device__ __forceinline__ void place_range(const uint32_t range, const uint32_t
   uint32_t* gcount = gfirst + span;
   uint32_t* gchunk = gcount + span;
   constexpr int NWV = kRangeThreads / kWave;
-  uint64_t acc = 0;
-  uint32_t live = 0;
-  {
-    constexpr int U = 16;   // loads in flight per thread: the last ranges read ~G words, two or three round trips
-    for (uint32_t g = threadIdx.x; g < g0; g += kRangeThreads * U) {
-      uint32_t c[U];
+  const uint64_t epoch = plan.epochs[1] & kEpochMask;
+  const uint32_t n0 = plan.rstart[range], n1 = plan.rstart[range + 1];
+  for (uint32_t i = threadIdx.x; i < span; i += kRangeThreads) gcount[i] = 0u;
+  __syncthreads();
+  // ---- 1. histogram, scan, publication ----
+  for (uint32_t b0 = n0 + threadIdx.x; b0 < n1; b0 += kRangeThreads * kSortBatch) {
+    uint32_t g[kSortBatch];
 #pragma unroll
-      for (int u = 0; u < U; ++u) c[u] = g + u * kRangeThreads < g0 ? plan.counts[g + u * kRangeThreads] : 0u;
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        acc += pack_count(c[u]);
-        live += c[u] != 0u ? 1u : 0u;
-      }
+    for (int u = 0; u < kSortBatch; ++u) {
+      const uint32_t n = b0 + u * kRangeThreads;
+      g[u] = n < n1 ? plan.grp_mid[n] - g0 : kNoGroup;
     }
 #pragma unroll
-    for (int d = kWave / 2; d > 0; d >>= 1) {
-      const uint32_t lo_w = __shfl_down((uint32_t)acc, d, kWave), hi_w = __shfl_down((uint32_t)(acc >> 32), d, kWave);
-      acc += (uint64_t)lo_w | ((uint64_t)hi_w << 32);
-      live += __shfl_down(live, d, kWave);
-    }
-    if ((threadIdx.x & 63) == 0) {
-      red[threadIdx.x >> 6] = acc;
-      red[NWV + 1 + (threadIdx.x >> 6)] = live;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      uint64_t a = 0, l = 0;
-      for (int w = 0; w < NWV; ++w) {
-        a += red[w];
-        l += red[NWV + 1 + w];
-      }
-      red[NWV] = a;
-      red[2 * NWV + 1] = l;
-    }
-    __syncthreads();
+    for (int u = 0; u < kSortBatch; ++u)
+      if (g[u] < span) atomicAdd(&gcount[g[u]], 1u);
   }
-  const uint64_t base = red[NWV];
+  __syncthreads();
   uint64_t carry = 0;
   uint32_t live_here = 0;
   for (uint32_t b0 = 0; b0 < span; b0 += kRangeThreads) {
     const uint32_t i = b0 + threadIdx.x;
     const bool on = i < span && g0 + i < G;
-    const uint32_t c = on ? plan.counts[g0 + i] : 0u;
+    const uint32_t c = i < span ? gcount[i] : 0u;
     uint64_t total;
-    const uint64_t pre = base + carry + block_exclusive<uint64_t, kRangeThreads>(pack_count(c), red, total);
-    if (on) {
-      gfirst[i] = cursor[i] = (uint32_t)pre;
-      gcount[i] = c;
+    const uint64_t pre = carry + block_exclusive<uint64_t, kRangeThreads>(pack_count(c), red, total);
+    if (i < span) {
+      gfirst[i] = cursor[i] = n0 + (uint32_t)pre;
       gchunk[i] = (uint32_t)(pre >> 32);
-      plan.gpre[g0 + i] = pre;
     }
+    if (on) plan.counts[g0 + i] = c;
     carry += total;
     live_here += (uint32_t)__syncthreads_count(c != 0u);
   }
-  if (range == ranges - 1 && threadIdx.x == 0) {
-    plan.gpre[G] = base + carry;   // (live ids, chunks)
-    // how many groups hold an id at all: the backward's epilogue / finalize pick their sparse or dense form by it
-    plan.counts[G] = (uint32_t)red[2 * NWV + 1] + live_here;
+  const uint32_t chunks_here = (uint32_t)(carry >> 32);
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&plan.rpub[range], (epoch << 24) | (uint64_t)chunks_here, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&plan.rpub[ranges + range], (epoch << 24) | (uint64_t)live_here, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
-  const uint32_t n0 = plan.rstart[range], n1 = plan.rstart[range + 1];
+  // ---- 2. final positions ----
   for (uint32_t b0 = n0 + threadIdx.x; b0 < n1; b0 += kRangeThreads * kSortBatch) {
     uint32_t gl[kSortBatch], i2v[kSortBatch], vv[kSortBatch];   // all loads of the batch first
 #pragma unroll
@@ -477,15 +498,63 @@ __device__ __forceinline__ void place_range(const uint32_t range, const uint32_t
       if (dst >= nnz) continue;   // as in the spread step: never trust a counter with an address
       plan.i2s[dst] = i2v[u];
       plan.vals[dst] = vv[u];
-      const uint32_t rank = dst - gfirst[gl[u]];
-      if (rank % kChunk == 0) {  // this id opens a chunk of its group: it writes the descriptor
-        const uint32_t c = gcount[gl[u]];
-        const uint32_t chunks = (c + kChunk - 1) / kChunk, k = rank / kChunk;
-        const uint32_t len = c - rank < (uint32_t)kChunk ? c - rank : (uint32_t)kChunk;
-        if (gchunk[gl[u]] + k < max_chunks) plan.ctab[gchunk[gl[u]] + k] = make_uint4(dst, g0 + gl[u], len | (k == 0 ? kFirstBit : 0u) | (k + 1 == chunks ? kLastBit : 0u),
-                                                  gchunk[gl[u]] + chunks);
-      }
     }
+  }
+  // ---- 3. look back: chunks (and, for the last range, non-empty groups) of the ranges before this one ----
+  uint64_t before = 0, live_before = 0;
+  if (threadIdx.x < range) {
+    const bool want_live = range == ranges - 1;
+    uint64_t v = 0, w = epoch << 24;
+    for (uint32_t spin = 0; spin < (1u << 20); ++spin) {
+      v = __hip_atomic_load(&plan.rpub[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (want_live) w = __hip_atomic_load(&plan.rpub[ranges + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((v >> 24) == epoch && (w >> 24) == epoch) break;
+      __builtin_amdgcn_s_sleep(8);
+    }
+    before = (v >> 24) == epoch ? (v & 0xffffffull) : 0ull;
+    live_before = (w >> 24) == epoch ? (w & 0xffffffull) : 0ull;
+  }
+#pragma unroll
+  for (int d = kWave / 2; d > 0; d >>= 1) {
+    before += __shfl_down((uint32_t)before, d, kWave);        // (< 2^32: at most 2^26 chunks in a call)
+    live_before += __shfl_down((uint32_t)live_before, d, kWave);
+  }
+  __syncthreads();   // (red was the scan's scratch)
+  if ((threadIdx.x & 63) == 0) {
+    red[threadIdx.x >> 6] = before;
+    red[NWV + 1 + (threadIdx.x >> 6)] = live_before;
+  }
+  __syncthreads();
+  uint64_t chunk_base = 0, live_all = 0;
+  for (int w = 0; w < NWV; ++w) {
+    chunk_base += red[w];
+    live_all += red[NWV + 1 + w];
+  }
+  // ---- 4. group starts and chunk descriptors ----
+  for (uint32_t i = threadIdx.x; i < span; i += kRangeThreads) {
+    const uint32_t g = g0 + i;
+    if (g >= G) continue;
+    const uint32_t c = gcount[i], first = gfirst[i];
+    const uint32_t ch0 = (uint32_t)chunk_base + gchunk[i];
+    plan.gpre[g] = (uint64_t)first | ((uint64_t)ch0 << 32);
+    const uint32_t chunks = (c + kChunk - 1) / kChunk;
+    for (uint32_t k = 0; k < chunks; ++k) {
+      const uint32_t rest = c - k * kChunk;
+      const uint32_t len = rest < (uint32_t)kChunk ? rest : (uint32_t)kChunk;
+      if (ch0 + k < max_chunks)
+        plan.ctab[ch0 + k] = make_uint4(first + k * kChunk, g, len | (k == 0 ? kFirstBit : 0u) | (k + 1 == chunks ? kLastBit : 0u), ch0 + chunks);
+    }
+  }
+  if (threadIdx.x == 0) {
+    if (range == ranges - 1) {
+      plan.gpre[G] = (uint64_t)n1 | ((chunk_base + chunks_here) << 32);   // (live ids, chunks)
+      // how many groups hold an id at all: the backward's epilogue / finalize pick their sparse or dense form by it
+      plan.counts[G] = (uint32_t)live_all + live_here;
+    }
+    if (range == 0) plan.epochs[0] = plan.epochs[1];   // the call is counted (nobody reads this word during this launch)
+    // this range's id counter, read for the last time by the spread step: left at (the NEXT call's tag | 0), so that
+    // the next decode step's first add already counts
+    plan.rcount[range] = ((plan.epochs[1] + 1ull) & kEpochMask38) << 26;
   }
 }
 
@@ -494,6 +563,50 @@ __global__ __launch_bounds__(kRangeThreads) void fast3_place_kernel(uint32_t nnz
   extern __shared__ uint32_t lds_s[];
   __shared__ uint64_t red[2 * (kRangeThreads / kWave + 1)];
   place_range(blockIdx.x, gridDim.x, G, shift, nnz, max_chunks, plan, lds_s, red);
+}
+
+// The piece table of a call past one 32-bit row window (struct Piece): a greedy walk over the id list on the device.  A
+// piece ends after `max_ids` ids or in front of the first id whose bag lies `max_rows` bags past the piece's first bag,
+// whichever comes first -- so every row of a piece is < max_rows when counted from its first bag, whatever the bag lengths
+// (empty bags included).  At most ceil(nnz / max_ids) + ceil(B / max_rows) pieces: the host launches that many, unused
+// slots have count 0.  One thread: a few dozen steps of one binary search each.
+__global__ void plan_pieces_kernel(const int64_t* __restrict__ offsets, int64_t B, int64_t nnz, const int32_t* __restrict__ nnz_dev,
+                                   long long max_ids, long long max_rows, int D, int slots, Piece* __restrict__ tab) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const long long total = live_count(nnz, nnz_dev);
+  long long pos = 0, zr = 0;
+  for (int k = 0; k < slots; ++k) {
+    Piece pc;
+    pc.pos0 = pos;
+    pc.count = 0;
+    pc.rowbase = 0;
+    pc.zero0 = pc.zero1 = zr;
+    pc.window_bytes = 0;
+    if (pos < total) {
+      const long long rb = bag_of_position(offsets, B, pos);
+      const long long row_end = rb + max_rows;   // first bag this piece must not reach
+      long long end = row_end < B ? (long long)offsets[row_end] : total;   // first position of that bag
+      end = end > total ? total : end;
+      end = end > pos + max_ids ? pos + max_ids : end;
+      if (end <= pos) end = pos + 1;   // (cannot happen: the bag of `pos` starts at or before it and ends after it)
+      pc.count = end - pos;
+      pc.rowbase = rb;
+      // bags to clear: from where the piece before stopped up to the bag the next piece starts in -- inclusive when that
+      // bag began inside this piece (it is split between the two, and this one runs first)
+      if (end < total) {
+        const long long nb = bag_of_position(offsets, B, end);
+        pc.zero1 = (long long)offsets[nb] == end ? nb : nb + 1;
+      } else {
+        pc.zero1 = B;
+      }
+      if (pc.zero1 < pc.zero0) pc.zero1 = pc.zero0;
+      const long long rows_left = B - rb < max_rows ? B - rb : max_rows;
+      pc.window_bytes = rows_left * (long long)D * 4;
+      zr = pc.zero1;
+      pos = end;
+    }
+    tab[k] = pc;
+  }
 }
 
 // ---------------------------------------------------------------------------------
@@ -510,7 +623,7 @@ __global__ __launch_bounds__(kRangeThreads) void fast3_place_kernel(uint32_t nnz
 constexpr int kPrefixGroups = TTEMB_PREFIX_GROUPS;   // values of i0 per wavefront
 template <int Q0, int Q1, int Q2, int R1, int R2>
 __device__ __forceinline__ void prefix_unit(const float* __restrict__ G0, const float* __restrict__ G1, uint32_t p0,
-                                            const GroupPlan& plan, uint32_t i0_block, uint32_t i1, int lane, uint32_t epoch) {
+                                            const GroupPlan& plan, uint32_t i0_block, uint32_t i1, int lane, bool stamps) {
   using C = Cfg<Q0, Q1, Q2, R1, R2>;
   constexpr int GM = 16 / Q0;  // whole groups per 16-row MFMA tile (q0 = 5: three groups, the last tile row idles)
   const int hi = lane >> 4, lo = lane & 15;
@@ -518,10 +631,10 @@ __device__ __forceinline__ void prefix_unit(const float* __restrict__ G0, const 
   const uint32_t i0_end = i0_begin + kPrefixGroups < p0 ? i0_begin + kPrefixGroups : p0;
   // any work at all?  (one lane per i0 of the slice)
   const uint32_t my = i0_begin + lane;
-  // which groups hold an id: their counters when the grouping is complete (epoch 0), else the stamps the decode step of
-  // this call left (the unit then runs next to the spread step, before the counters exist)
+  // which groups hold an id: their counters when the grouping is complete, else the stamps the decode step of this call
+  // left (the unit then runs next to the spread step, before the counters exist; epochs[0] is stable until the place step)
   const bool mine = lane < kPrefixGroups && my < i0_end &&
-                    (epoch != 0u ? plan.gstamp[i1 * p0 + my] == epoch : plan.counts[i1 * p0 + my] != 0u);
+                    (stamps ? plan.gstamp[i1 * p0 + my] == (uint32_t)(plan.epochs[0] + 1ull) : plan.counts[i1 * p0 + my] != 0u);
   const unsigned long long live = __ballot(mine);
   if (!live) return;
   const float* g1 = G1 + (size_t)i1 * C::ROW1;
@@ -564,8 +677,8 @@ __device__ __forceinline__ void prefix_unit(const float* __restrict__ G0, const 
 
 template <int Q0, int Q1, int Q2, int R1, int R2>
 __global__ __launch_bounds__(64) void fast3_prefix_kernel(const float* __restrict__ G0, const float* __restrict__ G1,
-                                                          uint32_t p0, uint32_t epoch, GroupPlan plan) {
-  prefix_unit<Q0, Q1, Q2, R1, R2>(G0, G1, p0, plan, blockIdx.x, blockIdx.y, (int)threadIdx.x, epoch);
+                                                          uint32_t p0, uint32_t stamps, GroupPlan plan) {
+  prefix_unit<Q0, Q1, Q2, R1, R2>(G0, G1, p0, plan, blockIdx.x, blockIdx.y, (int)threadIdx.x, stamps != 0u);
 }
 
 // Does the prefix unit fit the 128 registers of a 1024-thread workgroup next to the spread step?  At rank 32 the G1 row a
@@ -581,22 +694,21 @@ struct PrefixRides {
 // each -- two latency-bound kernels share the machine instead of queueing.
 template <int Q0, int Q1, int Q2, int R1, int R2>
 __global__ __launch_bounds__(kSortThreads) void fast3_spread_prefix_kernel(uint32_t slices, uint32_t nnz, uint32_t per_slice,
-                                                                          uint32_t shift, uint32_t ranges, uint32_t epoch,
+                                                                          uint32_t shift, uint32_t ranges,
                                                                           const float* __restrict__ G0,
                                                                           const float* __restrict__ G1, uint32_t p0,
                                                                           uint32_t p1, GroupPlan plan) {
   __shared__ uint32_t cursor[kMaxRanges];
-  __shared__ uint32_t part[2 * kSortThreads];
   __shared__ uint32_t wave_sums[kSortThreads / kWave];
   if (blockIdx.x < slices) {
-    spread_slice(blockIdx.x, slices, nnz, per_slice, shift, ranges, plan, cursor, part, wave_sums);
+    spread_slice(blockIdx.x, slices, nnz, per_slice, shift, ranges, plan, cursor, wave_sums);
     return;
   }
   const uint32_t blocks0 = (p0 + kPrefixGroups - 1) / kPrefixGroups;
   const uint32_t unit = (blockIdx.x - slices) * (kSortThreads / kWave) + (threadIdx.x >> 6);
   if (unit >= blocks0 * p1) return;
   if constexpr (PrefixRides<Q0, Q1, Q2, R1, R2>::value)
-    prefix_unit<Q0, Q1, Q2, R1, R2>(G0, G1, p0, plan, unit % blocks0, unit / blocks0, (int)(threadIdx.x & 63), epoch);
+    prefix_unit<Q0, Q1, Q2, R1, R2>(G0, G1, p0, plan, unit % blocks0, unit / blocks0, (int)(threadIdx.x & 63), true);
 }
 
 // ---------------------------------------------------------------------------------
@@ -664,6 +776,10 @@ __global__ __launch_bounds__(kChainWaves * 64) void fast3_forward_kernel(const f
   constexpr int D4 = C::D / 4, NLO = (D4 + 3) / 4;          // float4 pieces of an output row / per lane
   constexpr int PF = C::M2 * R2, PF4 = PF / 4, NLP = (PF4 + kWave - 1) / kWave;
   const rsrc_t r_g2 = make_rsrc(G2, p2 * (uint32_t)C::ROW2 * 4u);
+  if (plan.piece != nullptr) {   // a piece of a larger call: rows count from the piece's first bag
+    out += plan.piece->rowbase * (long long)C::D;
+    out_bytes = (uint32_t)plan.piece->window_bytes;
+  }
   const rsrc_t r_out = make_rsrc(out, out_bytes);
   const uint32_t rowpiece = 16u * (uint32_t)j_l;
   const uint32_t g_last = (F4G % 4 == 0 || j_l + 4 * (NLG - 1) < F4G) ? rowpiece + 64u * (NLG - 1) : kOobBase;
@@ -943,6 +1059,10 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
   constexpr int F4D = C::D / 4, NLD = (F4D + 3) / 4;      // float4 pieces of a d_output row / per lane
   constexpr int PF = C::M2 * R2, PF4 = PF / 4, NLP = (PF4 + kWave - 1) / kWave;
   const rsrc_t r_g2 = make_rsrc(G2, p2 * (uint32_t)C::ROW2 * 4u);
+  if (plan.piece != nullptr) {   // a piece of a larger call: rows count from the piece's first bag
+    d_out += plan.piece->rowbase * (long long)C::D;
+    dout_bytes = (uint32_t)plan.piece->window_bytes;
+  }
   const rsrc_t r_do = make_rsrc(d_out, dout_bytes);
 
   // ---- kernel-lifetime lane constants ----
@@ -1131,6 +1251,47 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
 
 #if !(defined(TTEMB_ABL) && (TTEMB_ABL & 4))
     // ---- dP += dO (q0q1 x 16 q2) . G2s^T (16 q2 x r2); K-steps whose four ids lie past the chunk's length are skipped ----
+#ifndef TTEMB_NO_PIPE_LDS
+    // The LDS reads of block b4 + 1 are issued BEFORE the MFMAs of block b4 (two operand sets): a block no longer opens
+    // with a wait for its own reads (~100 cycles, three or four times per block).  The reads of a block past the chunk's
+    // length are issued all the same (they hit rows of an older chunk and are not used).
+    {
+      float av2[2][Q2][C::MT2], bv2[2][Q2][C::RT2];
+      auto load_block = [&](int b4, int slot) {
+#pragma unroll
+        for (int kk = 0; kk < Q2; ++kk) {
+#pragma unroll
+          for (int mt = 0; mt < C::MT2; ++mt) av2[slot][kk][mt] = dbuf[offA[mt] + b4 * 4 * C::LDOB + kk];
+#pragma unroll
+          for (int t = 0; t < C::RT2; ++t) {
+            bv2[slot][kk][t] = bbuf[offB[t] + b4 * 4 * C::LDBB + kk];
+            if (16 * t + lo >= R2) bv2[slot][kk][t] = 0.f;
+          }
+        }
+      };
+      load_block(0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int b4 = 0; b4 < kChunk / 4; ++b4) {
+        if (b4 + 1 < kChunk / 4) load_block(b4 + 1, (b4 + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if ((uint32_t)(4 * b4) < len) {
+#pragma unroll
+          for (int kk = 0; kk < Q2; ++kk)
+#pragma unroll
+            for (int mt = 0; mt < C::MT2; ++mt)
+#pragma unroll
+              for (int t = 0; t < C::RT2; ++t) {
+                if (kNarrowTail && mt == C::MT2 - 1)
+                  dp[mt][t] = __builtin_amdgcn_mfma_f32_4x4x1f32(av2[b4 & 1][kk][mt], bv2[b4 & 1][kk][t], dp[mt][t], 0, 0, 0);
+                else
+                  dp[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av2[b4 & 1][kk][mt], bv2[b4 & 1][kk][t], dp[mt][t], 0, 0, 0);
+              }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#else
 #pragma unroll
     for (int b4 = 0; b4 < kChunk / 4; ++b4) {
       if ((uint32_t)(4 * b4) < len) {
@@ -1158,6 +1319,7 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
       __builtin_amdgcn_sched_barrier(0);  // keeps operand loads from piling up in registers
     }
 #endif
+#endif
     TTEMB_STAMP(1);
     // ---- E = P^T (r2 x q0q1) . dO (q0q1 x 16 q2): the A operand (P^T) is read once, column tiles without an id are skipped ----
     f32x4 e[C::RT2][C::NT2];
@@ -1174,6 +1336,36 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
         if (16 * t + lo >= R2 || !k_ok) ap[s][t] = 0.f;
       }
     }
+#ifndef TTEMB_NO_PIPE_LDS   // (the same two-set scheme for the B operand of the E product: -2.5 % on the fused kernel, A/B in one call)
+    {
+      float be[2][KS];
+      auto load_tile = [&](int nt, int slot) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          const bool k_ok = 4 * s + 3 < C::M2 || 4 * s + hi < C::M2;
+          be[slot][s] = dbuf[offE[nt] + 4 * s * Q2];
+          if (!k_ok) be[slot][s] = 0.f;
+        }
+      };
+      load_tile(0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nt = 0; nt < C::NT2; ++nt) {
+        if (nt + 1 < C::NT2) load_tile(nt + 1, (nt + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if ((uint32_t)(16 * nt) < len * Q2) {
+#pragma unroll
+          for (int t = 0; t < C::RT2; ++t) e[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int t = 0; t < C::RT2; ++t)
+              e[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[s][t], be[nt & 1][s], e[t][nt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#else
 #pragma unroll
     for (int nt = 0; nt < C::NT2; ++nt) {
       if ((uint32_t)(16 * nt) < len * Q2) {
@@ -1191,6 +1383,7 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+#endif
 #endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();  // every LDS read of this chunk is done: the next chunk's rows may land
@@ -1276,8 +1469,11 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
       }
     }
     if (FUSE && reduce_now) {
+#if !(defined(TTEMB_ABL) && (TTEMB_ABL & 32))   // (ablation 32: no barriers -- wrong sums, timing only)
       __syncthreads();   // the round's E rows and their lists are in LDS
+#endif
       TTEMB_STAMP(5);
+#if !(defined(TTEMB_ABL) && (TTEMB_ABL & 16))   // (ablation 16: no list walk)
       {
         // slab row of this lane in quad q: i2 = 8 (q GPW + lane group) + wave.  First the heads of all quads, then the
         // first row of every list (reads in flight together), then whatever is left of longer lists
@@ -1315,9 +1511,15 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
           }
         }
       }
+#endif
+#if defined(TTEMB_ABL) && (TTEMB_ABL & 32)
+      const bool any = more1;   // every wavefront for itself (the loop ends with the wavefront's own share)
+      TTEMB_STAMP(6);
+#else
       const bool any = __ballot(lane < kFuseWaves && f_more[lane & (kFuseWaves - 1)] != 0u) != 0ull;
       TTEMB_STAMP(6);
       __syncthreads();   // every E row has been added: the regions take the next chunks' rows
+#endif
       TTEMB_STAMP(7);
       stage((d_nxt.z & kFirstBit) != 0u);
       o_nn = offsets(d_nn, i2_nn, val_nn);
@@ -1740,8 +1942,8 @@ __global__ __launch_bounds__((EpiCfg<Q0, Q1, Q2, R1, R2>::WAVES * 64)) void fast
 // rows split the terms, so every load instruction reads 128 contiguous bytes per row and many
 // are in flight; the 8 partial sums meet in LDS.  Every output is written exactly once.
 __device__ __forceinline__ void finalize_emit(const FusedUpdate& upd, int t, float* __restrict__ grad, int idx, float g) {
-  if (upd.w[0] == nullptr) {   // dense mode: the gradient itself
-    grad[idx] = g;
+  if (upd.w[0] == nullptr) {   // dense mode: the gradient itself (eps = 1: added to what an earlier piece of the call left)
+    grad[idx] = upd.eps != 0.f ? grad[idx] + g : g;
   } else if (upd.st[0] == nullptr) {   // fused SGD (tt_embeddings_cuda.cu:381-397), every row
     upd.w[t][idx] -= upd.lr * g;
   } else {                             // fused Adagrad (tt_embeddings_cuda.cu:399-419)
@@ -1900,6 +2102,7 @@ static bool wide(const DevShape& s) {
 }
 
 bool fast3_supported(const DevShape& s) { return classify(s) || wide(s); }
+bool fast3_wide(const DevShape& s) { return wide(s); }
 
 static int64_t num_groups(const DevShape& s) { return (int64_t)s.p[0] * s.p[1]; }
 
@@ -1934,13 +2137,46 @@ bool fast3_pays(const DevShape& s, int64_t nnz) {
 
 // the chain kernels address every table through 32-bit byte offsets (buffer descriptors): 4 GiB each; the dG2
 // reduce keeps two counters per i2 in LDS (p2 <= 4096: 36 KB); p1 is a grid.y extent
-bool fast3_fits(const DevShape& s, int64_t nnz, int64_t B) {
-  const int64_t lim = int64_t(1) << 31;   // an offset of 2 GiB marks "no row" in the chain kernels (kOobBase)
-  return B * s.D * 4 < lim && B < (int64_t(1) << 24) && (wide(s) || nnz * (int64_t)s.row_len[2] * 4 < lim) &&
-         num_groups(s) * (int64_t)s.q[0] * s.q[1] * s.R[2] * 4 < lim && s.p[2] <= 4096 && s.p[1] < 65536 &&
-         num_groups(s) <= (int64_t)kMaxRanges * 4096 &&   // the grouping pass: <= 512 ranges of <= 4096 groups (64 KB of LDS),
-         nnz <= (int64_t)kMaxSlices * 0xffff;             // <= 1024 slices of < 65 536 ids (uint16 histogram table)
+// the table itself: what no sub-batching can cure
+static bool fits_shape(const DevShape& s) {
+  const int64_t lim = int64_t(1) << 31;
+  return num_groups(s) * (int64_t)s.q[0] * s.q[1] * s.R[2] * 4 < lim && s.p[2] <= 4096 && s.p[1] < 65536 &&
+         num_groups(s) <= (int64_t)kMaxRanges * 4096;   // the grouping pass: <= 512 ranges of <= 4096 groups (64 KB of LDS)
 }
+// DIAGNOSTIC (ttemb_set_piece_limits): tests cut small calls into pieces with it; 0 = the hardware's limits
+static std::atomic<int64_t> g_piece_rows{0}, g_piece_ids{0};
+void fast3_set_piece_limits(int64_t rows, int64_t ids) {
+  g_piece_rows.store(rows > 0 ? rows : 0);
+  g_piece_ids.store(ids > 0 ? ids : 0);
+}
+// one piece: `nnz` ids whose bags span `B` rows
+static bool fits_piece(const DevShape& s, int64_t nnz, int64_t B) {
+  const int64_t lim = int64_t(1) << 31;   // an offset of 2 GiB marks "no row" in the chain kernels (kOobBase)
+  const int64_t tr = g_piece_rows.load(), ti = g_piece_ids.load();
+  if ((tr > 0 && B > tr) || (ti > 0 && nnz > ti)) return false;
+  return B * s.D * 4 < lim && B < (int64_t(1) << 24) && (wide(s) || nnz * (int64_t)s.row_len[2] * 4 < lim) &&
+         nnz < (int64_t(1) << 26);        // 26-bit range counters under their epoch tags
+}
+// rows / ids of a piece of a call that is cut up (struct Piece): the row window the chain kernels address, and a cap on the ids
+// that keeps a piece's tables (the E table of the unfused backward: ids x r2 q2 floats) under 2 GiB and the workspace modest
+static int64_t piece_rows(const DevShape& s) {
+  const int64_t by_bytes = ((int64_t(1) << 31) - 1) / ((int64_t)s.D * 4), by_field = (int64_t(1) << 24) - 1, t = g_piece_rows.load();
+  const int64_t hw = by_bytes < by_field ? by_bytes : by_field;
+  return t > 0 && t < hw ? t : hw;
+}
+static int64_t piece_ids(const DevShape& s) {
+  const int64_t by_e = ((int64_t(1) << 31) - 1) / ((int64_t)s.row_len[2] * 4), cap = int64_t(4) << 20, t = g_piece_ids.load();
+  const int64_t hw = (wide(s) || by_e > cap) ? cap : by_e;
+  return t > 0 && t < hw ? t : hw;
+}
+static int piece_slots(const DevShape& s, int64_t nnz, int64_t B) {
+  const int64_t li = piece_ids(s), lr = piece_rows(s);
+  return (int)((nnz + li - 1) / li + (B + lr - 1) / lr);
+}
+bool fast3_fits(const DevShape& s, int64_t nnz, int64_t B) { return fits_shape(s) && fits_piece(s, nnz, B); }
+// a call past one piece runs as several (needs the bag boundaries: `offsets`)
+bool fast3_fits_in_pieces(const DevShape& s, int64_t nnz, int64_t B) { return fits_shape(s) && nnz > 0 && B > 0 && nnz <= 0x7fffffffll; }
+static int64_t pieces_head_bytes(const DevShape& s, int64_t nnz, int64_t B) { return align256((int64_t)piece_slots(s, nnz, B) * (int64_t)sizeof(Piece)); }
 
 #ifndef TTEMB_ROWS_B
 #define TTEMB_ROWS_B 2048
@@ -2078,9 +2314,12 @@ static int64_t carve_workspace(const DevShape& s, int64_t nnz, bool bwd, bool pl
   if (need_grouping) {
     uint32_t* in[6];
     for (int i = 0; i < 6; ++i) in[i] = (uint32_t*)take(nnz * 4);
-    uint16_t* sh = (uint16_t*)take((int64_t)sort_slices(nnz) * sort_ranges(G) * 2);
+    uint32_t* sh = (uint32_t*)take((int64_t)sort_slices(nnz) * sort_ranges(G) * 4);
+    uint64_t* rc = (uint64_t*)take(sort_ranges(G) * 8);
     uint32_t* rs = (uint32_t*)take((sort_ranges(G) + 1) * 4);
     uint32_t* gs = (uint32_t*)take(G * 4);
+    uint64_t* ep = (uint64_t*)take(16);
+    uint64_t* rp = (uint64_t*)take(sort_ranges(G) * 16);
     if (pl) {
       pl->grp_in = in[0];
       pl->i2_in = in[1];
@@ -2089,8 +2328,11 @@ static int64_t carve_workspace(const DevShape& s, int64_t nnz, bool bwd, bool pl
       pl->i2_mid = in[4];
       pl->vals_mid = in[5];
       pl->shist = sh;
+      pl->rcount = rc;
       pl->rstart = rs;
       pl->gstamp = gs;
+      pl->epochs = ep;
+      pl->rpub = rp;
     }
   }
   if (wide(s)) {   // the lists of non-empty rows the compacted GEMMs walk (rebuilt from the plan's counts by every call)
@@ -2121,24 +2363,17 @@ static int64_t carve_workspace(const DevShape& s, int64_t nnz, bool bwd, bool pl
 }
 
 int64_t fast3_workspace_bytes(const DevShape& s, int32_t op, int64_t nnz, int64_t B) {
-  (void)B;
+  if (!fits_piece(s, nnz, B)) {   // several pieces: the piece table, then one piece's tables (plan inside)
+    const int64_t li = piece_ids(s);
+    return pieces_head_bytes(s, nnz, B) + carve_workspace(s, nnz < li ? nnz : li, op == TTEMB_OP_BACKWARD, true, true, nullptr, nullptr) + 256;
+  }
   return carve_workspace(s, nnz, op == TTEMB_OP_BACKWARD, true, true, nullptr, nullptr) + 256;
 }
 
 // fill plan->{i2s, vals, counts, gpre, ctab} from the ids
 static int run_prefix(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, hipStream_t st);
 static int run_spread_prefix(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int64_t nnz, int slices, uint32_t per_slice,
-                             int ranges, int shift, uint32_t epoch, hipStream_t st);
-
-// A word no earlier call of this process has used (0 is "no stamps"): the decode step marks the groups that hold an id with it.
-// Whatever else the stamp array holds -- a fresh allocation, another table's stamps, those of the same call replayed from a
-// captured graph -- can at worst make the prefix kernel compute a product for a group without ids.
-static uint32_t next_epoch() {
-  static std::atomic<uint32_t> counter{0};
-  uint32_t e = counter.fetch_add(1u, std::memory_order_relaxed) + 1u;
-  if (e == 0u) e = counter.fetch_add(1u, std::memory_order_relaxed) + 1u;
-  return e;
-}
+                             int ranges, int shift, hipStream_t st);
 
 static int group_ids(const DevShape& s, const CorePtrs& cores, const int64_t* indices, const int64_t* rowidx,
                      const int64_t* offsets, int64_t nnz, const int32_t* nnz_dev, int64_t B, float* zero_out,
@@ -2149,15 +2384,14 @@ static int group_ids(const DevShape& s, const CorePtrs& cores, const int64_t* in
   const uint32_t per_slice = (uint32_t)((nnz + slices - 1) / slices);
   const size_t span = (size_t)1 << shift;
   if (ranges > kMaxRanges || span * 16 > 64 * 1024) return fail(TTEMB_E_UNSUPPORTED, "too many (i0, i1) groups for the grouping pass");
-  if (per_slice > 0xffffu) return fail(TTEMB_E_UNSUPPORTED, "too many ids for the grouping pass (a slice holds < 65 536)");
-  const uint32_t epoch = next_epoch();
+  if (nnz >= (int64_t(1) << 26)) return fail(TTEMB_E_UNSUPPORTED, "too many ids for the grouping pass (26-bit range counters)");
   hipLaunchKernelGGL(fast3_decode_kernel, dim3((unsigned)slices), dim3(kSortThreads), 0, st, indices, rowidx, offsets,
                      (uint32_t)nnz, per_slice, nnz_dev, B, s.D, zero_out, sentinel, (uint32_t)s.p[0], (uint32_t)s.p[1],
-                     (uint32_t)s.p[2], (uint32_t)shift, (uint32_t)ranges, (uint32_t)G, epoch, *plan);
+                     (uint32_t)s.p[2], (uint32_t)shift, (uint32_t)ranges, *plan);
   int rc = check_hip(hipGetLastError(), "fast3_decode_kernel");
   if (rc) return rc;
   if (with_prefix && !wide(s)) {
-    rc = run_spread_prefix(s, cores, *plan, nnz, slices, per_slice, ranges, shift, epoch, st);
+    rc = run_spread_prefix(s, cores, *plan, nnz, slices, per_slice, ranges, shift, st);
   } else {
     hipLaunchKernelGGL(fast3_spread_kernel, dim3((unsigned)slices), dim3(kSortThreads), 0, st, (uint32_t)nnz, per_slice,
                        (uint32_t)shift, (uint32_t)ranges, *plan);
@@ -2176,8 +2410,10 @@ static int group_ids(const DevShape& s, const CorePtrs& cores, const int64_t* in
 // two-phase forward), 2 = the plan is grouped, add the prefix products, 3 = the plan is complete
 static int prepare(const DevShape& s, const CorePtrs& cores, bool bwd, const int64_t* indices, const int64_t* rowidx,
                    const int64_t* offsets, int64_t nnz, const int32_t* nnz_dev, int64_t B, float* zero_out, void* ws,
-                   int64_t ws_bytes, void* plan_buf, int64_t plan_bytes, int plan_state, GroupPlan* plan, hipStream_t st) {
+                   int64_t ws_bytes, void* plan_buf, int64_t plan_bytes, int plan_state, GroupPlan* plan, hipStream_t st,
+                   const Piece* piece = nullptr) {
   memset(plan, 0, sizeof(*plan));
+  plan->piece = piece;
   const bool external = plan_buf != nullptr && plan_bytes >= fast3_plan_bytes(s, nnz);
   if (plan_state != 0 && !external) return fail(TTEMB_E_BADARG, "this call needs a plan buffer of ttemb_plan_bytes() bytes");
   const bool reuse = plan_state >= 2;
@@ -2201,7 +2437,7 @@ template <int Q0, int Q1, int Q2, int R1, int R2>
 static int run_prefix_t(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, hipStream_t st) {
   hipLaunchKernelGGL((fast3_prefix_kernel<Q0, Q1, Q2, R1, R2>),
                      dim3((unsigned)((s.p[0] + kPrefixGroups - 1) / kPrefixGroups), (unsigned)s.p[1]), dim3(64), 0, st,
-                     cores.c[0], cores.c[1], (uint32_t)s.p[0], 0u, plan);   // (epoch 0: on the counters of a complete grouping)
+                     cores.c[0], cores.c[1], (uint32_t)s.p[0], 0u, plan);   // (on the counters of a complete grouping)
   return check_hip(hipGetLastError(), "fast3_prefix_kernel");
 }
 
@@ -2256,27 +2492,27 @@ static int run_prefix(const DevShape& s, const CorePtrs& cores, const GroupPlan&
 
 template <int Q0, int Q1, int Q2, int R1, int R2>
 static int run_spread_prefix_t(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int64_t nnz, int slices,
-                               uint32_t per_slice, int ranges, int shift, uint32_t epoch, hipStream_t st) {
+                               uint32_t per_slice, int ranges, int shift, hipStream_t st) {
   unsigned units = (unsigned)((s.p[0] + kPrefixGroups - 1) / kPrefixGroups) * (unsigned)s.p[1];
   const unsigned per_wg = kSortThreads / kWave;
   if constexpr (!PrefixRides<Q0, Q1, Q2, R1, R2>::value) {   // a launch of its own, on this call's stamps
     hipLaunchKernelGGL((fast3_prefix_kernel<Q0, Q1, Q2, R1, R2>),
                        dim3((unsigned)((s.p[0] + kPrefixGroups - 1) / kPrefixGroups), (unsigned)s.p[1]), dim3(64), 0, st,
-                       cores.c[0], cores.c[1], (uint32_t)s.p[0], epoch, plan);
+                       cores.c[0], cores.c[1], (uint32_t)s.p[0], 1u, plan);
     int rc = check_hip(hipGetLastError(), "fast3_prefix_kernel");
     if (rc) return rc;
     units = 0;
   }
   hipLaunchKernelGGL((fast3_spread_prefix_kernel<Q0, Q1, Q2, R1, R2>), dim3((unsigned)slices + (units + per_wg - 1) / per_wg),
-                     dim3(kSortThreads), 0, st, (uint32_t)slices, (uint32_t)nnz, per_slice, (uint32_t)shift, (uint32_t)ranges, epoch,
+                     dim3(kSortThreads), 0, st, (uint32_t)slices, (uint32_t)nnz, per_slice, (uint32_t)shift, (uint32_t)ranges,
                      cores.c[0], cores.c[1], (uint32_t)s.p[0], (uint32_t)s.p[1], plan);
   return check_hip(hipGetLastError(), "fast3_spread_prefix_kernel");
 }
 
 static int run_spread_prefix(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int64_t nnz, int slices, uint32_t per_slice,
-                             int ranges, int shift, uint32_t epoch, hipStream_t st) {
+                             int ranges, int shift, hipStream_t st) {
   if (classify(s)) {
-#define TTEMB_X(a, b, c, d, e) if (shape_is(s, a, b, c, d, e)) return run_spread_prefix_t<a, b, c, d, e>(s, cores, plan, nnz, slices, per_slice, ranges, shift, epoch, st);
+#define TTEMB_X(a, b, c, d, e) if (shape_is(s, a, b, c, d, e)) return run_spread_prefix_t<a, b, c, d, e>(s, cores, plan, nnz, slices, per_slice, ranges, shift, st);
     TTEMB_FAST3_SHAPES(TTEMB_X)
 #undef TTEMB_X
   }
@@ -2398,6 +2634,36 @@ int launch_forward_fast3(const DevShape& s, const CorePtrs& cores, const int64_t
                          int64_t B, float* output, bool zero_rows, void* ws, int64_t ws_bytes, void* plan_buf,
                          int64_t plan_bytes, int phase, hipStream_t st) {
   if (nnz <= 0) return TTEMB_OK;
+  if (!fits_piece(s, nnz, B)) {
+    // The call is cut into pieces (struct Piece).  The id-only half of a two-phase forward does nothing then, the lookup half
+    // is the whole forward; the caller's plan buffer is not used (a plan describes one piece; the backward regroups).
+    if (phase == 1) return TTEMB_OK;
+    if (offsets == nullptr) return fail(TTEMB_E_UNSUPPORTED, "a call of this size needs the bag boundaries (offsets)");
+    const int slots = piece_slots(s, nnz, B);
+    const int64_t head = pieces_head_bytes(s, nnz, B), li = piece_ids(s), np = nnz < li ? nnz : li;
+    if (ws == nullptr || ws_bytes < head) return fail(TTEMB_E_WORKSPACE, "forward needs room for the piece table");
+    Piece* tab = reinterpret_cast<Piece*>(ws);
+    hipLaunchKernelGGL(plan_pieces_kernel, dim3(1), dim3(64), 0, st, offsets, B, nnz, nnz_dev, (long long)li, (long long)piece_rows(s),
+                       s.D, slots, tab);
+    int rc = check_hip(hipGetLastError(), "plan_pieces_kernel");
+    for (int k = 0; k < slots && rc == TTEMB_OK; ++k) {
+      GroupPlan plan;
+      rc = prepare(s, cores, false, indices, rowidx, offsets, np, nullptr, B, zero_rows ? output : nullptr,
+                   reinterpret_cast<char*>(ws) + head, ws_bytes - head, nullptr, 0, 0, &plan, st, tab + k);
+      if (rc) break;
+      rc = fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
+      if (wide(s)) {
+#define TTEMB_X(a, b, c, d, e) if (shape_is(s, a, b, c, d, e)) rc = run_forward_direct<a, b, c, d, e>(s, cores, plan, np, piece_rows(s), output, st);
+        TTEMB_WIDE3_SHAPES(TTEMB_X)
+#undef TTEMB_X
+      } else {
+#define TTEMB_X(a, b, c, d, e) if (shape_is(s, a, b, c, d, e)) rc = run_forward<a, b, c, d, e>(s, cores, plan, np, piece_rows(s), output, st);
+        TTEMB_FAST3_SHAPES(TTEMB_X)
+#undef TTEMB_X
+      }
+    }
+    return rc;
+  }
   GroupPlan plan;
   int rc = prepare(s, cores, false, indices, rowidx, offsets, nnz, nnz_dev, B, zero_rows ? output : nullptr, ws, ws_bytes,
                    plan_buf, plan_bytes, phase, &plan, st);   // phase 0 / 1 / 2 = whole forward / ids only / lookup on a grouped plan
@@ -2502,6 +2768,38 @@ int launch_backward_fast3(const DevShape& s, const CorePtrs& cores, const int64_
     if (rc) return rc;
   }
   if (nnz <= 0) return TTEMB_OK;
+  if (!fits_piece(s, nnz, B)) {
+    // piece by piece (struct Piece): every piece regroups its ids (a plan describes one piece) and ADDS its gradient to what
+    // the pieces before it left -- the reference accumulates its batch_count chunks into d_tt_cores the same way and steps
+    // once (tt_embeddings_cuda.cu:633-651).  The optimiser step is the caller's, on the summed gradient.
+    if (update != nullptr) return fail(TTEMB_E_BADARG, "internal: a call in pieces writes gradients, the step follows");
+    if (offsets == nullptr) return fail(TTEMB_E_UNSUPPORTED, "a call of this size needs the bag boundaries (offsets)");
+    const int slots = piece_slots(s, nnz, B);
+    const int64_t head = pieces_head_bytes(s, nnz, B), li = piece_ids(s), np = nnz < li ? nnz : li;
+    if (ws == nullptr || ws_bytes < head) return fail(TTEMB_E_WORKSPACE, "backward needs room for the piece table");
+    Piece* tab = reinterpret_cast<Piece*>(ws);
+    hipLaunchKernelGGL(plan_pieces_kernel, dim3(1), dim3(64), 0, st, offsets, B, nnz, nnz_dev, (long long)li, (long long)piece_rows(s),
+                       s.D, slots, tab);
+    int rc = check_hip(hipGetLastError(), "plan_pieces_kernel");
+    for (int k = 0; k < slots && rc == TTEMB_OK; ++k) {
+      GroupPlan plan;
+      rc = prepare(s, cores, true, indices, rowidx, offsets, np, nullptr, B, nullptr, reinterpret_cast<char*>(ws) + head, ws_bytes - head,
+                   nullptr, 0, 0, &plan, st, tab + k);
+      if (rc) break;
+      upd.eps = k > 0 ? 1.f : 0.f;   // (dense mode: finalize adds to the gradient instead of writing it)
+      rc = fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
+      if (wide(s)) {
+#define TTEMB_X(a, b, c, d, e) if (shape_is(s, a, b, c, d, e)) rc = run_backward_wide<a, b, c, d, e>(s, cores, plan, np, piece_rows(s), d_output, d_cores, upd, st);
+        TTEMB_WIDE3_SHAPES(TTEMB_X)
+#undef TTEMB_X
+      } else {
+#define TTEMB_X(a, b, c, d, e) if (shape_is(s, a, b, c, d, e)) rc = run_backward<a, b, c, d, e>(s, cores, plan, np, piece_rows(s), d_output, d_cores, upd, st);
+        TTEMB_FAST3_SHAPES(TTEMB_X)
+#undef TTEMB_X
+      }
+    }
+    return rc;
+  }
   GroupPlan plan;
   int rc = prepare(s, cores, true, indices, rowidx, offsets, nnz, nnz_dev, B, nullptr, ws, ws_bytes,
                    const_cast<void*>(plan_buf), plan_bytes,

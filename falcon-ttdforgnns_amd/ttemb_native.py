@@ -28,7 +28,7 @@ PATH_AUTO, PATH_GENERIC, PATH_FAST3, PATH_PER_BAG = 0, 1, 2, 3
 # every symbol include/ttemb.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = (
     "ttemb_abi_version", "ttemb_last_error", "ttemb_workspace_bytes", "ttemb_plan_bytes", "ttemb_set_path",
-    "ttemb_profile_enable", "ttemb_profile_read",
+    "ttemb_profile_enable", "ttemb_profile_read", "ttemb_kernel_family", "ttemb_set_piece_limits",
     "ttemb_forward", "ttemb_forward_group", "ttemb_forward_lookup", "ttemb_backward_dense", "ttemb_backward_sgd", "ttemb_backward_adagrad",
     "ttemb_sgd_step", "ttemb_adagrad_step", "ttemb_cache_update", "ttemb_cache_update_one_sweep", "ttemb_cache_populate",
     "ttemb_preprocess", "ttemb_preprocess_update", "ttemb_cache_forward", "ttemb_cache_backward_sgd",
@@ -74,6 +74,8 @@ def _load() -> ctypes.CDLL:
     lib.ttemb_set_path.argtypes = [i32]
     lib.ttemb_profile_enable.argtypes = [i32]
     lib.ttemb_profile_read.argtypes = [i32, ctypes.POINTER(ctypes.c_float)]
+    lib.ttemb_kernel_family.argtypes = [shp, i64, i64, i32]
+    lib.ttemb_set_piece_limits.argtypes = [i64, i64]
     lib.ttemb_plan_bytes.restype = i64
     lib.ttemb_plan_bytes.argtypes = [shp, i64]
     lib.ttemb_forward.argtypes = [shp, vp, vp, vp, vp, i64, vp, i64, vp, vp, i64, vp, i64, vp]
@@ -235,6 +237,26 @@ def plan_bytes(shape: Shape, nnz: int) -> int:
             _check(int(n))
         n = _size_cache[key] = int(n)
     return n
+
+
+FAMILY_SCALAR, FAMILY_PER_BAG, FAMILY_PER_BAG_RT, FAMILY_GROUPED, FAMILY_GROUPED_WIDE, FAMILY_MERGED = 0, 1, 2, 3, 4, 16
+
+
+def kernel_family(shape: Shape, nnz: int, B: int, ids_with_offsets: bool = True) -> int:
+    """Which kernels a lookup of this size would run (``FAMILY_*``, ``| FAMILY_MERGED`` for a 2- / 4-core table on a
+    3-core view) under the current ``set_path``; launches nothing."""
+    rc = LIB.ttemb_kernel_family(ctypes.byref(shape), nnz, B, 1 if ids_with_offsets else 0)
+    if rc < 0:
+        _check(rc)
+    return rc
+
+
+def set_piece_limits(rows: int = 0, ids: int = 0) -> None:
+    """Diagnostic: cut calls into pieces of at most ``rows`` bags / ``ids`` ids (0 = the hardware's limits)."""
+    global path_epoch
+    _check(LIB.ttemb_set_piece_limits(rows, ids))
+    _size_cache.clear()
+    path_epoch += 1
 
 
 def new_plan(shape: Shape, nnz: int, device: torch.device) -> Optional[torch.Tensor]:

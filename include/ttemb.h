@@ -87,6 +87,35 @@ int64_t ttemb_plan_bytes(const ttemb_shape_t* shape, int64_t nnz);
 /* Select the kernel family used by later calls, process-wide (TTEMB_PATH_*). */
 int ttemb_set_path(int32_t path);
 
+/* A call whose [B][D] tensor does not fit one 32-bit window of byte offsets (2^24 rows or 2 GiB: what the grouped kernels
+ * address through buffer descriptors) -- SAGE.inference looks up every node of the graph in one call, gnn_model.py:220-253 --
+ * runs on the grouped path as a sequence of PIECES of the id list (the reference chunks any call by batch_count,
+ * tt_embeddings_cuda.cu:1011-1027).  The boundaries follow `offsets` and are computed on the device: no host
+ * synchronisation.  Needs `offsets`; ttemb_plan_bytes() is 0 for such a call (the backward regroups piece by piece), and
+ * the fused backward entry points write the summed gradient into the workspace and step once.
+ * DIAGNOSTIC, process-wide: smaller limits than the hardware's (rows per piece, ids per piece; 0 = default), so that
+ * tests can cut a small call into many pieces.  Never changes a result. */
+int ttemb_set_piece_limits(int64_t rows, int64_t ids);
+
+/* Which kernels a lookup of `nnz` ids in `B` bags on this table would run, under the current ttemb_set_path: a
+ * DIAGNOSTIC for tests, benchmarks and tuners (tuning_SAGE.py searches ranks in [2, 256]) -- it launches nothing.
+ * `ids_with_offsets` != 0: the ids come with their bag boundaries and no row index (what TTEmbeddingBag.forward passes).
+ *   TTEMB_FAMILY_SCALAR   wave-per-id kernels, plain FMA (any T, any shape)
+ *   TTEMB_FAMILY_PER_BAG  one wavefront per bag, fp32 MFMA per id, an instantiated (q, ranks) shape
+ *   TTEMB_FAMILY_PER_BAG_RT  the same with run-time (q, ranks): any 3-core shape with q0, q2 <= 16 and q0 q1 <= 64
+ *   TTEMB_FAMILY_GROUPED  the grouped chain (ranks <= 32, an instantiated shape)
+ *   TTEMB_FAMILY_GROUPED_WIDE  the grouped chain of ranks 64 / 128 / 256
+ * | TTEMB_FAMILY_MERGED when a 2- or 4-core table rides on a 3-core view (a virtual core built per call). */
+enum {
+  TTEMB_FAMILY_SCALAR = 0,
+  TTEMB_FAMILY_PER_BAG = 1,
+  TTEMB_FAMILY_PER_BAG_RT = 2,
+  TTEMB_FAMILY_GROUPED = 3,
+  TTEMB_FAMILY_GROUPED_WIDE = 4,
+  TTEMB_FAMILY_MERGED = 16
+};
+int ttemb_kernel_family(const ttemb_shape_t* shape, int64_t nnz, int64_t B, int32_t ids_with_offsets);
+
 /* Measurement hook (bench.py's roofline leg).  While enabled (process-wide), the
  * main chain kernel of every ttemb_forward / ttemb_backward_* call is bracketed by
  * hipEvents on the call's stream.  ttemb_profile_read waits for the most recent bracket of

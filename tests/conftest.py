@@ -28,6 +28,7 @@ def _kernel_family_back_to_auto():
     mod = sys.modules.get("ttemb_native")
     if mod is not None:
         mod.set_path(mod.PATH_AUTO)
+        mod.set_piece_limits(0, 0)
 
 
 def pytest_configure(config):

@@ -775,3 +775,142 @@ def test_one_sweep_insert_reproduces_the_reference_after_an_eviction(orc):
         torch.cuda.synchronize()
         assert int((keys == b).sum()) == want_slots
         assert int(freq[keys == b].sum()) == 4
+
+
+@pytest.mark.parametrize("n_ids", [300, 40000])
+def test_fused_probe_pass_equals_update_then_preprocess(orc, n_ids):
+    """ttemb_preprocess_update == ttemb_cache_update followed by ttemb_preprocess(warmup = 0), bit for bit: the table, the
+    counters, the partitioned ids / rows / locations, the TT count and the duplicate flag -- on a populated table whose
+    batch holds cached, tracked-but-evicted, new and repeated ids; and both equal the oracle."""
+    import ttemb_native as nat
+    rng = np.random.default_rng(21)
+    H, C, n_emb = 4096, 600, 100000
+    keys = torch.full((H,), -1, dtype=torch.int64).cuda()
+    freq = torch.zeros(H, dtype=torch.int64).cuda()
+    state = torch.full((H,), -1, dtype=torch.int32).cuda()
+    hot = rng.choice(n_emb, size=1500, replace=False)
+    for _ in range(6):
+        nat.cache_update(torch.tensor(rng.choice(hot, size=2000)).cuda(), keys, freq)
+    # populate by hand (ranks of the C most frequent slots), evicting the rest like mark_popular does
+    f = freq.cpu().numpy()
+    order = np.argsort(-f, kind="stable")
+    st = np.full(H, -1, np.int32)
+    k_np = keys.cpu().numpy().copy()
+    live = order[:C][f[order[:C]] > 0]
+    st[live] = np.arange(live.shape[0], dtype=np.int32)
+    gone = np.setdiff1d(np.flatnonzero(k_np != -1), live)
+    k_np[gone] = -1
+    f[gone] = 0
+    keys, freq, state = torch.tensor(k_np).cuda(), torch.tensor(f).cuda(), torch.tensor(st).cuda()
+    batch = np.concatenate([rng.choice(hot, size=n_ids // 2), rng.integers(0, n_emb, size=n_ids - n_ids // 2)])
+    rng.shuffle(batch)
+    cuts = np.sort(rng.integers(0, n_ids + 1, size=n_ids // 2))   # ragged bags, some of them empty
+    offs = np.concatenate([[0], cuts, [n_ids]]).astype(np.int64)
+    B = offs.shape[0] - 1
+    idx, t_offs = torch.tensor(batch).cuda(), torch.tensor(offs).cuda()
+
+    def run(fused):
+        k, fq = keys.clone(), freq.clone()
+        outs = [torch.empty_like(idx), torch.empty_like(idx), torch.empty(n_ids, dtype=torch.int32).cuda(),
+                torch.full((2,), -7, dtype=torch.int32).cuda()]
+        stamp = torch.empty(C, dtype=torch.int32).cuda().fill_(12345)   # any content
+        if not fused:
+            nat.cache_update(idx, k, fq)
+        nat.preprocess(idx, t_offs, B, False, k, state, outs[0], outs[1], outs[2], outs[3], nat.Workspace(), stamp, 0,
+                       fq if fused else None)
+        torch.cuda.synchronize()
+        return [k.cpu().numpy(), fq.cpu().numpy()] + [o.cpu().numpy() for o in outs]
+
+    two, one = run(False), run(True)
+    ntt = int(two[5][0])
+    assert 0 < ntt < n_ids
+    # ids that are not tracked yet are inserted by concurrent threads: which of two colliding new keys gets a contested slot
+    # is a race in both forms, so the tables are compared as multisets of (key, count) and the outputs exactly
+    for a, b in zip(two[2:], one[2:]):
+        np.testing.assert_array_equal(a, b)
+    tracked = lambda k, fq: sorted(zip(k[k != -1].tolist(), fq[k != -1].tolist()))
+    assert len(tracked(two[0], two[1])) == len(tracked(one[0], one[1]))
+    if n_ids <= 300:
+        assert tracked(two[0], two[1]) == tracked(one[0], one[1])
+    # against the oracle's lookup on the table as it was before the batch (the update never moves a tracked key)
+    is_tt, loc = orc.cache_lookup(batch, k_np, st)
+    assert ntt == int(is_tt.sum())
+    np.testing.assert_array_equal(one[4][ntt:][::-1], loc[~is_tt])
+    assert int(one[5][1]) == int(np.unique(loc[~is_tt]).shape[0] != (~is_tt).sum())
+
+
+def test_cache_live_step_with_and_without_the_fused_probe_pass(ops):
+    """The live-cache training step through the class with update_cache_state + preprocess_indices_sync as ONE probe pass
+    (default) and as the reference's two calls (`lfu_one_sweep_insert`-free module forced onto the two-call route): same
+    rows, same cache rows, same cores, same LFU counters.  Both modules start from one state (a copy of the first one's
+    state dict: two tables filled independently differ by insertion races)."""
+    torch.manual_seed(5)
+    rng = np.random.default_rng(5)
+    p, q, r = [125, 140, 140], [4, 5, 5], [16, 16]
+    n = 2449029
+    mk = lambda: ops.TTEmbeddingBag(n, 100, r, p, q, sparse=True, use_cache=True, cache_size=20000, hashtbl_size=n,
+                                    weight_dist="normal", learning_rate=0.05)
+    a = mk()
+    for ca in a.tt_cores:
+        ca.data.mul_(300.0)
+    hot = rng.choice(n, size=15000, replace=False)
+    for _ in range(3):
+        w = np.concatenate([rng.choice(hot, size=30000), rng.integers(0, n, size=30000)])
+        a(torch.tensor(w).cuda(), torch.arange(w.shape[0] + 1).cuda())
+    a.cache_populate()
+    b = mk()
+    b.load_state_dict(a.state_dict())
+    assert not b.warmup
+    b._fused_probe = lambda: False   # the two-call route
+    for step in range(2):
+        batch = np.concatenate([rng.choice(hot, size=12000, replace=False), rng.integers(0, n, size=60000)])
+        if step == 0:
+            offs = np.arange(batch.shape[0] + 1)
+        else:   # ragged bags: multi-id bags take the atomic path in both the TT and the cache kernels
+            cuts = np.sort(rng.choice(np.arange(1, batch.shape[0]), size=50000, replace=False))
+            offs = np.concatenate([[0], cuts, [batch.shape[0]]])
+        idx, t_offs = torch.tensor(batch).cuda(), torch.tensor(offs).cuda()
+        oa, ob = a(idx, t_offs), b(idx, t_offs)
+        torch.testing.assert_close(oa, ob, rtol=1e-5, atol=1e-6)
+        d = (torch.rand_like(oa) - 0.5) * 0.02
+        oa.backward(d)
+        ob.backward(d)
+        torch.cuda.synchronize()
+        torch.testing.assert_close(a.cache_weight.data, b.cache_weight.data, rtol=1e-5, atol=1e-6)
+        for ca, cb in zip(a.tt_cores, b.tt_cores):
+            torch.testing.assert_close(ca.data, cb.data, rtol=1e-4, atol=1e-6)
+        # counters of the keys both tables track (ids met for the first time race for contested slots in either form)
+        ka, kb = a.hashtbl.cpu().numpy(), b.hashtbl.cpu().numpy()
+        both = (ka == kb) & (ka != -1)
+        assert both.sum() > 0.99 * (ka != -1).sum()
+        np.testing.assert_array_equal(a.cache_freq.cpu().numpy()[both], b.cache_freq.cpu().numpy()[both])
+
+
+def test_capture_guards(ops):
+    """A captured lookup refuses to run once what it baked in no longer holds: a cache gone live, a changed eps, re-allocated
+    cores; during warm-up it keeps the LFU statistics going."""
+    p, q, r = [125, 140, 140], [4, 5, 5], [16, 16]
+    emb = ops.TTEmbeddingBag(2449029, 100, r, p, q, sparse=True, use_cache=True, cache_size=1000, hashtbl_size=50000,
+                             weight_dist="normal", learning_rate=0.1)
+    n = 512
+    cap = emb.capture(n, n)
+    ids = torch.arange(n, dtype=torch.int64).cuda() * 7
+    cap(ids)
+    torch.cuda.synchronize()
+    assert int(emb.cache_freq.sum().item()) == n   # warm-up statistics counted through the captured call
+    emb.eps = 1e-3
+    with pytest.raises(RuntimeError):
+        cap(ids)
+    emb.eps = 1.0e-10
+    cap(ids)
+    emb.tt_cores[1] = torch.nn.Parameter(emb.tt_cores[1].data.clone())
+    assert emb._cores()[1] is emb.tt_cores[1]   # the cached tuple follows a swap of ANY core, not only the first
+    with pytest.raises(RuntimeError):
+        cap(ids)
+    cap2 = emb.capture(n, n)
+    cap2(ids)
+    emb.cache_populate()
+    with pytest.raises(RuntimeError):
+        cap2(ids)
+    with pytest.raises(AssertionError):
+        emb.capture(n, n)

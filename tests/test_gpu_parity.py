@@ -716,3 +716,223 @@ def test_fast_path_with_a_device_side_live_count(nat, orc, live, wide):
         ref = orc.tt_dense_backward(idx[:live], np.arange(live + 1), d_out[:live], cores, p, q, R)
         assert_grads_close([g.cpu().numpy() for g in grads], ref, rel=2e-4)
     assert np.array_equal(outs[0], outs[1])
+
+
+# ---------------------------------------------------------------------------------------
+# run-time (q, ranks): every 3-core shape without an instantiated template runs the per-bag MFMA kernels of
+# ttemb_rt3.inc (2- / 4-core tables through their 3-core view), not the wave-per-id scalar kernels
+# ---------------------------------------------------------------------------------------
+RT_SHAPES = [
+    ([30, 35, 40], [4, 5, 5], [12, 12]),       # the products factorisation at a rank between the instantiated ones
+    ([30, 35, 40], [4, 5, 5], [24, 24]),
+    ([20, 25, 30], [4, 5, 5], [48, 48]),
+    ([30, 35, 40], [2, 5, 10], [16, 16]),      # q shapes no template has
+    ([30, 35, 40], [3, 4, 8], [16, 24]),
+    ([20, 20, 20], [4, 5, 5], [6, 7]),         # ranks that are not multiples of the MFMA K
+    ([12, 15, 10, 11], [2, 4, 4, 4], [12, 12, 12]),   # 4 cores: (G0.G1, G2, G3), merged q = 8,4,4 at rank 12
+    ([90, 120], [8, 16], [12]),                # 2 cores lifted onto three with the identity in the middle
+    ([25, 30, 35], [4, 16, 2], [8, 8]),        # q0 q1 = 64: four row tiles of P
+]
+
+
+def _run_ids_offsets(nat, p, q, R, cores, indices, offsets, d_output):
+    """forward + dense backward the way the module calls them: ids + offsets, no row index"""
+    shape = nat.make_shape(p, q, R)
+    ws = nat.Workspace()
+    c = [dev(x) for x in cores]
+    idx, offs = dev(indices, torch.int64), dev(offsets, torch.int64)
+    B, nnz = offs.numel() - 1, idx.numel()
+    out = torch.full((B, int(np.prod(q))), float("nan"), device="cuda")
+    nat.forward(shape, c, idx, None, offs, nnz, None, B, out, ws)
+    grads = [torch.full_like(x, float("nan")) for x in c]
+    nat.backward_dense(shape, c, idx, None, nnz, None, B, dev(d_output), grads, ws, None, offs)
+    torch.cuda.synchronize()
+    return out.cpu().numpy(), [g.cpu().numpy() for g in grads]
+
+
+@pytest.mark.parametrize("n_ids", [700, 20000])
+@pytest.mark.parametrize("p,q,r", RT_SHAPES)
+def test_runtime_shape_mfma_kernels(nat, orc, p, q, r, n_ids):
+    """Shapes without a template -- ranks 12 / 24 / 48, q = 2,5,10 / 3,4,8, ranks that are not multiples of 4, a 4-core and
+    a 2-core table off the listed shapes -- run the run-time-shape per-bag MFMA kernels at every batch size (the kernel
+    family is asked from the library, not assumed) and match the oracle; ragged bags, duplicates, empty bags."""
+    T = len(p)
+    R = [1] + list(r) + [1]
+    shape = nat.make_shape(p, q, R)
+    rng = np.random.default_rng(sum(p) + sum(q) + sum(r) + n_ids)
+    idx, offsets = _random_bags(rng, int(np.prod(p)), n_ids)
+    fam = nat.kernel_family(shape, int(idx.shape[0]), int(offsets.shape[0] - 1), True)
+    assert fam & ~nat.FAMILY_MERGED == nat.FAMILY_PER_BAG_RT, f"kernel family {fam}"
+    assert bool(fam & nat.FAMILY_MERGED) == (T != 3)
+    assert nat.kernel_family(shape, int(idx.shape[0]), int(offsets.shape[0] - 1), False) == nat.FAMILY_SCALAR   # (a row index, no offsets)
+    cores = [(rng.standard_normal((p[t], R[t] * q[t] * R[t + 1])) * 0.4).astype(np.float32) for t in range(T)]
+    want = orc.tt_forward(idx, offsets, cores, p, q, R)
+    d_out = ((rng.random(want.shape) - 0.5) * 0.2).astype(np.float32)
+    out, grads = _run_ids_offsets(nat, p, q, R, cores, idx, offsets, d_out)
+    np.testing.assert_allclose(out, want, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(want).max())))
+    assert_grads_close(grads, orc.tt_dense_backward(idx, offsets, d_out, cores, p, q, R), rel=2e-4)
+    # the scalar kernels (forced) agree: same rows, same gradients
+    nat.set_path(nat.PATH_GENERIC)
+    assert nat.kernel_family(shape, int(idx.shape[0]), int(offsets.shape[0] - 1), True) == nat.FAMILY_SCALAR
+    out_s, grads_s = _run_ids_offsets(nat, p, q, R, cores, idx, offsets, d_out)
+    nat.set_path(nat.PATH_AUTO)
+    np.testing.assert_allclose(out, out_s, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(want).max())))
+    assert_grads_close(grads, grads_s, rel=2e-4)
+
+
+def test_runtime_shape_module_trains(orc):
+    """The drop-in class on a rank-12 table (fused SGD in backward) against the oracle's closed form."""
+    import FBTT.tt_embeddings_ops as ops
+    torch.manual_seed(3)
+    p, q, r = [30, 35, 40], [4, 5, 5], [12, 12]
+    n, lr = int(np.prod(p)), 0.1
+    emb = ops.TTEmbeddingBag(n, 100, r, p, q, sparse=True, use_cache=False, weight_dist="normal", learning_rate=lr)
+    for c in emb.tt_cores:
+        c.data.mul_(60.0)
+    cores = [c.detach()[0].cpu().numpy().copy() for c in emb.tt_cores]
+    rng = np.random.default_rng(3)
+    ids = rng.integers(0, n, size=5000).astype(np.int64)
+    offs = np.arange(5001, dtype=np.int64)
+    out = emb(torch.tensor(ids).cuda(), torch.tensor(offs).cuda())
+    R = [1] + r + [1]
+    np.testing.assert_allclose(out.detach().cpu().numpy(), orc.tt_forward(ids, offs, cores, p, q, R), rtol=1e-4, atol=1e-4)
+    d_out = ((rng.random((5000, 100)) - 0.5) * 0.1).astype(np.float32)
+    out.backward(torch.tensor(d_out).cuda())
+    g = orc.tt_dense_backward(ids, offs, d_out, cores, p, q, R)
+    for c, c0, gr in zip(emb.tt_cores, cores, g):
+        np.testing.assert_allclose(c.detach()[0].cpu().numpy(), c0 - np.float32(lr) * gr, rtol=0,
+                                   atol=1e-5 + 2e-4 * float(np.abs(lr * gr).max()))
+
+
+# ---------------------------------------------------------------------------------------
+# calls past one 32-bit row window: the grouped path in pieces (reference: batch_count chunks, tt_embeddings_cuda.cu:1011-1027)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,ids", [(900, 0), (0, 700), (1500, 1100), (64, 4000)])
+@pytest.mark.parametrize("q,r", [([4, 5, 5], [16, 16]), ([8, 4, 4], [32, 32]), ([5, 5, 4], [64, 64])])
+def test_small_call_cut_into_pieces(nat, orc, q, r, rows, ids):
+    """The piece machinery on a small ragged call, cut by the diagnostic limits: by rows, by ids, by both, and with a row
+    window so small that runs of empty bags and multi-id bags straddle the cuts.  Forward rows, dense gradient, fused SGD
+    against the oracle; same results as the uncut call.  Fused dG2 (rank 16), E table (rank 32) and wide-rank (64) chains."""
+    p = [30, 35, 40]
+    R = [1] + r + [1]
+    D = int(np.prod(q))
+    rng = np.random.default_rng(rows + ids + r[0])
+    # ragged bags with long runs of empty bags and a few long bags
+    lens = rng.integers(0, 3, size=9000)
+    lens[rng.integers(0, 9000, size=40)] = 25
+    lens[2000:2300] = 0
+    lens[5000:5100] = 0
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    nnz = int(offsets[-1])
+    idx = rng.integers(0, int(np.prod(p)), size=nnz).astype(np.int64)
+    idx[: nnz // 8] = idx[nnz // 8: 2 * (nnz // 8)]
+    cores = [(rng.standard_normal((p[t], R[t] * q[t] * R[t + 1])) * 0.3).astype(np.float32) for t in range(3)]
+    want = orc.tt_forward(idx, offsets, cores, p, q, R)
+    d_out = ((rng.random(want.shape) - 0.5) * 0.2).astype(np.float32)
+    want_g = orc.tt_dense_backward(idx, offsets, d_out, cores, p, q, R)
+    nat.set_path(nat.PATH_FAST3)
+    shape = nat.make_shape(p, q, R)
+    assert nat.plan_bytes(shape, nnz) > 0
+    nat.set_piece_limits(rows, ids)
+    if ids:
+        assert nat.plan_bytes(shape, nnz) == 0   # a call in pieces keeps no plan
+    out, grads = _run_ids_offsets(nat, p, q, R, cores, idx, offsets, d_out)
+    np.testing.assert_allclose(out, want, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(want).max())))
+    assert_grads_close(grads, want_g, rel=2e-4)
+    # fused SGD through the C ABI: summed gradient, one step
+    ws = nat.Workspace()
+    c = [dev(x) for x in cores]
+    t_idx, t_offs = dev(idx, torch.int64), dev(offsets, torch.int64)
+    nat.backward_sgd(shape, c, t_idx, None, nnz, None, offsets.shape[0] - 1, dev(d_out), 0.05, ws, None, t_offs)
+    torch.cuda.synchronize()
+    for t in range(3):
+        np.testing.assert_allclose(c[t].cpu().numpy(), cores[t] - np.float32(0.05) * want_g[t], rtol=0,
+                                   atol=1e-5 + 2e-4 * float(np.abs(0.05 * want_g[t]).max()))
+    nat.set_piece_limits(0, 0)
+    nat.set_path(nat.PATH_AUTO)
+
+
+def test_call_past_2_24_rows_stays_on_the_grouped_path(nat, orc):
+    """B = 2^24 + 4096 bags of one id on the arxiv shape (an 8.6 GB output: past 2^24 rows AND past 2 GiB): the call runs
+    on the grouped kernels in pieces.  Spot rows against the oracle (first / last rows, rows around the cuts), the
+    permutation property on the whole tensor, and the dense gradient of a sparse d_output against the oracle's."""
+    p, q, r, n_emb = [56, 60, 51], [4, 4, 8], [8, 8], 169343
+    R, D = [1] + r + [1], 128
+    B = (1 << 24) + 4096
+    shape = nat.make_shape(p, q, R)
+    assert nat.kernel_family(shape, B, B, True) == nat.FAMILY_GROUPED
+    assert nat.kernel_family(shape, B, B, False) != nat.FAMILY_GROUPED   # (no bag boundaries: no pieces)
+    assert nat.plan_bytes(shape, B) == 0
+    rng = np.random.default_rng(24)
+    cores = [(rng.standard_normal((p[t], R[t] * q[t] * R[t + 1])) * 0.3).astype(np.float32) for t in range(3)]
+    c = [dev(x) for x in cores]
+    g = torch.Generator(device="cuda").manual_seed(24)
+    idx = torch.randint(0, n_emb, (B,), generator=g, device="cuda", dtype=torch.int64)
+    offs = torch.arange(B + 1, dtype=torch.int64, device="cuda")
+    ws = nat.Workspace()
+    out = torch.empty((B, D), device="cuda")
+    out.fill_(float("nan"))
+    nat.forward(shape, c, idx, None, offs, B, None, B, out, ws)
+    torch.cuda.synchronize()
+    rows_per_piece = (2 ** 31 - 1) // (4 * D)   # 4 194 303: the 2 GiB window decides at D = 128
+    spots = np.unique(np.concatenate([np.arange(64), np.arange(B - 64, B), rng.integers(0, B, size=3000)] +
+                                     [np.arange(k * rows_per_piece - 40, k * rows_per_piece + 40) for k in range(1, 5)] +
+                                     [np.arange((1 << 24) - 40, (1 << 24) + 40)]))
+    spots = spots[(spots >= 0) & (spots < B)]
+    t_sp = torch.tensor(spots, device="cuda")
+    got = out[t_sp].cpu().numpy()
+    want = orc.tt_rows(idx[t_sp].cpu().numpy(), cores, p, q, R)
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4)
+    assert not bool(torch.isnan(out[::997]).any())
+    # permutation property: looking the ids up in another order permutes the rows (checked on every row, block by block)
+    perm = torch.randperm(B, generator=g, device="cuda")
+    out2 = torch.empty_like(out)
+    nat.forward(shape, c, idx[perm].contiguous(), None, offs, B, None, B, out2, ws)
+    torch.cuda.synchronize()
+    for b0 in range(0, B, 1 << 22):
+        sl = slice(b0, min(B, b0 + (1 << 22)))
+        assert torch.equal(out2[sl], out[perm[sl]])
+    del out2
+    # dense backward of a d_output with 40 000 non-zero rows (the other rows contribute exact zeros): the oracle's gradient
+    # of those rows alone is the whole gradient
+    hot = np.unique(np.concatenate([rng.integers(0, B, size=40000), spots[:200]]))
+    d_out = out   # reuse the 8.6 GB buffer
+    d_out.zero_()
+    vals = ((rng.random((hot.shape[0], D)) - 0.5) * 0.2).astype(np.float32)
+    d_out[torch.tensor(hot, device="cuda")] = torch.tensor(vals, device="cuda")
+    grads = [torch.full_like(x, float("nan")) for x in c]
+    nat.backward_dense(shape, c, idx, None, B, None, B, d_out, grads, ws, None, offs)
+    torch.cuda.synchronize()
+    hot_ids = idx[torch.tensor(hot, device="cuda")].cpu().numpy()
+    want_g = orc.tt_dense_backward(hot_ids, np.arange(hot.shape[0] + 1, dtype=np.int64), vals, cores, p, q, R)
+    assert_grads_close([x.cpu().numpy() for x in grads], want_g, rel=2e-4)
+
+
+def test_fused_backward_at_the_full_409600_ids_against_the_oracle(nat, orc):
+    """BASELINE.json configs[1] at its full size -- 409 600 unique uniform ids on the products table, bag length 1 -- through
+    the fused chunk kernel: the dense gradient against the oracle's, which takes the batch in eight sub-batches and sums
+    (a gradient is additive over ids), and the fused SGD step against the closed form on the same sum."""
+    p, q, R, n_emb = CONFIGS["products"]
+    n = 409600
+    rng = np.random.default_rng(409600)
+    cores = [(rng.standard_normal((p[t], R[t] * q[t] * R[t + 1])) * 0.3).astype(np.float32) for t in range(3)]
+    idx = rng.choice(n_emb, size=n, replace=False).astype(np.int64)
+    offsets = np.arange(n + 1, dtype=np.int64)
+    d_out = ((rng.random((n, int(np.prod(q)))) - 0.5) * 0.1).astype(np.float32)
+    shape = nat.make_shape(p, q, R)
+    assert nat.kernel_family(shape, n, n, True) == nat.FAMILY_GROUPED
+    want = [np.zeros_like(c, dtype=np.float64) for c in cores]
+    for k in range(8):
+        sl = slice(k * n // 8, (k + 1) * n // 8)
+        part = orc.tt_dense_backward(idx[sl], np.arange(sl.stop - sl.start + 1, dtype=np.int64), d_out[sl], cores, p, q, R)
+        for t in range(3):
+            want[t] += part[t]
+    want = [w.astype(np.float32) for w in want]
+    _, grads = _run_ids_offsets(nat, p, q, R, cores, idx, offsets, d_out)
+    assert_grads_close(grads, want, rel=2e-4)
+    c = [dev(x) for x in cores]
+    nat.backward_sgd(shape, c, dev(idx, torch.int64), None, n, None, n, dev(d_out), 0.05, nat.Workspace(), None, dev(offsets, torch.int64))
+    torch.cuda.synchronize()
+    for t in range(3):
+        np.testing.assert_allclose(c[t].cpu().numpy(), cores[t] - np.float32(0.05) * want[t], rtol=0,
+                                   atol=1e-5 + 2e-4 * float(np.abs(0.05 * want[t]).max()))

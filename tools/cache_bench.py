@@ -61,6 +61,8 @@ def main():
         cached = torch.isin(b, slot_keys[emb.cache_state >= 0])
         hits.append(float(cached.float().mean()))
     print(f"cache live       : {timed(emb, test, d_out, offs):.3f} ms/step, hit rate {np.mean(hits) * 100:.1f} %", flush=True)
+    emb._fused_probe = lambda: False
+    print(f"cache live, update + preprocess as two calls: {timed(emb, test, d_out, offs):.3f} ms/step", flush=True)
 
 
 if __name__ == "__main__":

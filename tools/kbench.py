@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--path", default="auto")
     ap.add_argument("--what", default="both", choices=["both", "fwd", "bwd"])
     ap.add_argument("--no-rowidx", action="store_true", help="ids + offsets only, as the module passes them (the per-bag kernels need this form)")
+    ap.add_argument("--split", action="store_true", help="two-phase forward (ttemb_forward_group, then ttemb_forward_lookup): the grouping steps and the prefix products as launches of their own")
     a = ap.parse_args()
     p, q, R, n_emb = CFG[a.cfg]
     D = int(np.prod(q))
@@ -74,7 +75,12 @@ def main():
         f, b, c, g = [], [], [], []
         for i in range(a.iters + 3):
             if a.what in ("both", "fwd"):
-                nat.forward(shape, cores, idx, rowidx, offs, N, None, N, out, ws)
+                if a.split:
+                    plan = nat.new_plan(shape, N, idx.device)
+                    nat.forward(shape, cores, idx, rowidx, offs, N, None, N, out, ws, plan, phase=1)
+                    nat.forward(shape, cores, idx, rowidx, offs, N, None, N, out, ws, plan, phase=2)
+                else:
+                    nat.forward(shape, cores, idx, rowidx, offs, N, None, N, out, ws)
                 if i >= 3:
                     f.append(nat.profile_read(0))
                     g.append(nat.profile_read(3))
