@@ -234,7 +234,7 @@ def main():
         achieved = N * row_bytes / (dom_ms * 1e-3) / 1e9
         # HBM bytes per launch of that kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read from
         # inside the process): NOT measured by this run -- the files are named in the line -- valid for the default workload
-        traffic_src, busy_src = "profiles/r02_traffic.json", "profiles/r02_mfma_util.json"
+        traffic_src, busy_src = "profiles/r03_traffic.json", "profiles/r03_mfma_util.json"
         traffic = None
         try:
             if N == 409600 and args.path == "auto":

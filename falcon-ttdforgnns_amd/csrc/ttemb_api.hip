@@ -529,10 +529,10 @@ static int resolve_rowidx(const int64_t** rowidx, const int64_t* offsets, int64_
 static int backward_into(const DevShape& ds, const CorePtrs& cp, const int64_t* indices,
                          const int64_t* rowidx, const int64_t* offsets, int64_t nnz, const int32_t* nnz_dev, int64_t B,
                          const float* d_output, const CorePtrsMut& dst, void* ws, int64_t ws_bytes,
-                         const void* plan, int64_t plan_bytes, hipStream_t st, const FusedUpdate* update = nullptr) {
+                         const void* plan, int64_t plan_bytes, hipStream_t st, void* header, const FusedUpdate* update = nullptr) {
   if (use_fast3(ds, nnz, B, offsets != nullptr))
     return launch_backward_fast3(ds, cp, indices, rowidx, offsets, nnz, nnz_dev, B, d_output, dst, ws, ws_bytes, plan,
-                                 plan_bytes, st, update);
+                                 plan_bytes, st, update, header);
   const Merged4 m4 = merge_first_two(ds, nnz, B, rowidx == nullptr && offsets != nullptr, offsets != nullptr);
   if (m4.on) {   // 4 cores: the 3-core backward on (V, G2, G3), then dV back onto G0 and G1
     if (ws == nullptr || ws_bytes < 2 * m4.v_bytes) return fail(TTEMB_E_WORKSPACE, "backward needs room for the merged core");
@@ -553,7 +553,7 @@ static int backward_into(const DevShape& ds, const CorePtrs& cp, const int64_t* 
       if (rc == TTEMB_OK) rc = launch_backward_small3(m4.s3, c3, indices, offsets, nnz, nnz_dev, B, d_output, d3, st);
     } else {
       rc = launch_backward_fast3(m4.s3, c3, indices, rowidx, offsets, nnz, nnz_dev, B, d_output, d3,
-                                 reinterpret_cast<char*>(ws) + 2 * m4.v_bytes, ws_bytes - 2 * m4.v_bytes, plan, plan_bytes, st, nullptr);
+                                 reinterpret_cast<char*>(ws) + 2 * m4.v_bytes, ws_bytes - 2 * m4.v_bytes, plan, plan_bytes, st, nullptr, header);
     }
     if (rc || m4.a < 0) return rc;
     hipLaunchKernelGGL(split_pair_kernel, dim3((unsigned)(m4.pa + m4.pb), (unsigned)m4.K), dim3(256), 0, st, cp.c[m4.a], cp.c[m4.a + 1], dV, m4.pa,
@@ -604,23 +604,26 @@ int ttemb_profile_read(int32_t which, float* ms_host) {
 
 int64_t ttemb_workspace_bytes(const ttemb_shape_t* shape, int32_t op, int64_t nnz, int64_t B) {
   if (nnz < 0 || B < 0) return fail(TTEMB_E_BADARG, "negative size");
-  if (op == TTEMB_OP_PREPROCESS) return preprocess_workspace_bytes(nnz);
+  // EVERY op leaves the first kFast3HeaderBytes of its workspace alone: the grouped lookup keeps its few persistent words
+  // there, and callers reuse one workspace for all ops
+  if (op == TTEMB_OP_PREPROCESS) return kFast3HeaderBytes + preprocess_workspace_bytes(nnz);
   DevShape ds;
   int rc = make_dev_shape(shape, &ds);
   if (rc) return rc;
   const bool f3 = use_fast3(ds, op == TTEMB_OP_CACHE_POPULATE ? B : nnz, B);
   const Merged4 m4 = op == TTEMB_OP_CACHE_POPULATE ? Merged4{} : merge_first_two(ds, nnz, B, true);
+  // every lookup op's workspace begins with the header the grouped path keeps its few persistent words in
   switch (op) {
     case TTEMB_OP_FORWARD:
-      if (m4.on) return align256(nnz * 8) + m4.v_bytes + (m4.per_bag ? 0 : fast3_workspace_bytes(m4.s3, op, nnz, B));
-      return align256(nnz * 8) + (f3 ? fast3_workspace_bytes(ds, op, nnz, B) : 0);
+      if (m4.on) return kFast3HeaderBytes + align256(nnz * 8) + m4.v_bytes + (m4.per_bag ? 0 : fast3_workspace_bytes(m4.s3, op, nnz, B));
+      return kFast3HeaderBytes + align256(nnz * 8) + (f3 ? fast3_workspace_bytes(ds, op, nnz, B) : 0);
     case TTEMB_OP_BACKWARD:
-      if (m4.on) return grad_scratch_bytes(ds) + align256(nnz * 8) + 2 * m4.v_bytes + (m4.per_bag ? 0 : fast3_workspace_bytes(m4.s3, op, nnz, B));
-      return grad_scratch_bytes(ds) + align256(nnz * 8) + (f3 ? fast3_workspace_bytes(ds, op, nnz, B) : 0);
+      if (m4.on) return kFast3HeaderBytes + grad_scratch_bytes(ds) + align256(nnz * 8) + 2 * m4.v_bytes + (m4.per_bag ? 0 : fast3_workspace_bytes(m4.s3, op, nnz, B));
+      return kFast3HeaderBytes + grad_scratch_bytes(ds) + align256(nnz * 8) + (f3 ? fast3_workspace_bytes(ds, op, nnz, B) : 0);
     case TTEMB_OP_CACHE_POPULATE: {
       const int64_t sort = populate_workspace_bytes(nnz);
       if (sort < 0) return fail(TTEMB_E_HIP, "rocprim size query failed");
-      return sort + (f3 ? fast3_workspace_bytes(ds, TTEMB_OP_FORWARD, B, B) : 0);
+      return kFast3HeaderBytes + sort + (f3 ? fast3_workspace_bytes(ds, TTEMB_OP_FORWARD, B, B) : 0);
     }
     default:
       return fail(TTEMB_E_BADARG, "unknown op %d", op);
@@ -676,6 +679,12 @@ static int forward_phase(int phase, const ttemb_shape_t* shape, const float* con
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   CorePtrs cp;
   for (int t = 0; t < TTEMB_MAX_CORES; ++t) cp.c[t] = t < ds.T ? cores[t] : nullptr;
+  void* header = nullptr;   // the grouped path's persistent words: the first kFast3HeaderBytes of every lookup workspace
+  if (workspace != nullptr && workspace_bytes >= kFast3HeaderBytes) {
+    header = workspace;
+    workspace = reinterpret_cast<char*>(workspace) + kFast3HeaderBytes;
+    workspace_bytes -= kFast3HeaderBytes;
+  }
   const Merged4 m4 = nnz > 0 ? merge_first_two(ds, nnz, B, rowidx == nullptr && offsets != nullptr, offsets != nullptr) : Merged4{};
   if (m4.on && m4.per_bag && phase == 1) return TTEMB_OK;   // the per-bag kernels have no id-only half
   if (m4.on) {   // 4 cores through the 3-core kernels on (V = G0.G1, G2, G3); workspace: [row slot | V | 3-core]
@@ -697,13 +706,13 @@ static int forward_phase(int phase, const ttemb_shape_t* shape, const float* con
       if (rc) return rc;
     }
     return launch_forward_fast3(m4.s3, c3, indices, rowidx, offsets, nnz, nnz_dev, B, output, offsets != nullptr,
-                                w4 + head + m4.v_bytes, workspace_bytes - head - m4.v_bytes, plan, plan_bytes, phase, st);
+                                w4 + head + m4.v_bytes, workspace_bytes - head - m4.v_bytes, plan, plan_bytes, phase, st, header);
   }
   const bool f3 = nnz > 0 && use_fast3(ds, nnz, B, offsets != nullptr);
   if (phase == 1 && !f3) return TTEMB_OK;   // the generic kernels have no id-only half: phase 2 is their whole forward
   if (phase == 2 && f3) {
     return launch_forward_fast3(ds, cp, indices, rowidx, offsets, nnz, nnz_dev, B, output, offsets != nullptr, workspace,
-                                workspace_bytes, plan, plan_bytes, 2, reinterpret_cast<hipStream_t>(stream));
+                                workspace_bytes, plan, plan_bytes, 2, reinterpret_cast<hipStream_t>(stream), header);
   }
   if (rowidx == nullptr && offsets == nullptr && nnz > 0) return fail(TTEMB_E_BADARG, "rowidx and offsets are both null");
   if (!f3 && use_small3(ds, nnz, B, rowidx, offsets))   // one launch: every output row written once, zeros for an empty bag
@@ -725,7 +734,7 @@ static int forward_phase(int phase, const ttemb_shape_t* shape, const float* con
   if (rc || nnz == 0) return rc;
   if (f3)
     return launch_forward_fast3(ds, cp, indices, rowidx, offsets, nnz, nnz_dev, B, output, offsets != nullptr, workspace,
-                                workspace_bytes, plan, plan_bytes, phase, st);
+                                workspace_bytes, plan, plan_bytes, phase, st, header);
   if (current_path() == TTEMB_PATH_FAST3) return fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
   return launch_forward_generic(ds, cp, indices, rowidx, offsets, B, nnz, nnz_dev, output, st);
 }
@@ -775,14 +784,20 @@ int ttemb_backward_dense(const ttemb_shape_t* shape, const float* const* cores,
     cp.c[t] = t < ds.T ? cores[t] : nullptr;
     dp.c[t] = t < ds.T ? d_cores[t] : nullptr;
   }
-  // the gradient scratch region at the head of the workspace is unused in dense mode
+  void* header = nullptr;   // the grouped path's persistent words: the first kFast3HeaderBytes of every lookup workspace
+  if (workspace != nullptr && workspace_bytes >= kFast3HeaderBytes) {
+    header = workspace;
+    workspace = reinterpret_cast<char*>(workspace) + kFast3HeaderBytes;
+    workspace_bytes -= kFast3HeaderBytes;
+  }
+  // the gradient scratch region behind the header is unused in dense mode
   const int64_t skip = grad_scratch_bytes(ds);
   char* ws = reinterpret_cast<char*>(workspace);
   int64_t rest = workspace_bytes > skip ? workspace_bytes - skip : 0;
   ws = ws ? ws + skip : nullptr;
   rc = resolve_rowidx(&rowidx, offsets, nnz, B, &ws, &rest, st, use_fast3(ds, nnz, B, offsets != nullptr));
   if (rc) return rc;
-  return backward_into(ds, cp, indices, rowidx, offsets, nnz, nnz_dev, B, d_output, dp, ws, rest, plan, plan_bytes, st);
+  return backward_into(ds, cp, indices, rowidx, offsets, nnz, nnz_dev, B, d_output, dp, ws, rest, plan, plan_bytes, st, header);
 }
 
 static int fused_backward(const ttemb_shape_t* shape, float* const* cores, float* const* opt_state,
@@ -797,9 +812,12 @@ static int fused_backward(const ttemb_shape_t* shape, float* const* cores, float
   if (rc) return rc;
   if (nnz == 0) return TTEMB_OK;  // zero gradient: SGD is a no-op, Adagrad adds 0 and divides 0
   if (d_output == nullptr) return fail(TTEMB_E_BADARG, "d_output is null");
-  const int64_t need = grad_scratch_bytes(ds);
+  const int64_t need = kFast3HeaderBytes + grad_scratch_bytes(ds);
   if (workspace == nullptr || workspace_bytes < need)
     return fail(TTEMB_E_WORKSPACE, "backward needs %lld workspace bytes, got %lld", (long long)need, (long long)workspace_bytes);
+  void* header = workspace;   // the grouped path's persistent words: the first kFast3HeaderBytes of every lookup workspace
+  workspace = reinterpret_cast<char*>(workspace) + kFast3HeaderBytes;
+  workspace_bytes -= kFast3HeaderBytes;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   CorePtrs cp;
   CorePtrsMut gp;
@@ -832,7 +850,7 @@ static int fused_backward(const ttemb_shape_t* shape, float* const* cores, float
   upd.eps = eps;
   // the grouped path applies the step inside its last kernel; the generic path writes gradients, then steps
   rc = backward_into(ds, cp, indices, rowidx, offsets, nnz, nnz_dev, B, d_output, gp, rest_ws, rest, plan, plan_bytes, st,
-                     f3 ? &upd : nullptr);
+                     header, f3 ? &upd : nullptr);
   if (rc || f3) return rc;
   Seg3 seg;
   memset(&seg, 0, sizeof(seg));
@@ -914,6 +932,9 @@ int ttemb_cache_populate(const ttemb_shape_t* shape, const float* const* cores, 
     return fail(TTEMB_E_BADARG, "null buffer");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   int64_t* sorted_keys = nullptr;
+  if (workspace_bytes < kFast3HeaderBytes) return fail(TTEMB_E_WORKSPACE, "cache_populate: workspace smaller than its header");
+  workspace = reinterpret_cast<char*>(workspace) + kFast3HeaderBytes;   // (the lookups' persistent words)
+  workspace_bytes -= kFast3HeaderBytes;
   rc = launch_cache_populate_rank(hashtbl, cache_freq, cache_state, H, C, workspace, workspace_bytes,
                                   &sorted_keys, st);
   if (rc || C == 0) return rc;
@@ -946,8 +967,10 @@ static int preprocess_impl(const int64_t* indices, const int64_t* offsets, int64
   if (!hashtbl || !cache_state || !indices_out || !cache_loc_out || !nnz_tt_dev || !workspace)
     return fail(TTEMB_E_BADARG, "null buffer");
   if (indices_out == indices) return fail(TTEMB_E_BADARG, "partition cannot run in place");
+  if (workspace_bytes < kFast3HeaderBytes) return fail(TTEMB_E_WORKSPACE, "preprocess: workspace smaller than its header");
   return launch_partition(indices, offsets, nnz, B, hashtbl, cache_freq, cache_state, H, indices_out, rowidx_out,
-                          cache_loc_out, nnz_tt_dev, dup_stamp, workspace, workspace_bytes, st);
+                          cache_loc_out, nnz_tt_dev, dup_stamp, reinterpret_cast<char*>(workspace) + kFast3HeaderBytes,
+                          workspace_bytes - kFast3HeaderBytes, st);
 }
 
 int ttemb_preprocess(const int64_t* indices, const int64_t* offsets, int64_t nnz, int64_t B,

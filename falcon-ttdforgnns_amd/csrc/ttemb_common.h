@@ -79,7 +79,10 @@ int64_t fast3_plan_bytes(const DevShape& s, int64_t nnz);
 int launch_forward_fast3(const DevShape& s, const CorePtrs& cores, const int64_t* indices,
                          const int64_t* rowidx, const int64_t* offsets, int64_t nnz,
                          const int32_t* nnz_dev, int64_t B, float* output, bool zero_rows, void* ws,
-                         int64_t ws_bytes, void* plan, int64_t plan_bytes, int phase, hipStream_t st);
+                         int64_t ws_bytes, void* plan, int64_t plan_bytes, int phase, hipStream_t st, void* header);
+// `header`: kFast3HeaderBytes at the start of the caller's workspace, the same address for every op on that workspace: the
+// words of the grouping pass that outlive a call (its epoch, the pre-tagged range counters).  Any content is valid.
+constexpr int64_t kFast3HeaderBytes = 8192;
 // optimiser step folded into the last backward kernel (w == nullptr: none, gradients are written instead)
 struct FusedUpdate {
   float* w[TTEMB_MAX_CORES];
@@ -90,7 +93,7 @@ int launch_backward_fast3(const DevShape& s, const CorePtrs& cores, const int64_
                           const int64_t* rowidx, const int64_t* offsets, int64_t nnz, const int32_t* nnz_dev,
                           int64_t B, const float* d_output, const CorePtrsMut& d_cores, void* ws,
                           int64_t ws_bytes, const void* plan, int64_t plan_bytes, hipStream_t st,
-                          const FusedUpdate* update = nullptr);
+                          const FusedUpdate* update, void* header);
 
 // small batches of a 3-core table (ttemb_small3.inc): one wavefront per bag, MFMA per id, no grouping; `offsets` required.
 // The backward ADDS into d_cores (zeroed by the caller) with float atomics.

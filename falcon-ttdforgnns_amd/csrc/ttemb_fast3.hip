@@ -163,7 +163,9 @@ constexpr int kMaxSlices = 1024;
 constexpr int kMaxRanges = 512;               // ranges of the group space (a power-of-two number of groups each)
 constexpr int kSortBatch = 8;                 // ids per thread whose loads are in flight together
 constexpr uint32_t kFirstBit = 0x100u, kLastBit = 0x200u;   // flags next to a chunk's length
-constexpr uint64_t kEpochMask38 = (1ull << 38) - 1ull;      // epoch tag of the range counters: 38 bits above a 26-bit id count
+// Epoch tag of a range counter: 38 bits above a 26-bit id count, the top bit always SET -- whatever a word held before
+// (zeros, all-ones cache locations, floats), adding a count to it cannot produce a valid tag by carry.
+__host__ __device__ __forceinline__ uint64_t counter_tag(uint64_t epoch) { return ((epoch & ((1ull << 37) - 1ull)) | (1ull << 37)) << 26; }
 constexpr uint32_t kNoGroup = 0xffffffffu;
 
 // A call whose output (or d_output) tensor does not fit one 32-bit window of byte offsets -- 2^24 rows or 2 GiB, what the
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(kSortThreads) void fast3_decode_kernel(
   // memory, a layout that moved -- is taken over instead: look, then compare-and-swap to (tag | own count) or, once the
   // tag is there, add.  (The blind add that found the wrong tag changed a word that held nothing of value; the tag cannot
   // change back during the launch, so an add after a matching look is safe, and a lost swap just looks again.)
-  const uint64_t tag = ((plan.epochs[0] + 1ull) & kEpochMask38) << 26;
+  const uint64_t tag = counter_tag(plan.epochs[0] + 1ull);
   uint32_t* dst = plan.shist + (size_t)blockIdx.x * ranges;
   for (uint32_t i = threadIdx.x; i < ranges; i += kSortThreads) {
     unsigned long long* ctr = reinterpret_cast<unsigned long long*>(&plan.rcount[i]);
@@ -441,7 +443,7 @@ __device__ __forceinline__ void place_range(const uint32_t range, const uint32_t
   uint32_t* gcount = gfirst + span;
   uint32_t* gchunk = gcount + span;
   constexpr int NWV = kRangeThreads / kWave;
-  const uint64_t epoch = plan.epochs[1] & kEpochMask;
+  const uint64_t epoch = (plan.epochs[1] & (kEpochMask >> 1)) | (1ull << 39);   // (top bit set: zeros / all-ones never match)
   const uint32_t n0 = plan.rstart[range], n1 = plan.rstart[range + 1];
   for (uint32_t i = threadIdx.x; i < span; i += kRangeThreads) gcount[i] = 0u;
   __syncthreads();
@@ -505,7 +507,7 @@ __device__ __forceinline__ void place_range(const uint32_t range, const uint32_t
   if (threadIdx.x < range) {
     const bool want_live = range == ranges - 1;
     uint64_t v = 0, w = epoch << 24;
-    for (uint32_t spin = 0; spin < (1u << 20); ++spin) {
+    for (uint32_t spin = 0; spin < (1u << 16); ++spin) {
       v = __hip_atomic_load(&plan.rpub[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (want_live) w = __hip_atomic_load(&plan.rpub[ranges + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if ((v >> 24) == epoch && (w >> 24) == epoch) break;
@@ -554,7 +556,7 @@ __device__ __forceinline__ void place_range(const uint32_t range, const uint32_t
     if (range == 0) plan.epochs[0] = plan.epochs[1];   // the call is counted (nobody reads this word during this launch)
     // this range's id counter, read for the last time by the spread step: left at (the NEXT call's tag | 0), so that
     // the next decode step's first add already counts
-    plan.rcount[range] = ((plan.epochs[1] + 1ull) & kEpochMask38) << 26;
+    plan.rcount[range] = counter_tag(plan.epochs[1] + 1ull);
   }
 }
 
@@ -2315,10 +2317,8 @@ static int64_t carve_workspace(const DevShape& s, int64_t nnz, bool bwd, bool pl
     uint32_t* in[6];
     for (int i = 0; i < 6; ++i) in[i] = (uint32_t*)take(nnz * 4);
     uint32_t* sh = (uint32_t*)take((int64_t)sort_slices(nnz) * sort_ranges(G) * 4);
-    uint64_t* rc = (uint64_t*)take(sort_ranges(G) * 8);
     uint32_t* rs = (uint32_t*)take((sort_ranges(G) + 1) * 4);
     uint32_t* gs = (uint32_t*)take(G * 4);
-    uint64_t* ep = (uint64_t*)take(16);
     uint64_t* rp = (uint64_t*)take(sort_ranges(G) * 16);
     if (pl) {
       pl->grp_in = in[0];
@@ -2328,10 +2328,8 @@ static int64_t carve_workspace(const DevShape& s, int64_t nnz, bool bwd, bool pl
       pl->i2_mid = in[4];
       pl->vals_mid = in[5];
       pl->shist = sh;
-      pl->rcount = rc;
       pl->rstart = rs;
       pl->gstamp = gs;
-      pl->epochs = ep;
       pl->rpub = rp;
     }
   }
@@ -2411,9 +2409,15 @@ static int group_ids(const DevShape& s, const CorePtrs& cores, const int64_t* in
 static int prepare(const DevShape& s, const CorePtrs& cores, bool bwd, const int64_t* indices, const int64_t* rowidx,
                    const int64_t* offsets, int64_t nnz, const int32_t* nnz_dev, int64_t B, float* zero_out, void* ws,
                    int64_t ws_bytes, void* plan_buf, int64_t plan_bytes, int plan_state, GroupPlan* plan, hipStream_t st,
-                   const Piece* piece = nullptr) {
+                   void* header, const Piece* piece = nullptr) {
   memset(plan, 0, sizeof(*plan));
   plan->piece = piece;
+  // the words that outlive a call -- the grouping pass's epoch and its pre-tagged range counters -- sit in the header of
+  // the caller's workspace (kFast3HeaderBytes, at the same address for every op on that workspace): tables carved per call
+  // would be overwritten by the next call's other tables (the backward's gradients land where the forward grouped)
+  if (plan_state <= 1 && header == nullptr) return fail(TTEMB_E_WORKSPACE, "fast path needs the workspace header");
+  plan->epochs = reinterpret_cast<uint64_t*>(header);
+  plan->rcount = plan->epochs ? plan->epochs + 2 : nullptr;
   const bool external = plan_buf != nullptr && plan_bytes >= fast3_plan_bytes(s, nnz);
   if (plan_state != 0 && !external) return fail(TTEMB_E_BADARG, "this call needs a plan buffer of ttemb_plan_bytes() bytes");
   const bool reuse = plan_state >= 2;
@@ -2632,7 +2636,7 @@ static int run_backward_wide(const DevShape& s, const CorePtrs& cores, const Gro
 int launch_forward_fast3(const DevShape& s, const CorePtrs& cores, const int64_t* indices,
                          const int64_t* rowidx, const int64_t* offsets, int64_t nnz, const int32_t* nnz_dev,
                          int64_t B, float* output, bool zero_rows, void* ws, int64_t ws_bytes, void* plan_buf,
-                         int64_t plan_bytes, int phase, hipStream_t st) {
+                         int64_t plan_bytes, int phase, hipStream_t st, void* header) {
   if (nnz <= 0) return TTEMB_OK;
   if (!fits_piece(s, nnz, B)) {
     // The call is cut into pieces (struct Piece).  The id-only half of a two-phase forward does nothing then, the lookup half
@@ -2649,7 +2653,7 @@ int launch_forward_fast3(const DevShape& s, const CorePtrs& cores, const int64_t
     for (int k = 0; k < slots && rc == TTEMB_OK; ++k) {
       GroupPlan plan;
       rc = prepare(s, cores, false, indices, rowidx, offsets, np, nullptr, B, zero_rows ? output : nullptr,
-                   reinterpret_cast<char*>(ws) + head, ws_bytes - head, nullptr, 0, 0, &plan, st, tab + k);
+                   reinterpret_cast<char*>(ws) + head, ws_bytes - head, nullptr, 0, 0, &plan, st, header, tab + k);
       if (rc) break;
       rc = fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
       if (wide(s)) {
@@ -2666,7 +2670,7 @@ int launch_forward_fast3(const DevShape& s, const CorePtrs& cores, const int64_t
   }
   GroupPlan plan;
   int rc = prepare(s, cores, false, indices, rowidx, offsets, nnz, nnz_dev, B, zero_rows ? output : nullptr, ws, ws_bytes,
-                   plan_buf, plan_bytes, phase, &plan, st);   // phase 0 / 1 / 2 = whole forward / ids only / lookup on a grouped plan
+                   plan_buf, plan_bytes, phase, &plan, st, header);   // phase 0 / 1 / 2 = whole forward / ids only / lookup on a grouped plan
   if (rc || phase == 1) return rc;
   if (wide(s)) {
 #define TTEMB_X(a, b, c, d, e) if (shape_is(s, a, b, c, d, e)) return run_forward_direct<a, b, c, d, e>(s, cores, plan, nnz, B, output, st);
@@ -2757,7 +2761,7 @@ static int run_backward(const DevShape& s, const CorePtrs& cores, const GroupPla
 int launch_backward_fast3(const DevShape& s, const CorePtrs& cores, const int64_t* indices,
                           const int64_t* rowidx, const int64_t* offsets, int64_t nnz, const int32_t* nnz_dev,
                           int64_t B, const float* d_output, const CorePtrsMut& d_cores, void* ws, int64_t ws_bytes,
-                          const void* plan_buf, int64_t plan_bytes, hipStream_t st, const FusedUpdate* update) {
+                          const void* plan_buf, int64_t plan_bytes, hipStream_t st, const FusedUpdate* update, void* header) {
   FusedUpdate upd;
   memset(&upd, 0, sizeof(upd));
   if (update != nullptr) upd = *update;
@@ -2784,7 +2788,7 @@ int launch_backward_fast3(const DevShape& s, const CorePtrs& cores, const int64_
     for (int k = 0; k < slots && rc == TTEMB_OK; ++k) {
       GroupPlan plan;
       rc = prepare(s, cores, true, indices, rowidx, offsets, np, nullptr, B, nullptr, reinterpret_cast<char*>(ws) + head, ws_bytes - head,
-                   nullptr, 0, 0, &plan, st, tab + k);
+                   nullptr, 0, 0, &plan, st, header, tab + k);
       if (rc) break;
       upd.eps = k > 0 ? 1.f : 0.f;   // (dense mode: finalize adds to the gradient instead of writing it)
       rc = fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
@@ -2803,7 +2807,7 @@ int launch_backward_fast3(const DevShape& s, const CorePtrs& cores, const int64_
   GroupPlan plan;
   int rc = prepare(s, cores, true, indices, rowidx, offsets, nnz, nnz_dev, B, nullptr, ws, ws_bytes,
                    const_cast<void*>(plan_buf), plan_bytes,
-                   plan_buf != nullptr && plan_bytes >= fast3_plan_bytes(s, nnz) ? 3 : 0, &plan, st);
+                   plan_buf != nullptr && plan_bytes >= fast3_plan_bytes(s, nnz) ? 3 : 0, &plan, st, header);
   if (rc) return rc;
   if (wide(s)) {
 #define TTEMB_X(a, b, c, d, e) if (shape_is(s, a, b, c, d, e)) return run_backward_wide<a, b, c, d, e>(s, cores, plan, nnz, B, d_output, d_cores, upd, st);

@@ -6,10 +6,17 @@
  * `tt_embeddings` (FBTT/tt_embeddings.cpp:131-161); the replaced interface is cited
  * per function.  The boundary is plain C: raw device pointers, explicit sizes, an
  * opaque `hipStream_t` passed as `void*`, a caller-provided workspace.  No allocation,
- * no host synchronisation unless a function says so, and no state between calls except
- * two process-wide DIAGNOSTIC switches that never change a result: the kernel-family
- * override (ttemb_set_path; tests and benchmarks force a family with it) and the event
+ * no host synchronisation unless a function says so, and no state in the library between
+ * calls except process-wide DIAGNOSTIC switches that never change a result: the kernel-family
+ * override (ttemb_set_path), the piece limits (ttemb_set_piece_limits) and the event
  * profiler (ttemb_profile_enable).  A caller that never touches them has none.
+ *
+ * The workspace: every op leaves the first 8 KB of its workspace alone except the grouped
+ * lookup, which keeps a call counter and a few pre-tagged counters there (in DEVICE memory, so
+ * that a replayed HIP graph counts on).  Whatever those bytes hold is valid -- a fresh or
+ * recycled buffer costs the first call a slower counting step, never a wrong result -- so
+ * nothing has to be initialised; handing the same workspace to successive calls (what the
+ * Python class does) keeps the fast step.  One workspace must not serve two streams at once.
  *
  * Conventions
  *   - all pointers are DEVICE pointers unless the name ends in `_host`;
