@@ -366,6 +366,46 @@ def main():
             dt = (time.perf_counter() - t1) / len(test)
             cached = {"ids": N, "ms_per_step": round(dt * 1e3, 4), "lookups_per_s": round(N / dt, 1),
                       "cache_rows": int(cemb.cache_weight.shape[0]), "hit_rate": round(hit, 3)}
+            # the same frontiers through the cache-less module: what the cache is up against
+            for b in test[:4]:
+                emb(b, offsets).backward(d_out)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for b in test:
+                emb(b, offsets).backward(d_out)
+            torch.cuda.synchronize()
+            dt_off = (time.perf_counter() - t1) / len(test)
+            cached["cache_off_same_frontiers_ms"] = round(dt_off * 1e3, 4)
+            # HBM-bound gather / update kernels of the cached rows, from the committed rocprofv3 summary of the same workload
+            # (tools/cache_bench.py under tools/prof_cache.sh): algorithmic bytes per cached row -- forward 8 + 4 + 4 D read +
+            # 4 D written = 812 B, backward 8 + 4 + 4 D gradient + 4 D row read + 4 D written = 1 212 B -- over the kernel time
+            prof = "profiles/r03_cache_kernel_stats.csv"
+            try:
+                import csv
+                with open(os.path.join(ROOT, prof)) as fh:
+                    avg = {r["Name"].split("(")[0].replace("void ", "").replace("ttemb::", ""): float(r["AverageNs"]) * 1e-3
+                           for r in csv.DictReader(fh)}
+                rows = hit * N
+                kern = {}
+                for name, bpr in (("cache_forward_kernel", 8 + 4 + 8 * D), ("cache_scatter_add_kernel", 8 + 4 + 12 * D)):
+                    if name in avg:
+                        gbs = rows * bpr / (avg[name] * 1e-6) / 1e9
+                        kern[name] = {"avg_us": round(avg[name], 1), "bytes_per_cached_row": bpr, "gbs": round(gbs, 1),
+                                      "frac_of_hbm_peak": round(gbs / PEAK_HBM_GBS, 3)}
+                for name in ("cache_lookup_kernel<true>", "partition_scatter_kernel"):
+                    if name in avg:
+                        kern[name] = {"avg_us": round(avg[name], 1), "what": "per id of the batch, cached or not"}
+                cached["kernels"] = kern
+                cached["kernels_source"] = prof
+            except (OSError, KeyError, ValueError):
+                pass
+            # A cached row moves 2 024 B of HBM traffic per step (forward + update) and takes one more probe than a TT row,
+            # whose marginal cost on this hardware is lower (the TT step grows by ~0.34 ns per id, the cached rows' two
+            # kernels cost ~0.56 ns per row at the 3.1-3.6 TB/s random 400-byte rows sustain): no hit rate pays for the cache
+            # at this TT speed.  It is served for interface parity (BASELINE configs[2]), not for speed.
+            cached["break_even_hit_rate"] = None
+            cached["break_even_note"] = ("none: marginal cost of a cached row (gather + update kernels) exceeds that of a TT row "
+                                         "at every hit rate on MI355X; see DESIGN.md section 5c")
             del cemb
         # second half of BASELINE.json's metric: SAGE epoch time on the products shapes.  DGL / OGB are not in the
         # image, so the epoch is tools/sage_epoch.py's restatement of sage_dgl_partition.py:train() around the TT

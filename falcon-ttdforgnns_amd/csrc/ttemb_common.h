@@ -82,7 +82,7 @@ int launch_forward_fast3(const DevShape& s, const CorePtrs& cores, const int64_t
                          int64_t ws_bytes, void* plan, int64_t plan_bytes, int phase, hipStream_t st, void* header);
 // `header`: kFast3HeaderBytes at the start of the caller's workspace, the same address for every op on that workspace: the
 // words of the grouping pass that outlive a call (its epoch, the pre-tagged range counters).  Any content is valid.
-constexpr int64_t kFast3HeaderBytes = 8192;
+constexpr int64_t kFast3HeaderBytes = 40960;
 // optimiser step folded into the last backward kernel (w == nullptr: none, gradients are written instead)
 struct FusedUpdate {
   float* w[TTEMB_MAX_CORES];

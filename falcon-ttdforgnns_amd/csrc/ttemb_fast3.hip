@@ -163,6 +163,7 @@ constexpr int kMaxSlices = 1024;
 constexpr int kMaxRanges = 512;               // ranges of the group space (a power-of-two number of groups each)
 constexpr int kSortBatch = 8;                 // ids per thread whose loads are in flight together
 constexpr uint32_t kFirstBit = 0x100u, kLastBit = 0x200u;   // flags next to a chunk's length
+constexpr int kCountBanks = 8;                               // banks of range counters (see GroupPlan::rcount)
 // Epoch tag of a range counter: 38 bits above a 26-bit id count, the top bit always SET -- whatever a word held before
 // (zeros, all-ones cache locations, floats), adding a count to it cannot produce a valid tag by carry.
 __host__ __device__ __forceinline__ uint64_t counter_tag(uint64_t epoch) { return ((epoch & ((1ull << 37) - 1ull)) | (1ull << 37)) << 26; }
@@ -192,8 +193,11 @@ struct GroupPlan {           // device pointers into the caller's plan buffer / 
   uint32_t* i2_mid;
   uint32_t* vals_mid;
   uint32_t* shist;           // [slices][ranges] place of slice s inside range r (arrival order of the slices)
-  uint64_t* rcount;          // [ranges] (epoch << 26 | ids of the range so far): the tag makes a counter of an earlier call -- or
-                             //     whatever the memory held -- read as zero, so nothing has to be cleared between calls
+  uint64_t* rcount;          // [kCountBanks][kMaxRanges] (epoch tag | ids of the range so far, from the slices of the bank): the tag
+                             //     makes a counter of an earlier call -- or whatever the memory held -- read as zero, so nothing
+                             //     has to be cleared between calls.  Slices are dealt to the banks round-robin: the atomics of
+                             //     200 slices on ONE counter per range were a serial chain of 200 memory-side operations
+                             //     (decode 19-23 us); eight banks make it 25 (and the spread step adds eight words per range)
   uint32_t* rstart;          // [ranges + 1] first position of every range in the range-ordered arrays
   uint32_t* gstamp;          // [G] epoch (low word) of the last call that saw an id of the group (a stale or foreign word only
                              //     ever adds a prefix product nobody reads: it needs no clearing and no initial state)
@@ -345,7 +349,7 @@ __global__ __launch_bounds__(kSortThreads) void fast3_decode_kernel(
   const uint64_t tag = counter_tag(plan.epochs[0] + 1ull);
   uint32_t* dst = plan.shist + (size_t)blockIdx.x * ranges;
   for (uint32_t i = threadIdx.x; i < ranges; i += kSortThreads) {
-    unsigned long long* ctr = reinterpret_cast<unsigned long long*>(&plan.rcount[i]);
+    unsigned long long* ctr = reinterpret_cast<unsigned long long*>(&plan.rcount[(blockIdx.x % kCountBanks) * kMaxRanges + i]);
     unsigned long long old = atomicAdd(ctr, (unsigned long long)hist[i]);
     uint32_t place = (uint32_t)(old & 0x3ffffffull);
     if ((old & ~0x3ffffffull) != tag) {
@@ -369,9 +373,23 @@ __global__ __launch_bounds__(kSortThreads) void fast3_decode_kernel(
 // + this slice's place inside r.
 __device__ __forceinline__ void spread_slice(uint32_t s, uint32_t slices, uint32_t nnz, uint32_t per_slice, uint32_t shift,
                                              uint32_t ranges, const GroupPlan& plan, uint32_t* cursor, uint32_t* wave_sums) {
-  // (every slice added to every counter of this call -- zeros included -- so all of them carry this call's tag)
-  const uint32_t tot = threadIdx.x < ranges ? (uint32_t)(plan.rcount[threadIdx.x] & 0x3ffffffull) : 0u;
-  const uint32_t bef = threadIdx.x < ranges ? plan.shist[(size_t)s * ranges + threadIdx.x] : 0u;
+  // (every slice added to its bank's counter of every range -- zeros included -- so a bank that got a slice carries this
+  // call's tag; one that got none -- fewer slices than banks -- still holds the tag the place step before left, or anything:
+  // its count only counts under this call's tag)
+  uint32_t tot = 0, bef = 0;
+  if (threadIdx.x < ranges) {
+    const uint64_t tag = counter_tag(plan.epochs[0] + 1ull);
+    uint64_t w[kCountBanks];
+#pragma unroll
+    for (int b = 0; b < kCountBanks; ++b) w[b] = plan.rcount[b * kMaxRanges + threadIdx.x];
+    bef = plan.shist[(size_t)s * ranges + threadIdx.x];
+#pragma unroll
+    for (int b = 0; b < kCountBanks; ++b) {
+      const uint32_t c = (w[b] & ~0x3ffffffull) == tag ? (uint32_t)(w[b] & 0x3ffffffull) : 0u;
+      tot += c;
+      if ((uint32_t)b < s % kCountBanks) bef += c;   // the banks before this slice's come first inside the range
+    }
+  }
   uint32_t all;
   const uint32_t excl = block_exclusive<uint32_t, kSortThreads>(tot, wave_sums, all);
   if (threadIdx.x < ranges) {
@@ -556,7 +574,7 @@ __device__ __forceinline__ void place_range(const uint32_t range, const uint32_t
     if (range == 0) plan.epochs[0] = plan.epochs[1];   // the call is counted (nobody reads this word during this launch)
     // this range's id counter, read for the last time by the spread step: left at (the NEXT call's tag | 0), so that
     // the next decode step's first add already counts
-    plan.rcount[range] = counter_tag(plan.epochs[1] + 1ull);
+    for (int b = 0; b < kCountBanks; ++b) plan.rcount[b * kMaxRanges + range] = counter_tag(plan.epochs[1] + 1ull);
   }
 }
 
@@ -571,10 +589,30 @@ __global__ __launch_bounds__(kRangeThreads) void fast3_place_kernel(uint32_t nnz
 // piece ends after `max_ids` ids or in front of the first id whose bag lies `max_rows` bags past the piece's first bag,
 // whichever comes first -- so every row of a piece is < max_rows when counted from its first bag, whatever the bag lengths
 // (empty bags included).  At most ceil(nnz / max_ids) + ceil(B / max_rows) pieces: the host launches that many, unused
-// slots have count 0.  One thread: a few dozen steps of one binary search each.
-__global__ void plan_pieces_kernel(const int64_t* __restrict__ offsets, int64_t B, int64_t nnz, const int32_t* __restrict__ nnz_dev,
-                                   long long max_ids, long long max_rows, int D, int slots, Piece* __restrict__ tab) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+// slots have count 0.  One wavefront: a few dozen steps of two 64-ary searches each (four round trips at 16 M bags).
+// bag of position `pos` (the last b with offsets[b] <= pos), searched by a whole wavefront: 64 probes per round trip
+__device__ __forceinline__ long long wave_bag_of_position(const int64_t* __restrict__ offsets, long long B, long long pos, int lane) {
+  long long lo = 0, hi = B;   // invariant: offsets[lo] <= pos < offsets[hi]
+  while (hi - lo > 1) {
+    const long long span = hi - lo, step = (span + kWave - 1) / kWave;
+    long long probe = lo + (lane + 1) * step;
+    probe = probe > hi ? hi : probe;
+    const bool ok = probe < hi && (long long)offsets[probe] <= pos;   // true for a prefix of the lanes (offsets do not decrease)
+    const int k = __popcll(__ballot(ok));
+    const long long nlo = k > 0 ? lo + k * step : lo;           // the last probe that passed (k <= 63 here: probe k = 64 is hi or past it)
+    long long nhi = lo + (long long)(k + 1) * step;             // the first that did not
+    nhi = nhi > hi ? hi : nhi;
+    lo = nlo;
+    hi = nhi;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(kWave) void plan_pieces_kernel(const int64_t* __restrict__ offsets, int64_t B, int64_t nnz,
+                                                            const int32_t* __restrict__ nnz_dev, long long max_ids, long long max_rows,
+                                                            int D, int slots, Piece* __restrict__ tab) {
+  if (blockIdx.x != 0) return;
+  const int lane = threadIdx.x;
   const long long total = live_count(nnz, nnz_dev);
   long long pos = 0, zr = 0;
   for (int k = 0; k < slots; ++k) {
@@ -584,8 +622,8 @@ __global__ void plan_pieces_kernel(const int64_t* __restrict__ offsets, int64_t 
     pc.rowbase = 0;
     pc.zero0 = pc.zero1 = zr;
     pc.window_bytes = 0;
-    if (pos < total) {
-      const long long rb = bag_of_position(offsets, B, pos);
+    if (pos < total) {   // (wave-uniform)
+      const long long rb = wave_bag_of_position(offsets, B, pos, lane);
       const long long row_end = rb + max_rows;   // first bag this piece must not reach
       long long end = row_end < B ? (long long)offsets[row_end] : total;   // first position of that bag
       end = end > total ? total : end;
@@ -596,7 +634,7 @@ __global__ void plan_pieces_kernel(const int64_t* __restrict__ offsets, int64_t 
       // bags to clear: from where the piece before stopped up to the bag the next piece starts in -- inclusive when that
       // bag began inside this piece (it is split between the two, and this one runs first)
       if (end < total) {
-        const long long nb = bag_of_position(offsets, B, end);
+        const long long nb = wave_bag_of_position(offsets, B, end, lane);
         pc.zero1 = (long long)offsets[nb] == end ? nb : nb + 1;
       } else {
         pc.zero1 = B;
@@ -607,7 +645,7 @@ __global__ void plan_pieces_kernel(const int64_t* __restrict__ offsets, int64_t 
       zr = pc.zero1;
       pos = end;
     }
-    tab[k] = pc;
+    if (lane == 0) tab[k] = pc;
   }
 }
 
@@ -625,7 +663,7 @@ __global__ void plan_pieces_kernel(const int64_t* __restrict__ offsets, int64_t 
 constexpr int kPrefixGroups = TTEMB_PREFIX_GROUPS;   // values of i0 per wavefront
 template <int Q0, int Q1, int Q2, int R1, int R2>
 __device__ __forceinline__ void prefix_unit(const float* __restrict__ G0, const float* __restrict__ G1, uint32_t p0,
-                                            const GroupPlan& plan, uint32_t i0_block, uint32_t i1, int lane, bool stamps) {
+                                            const GroupPlan& plan, uint32_t i0_block, uint32_t i1, int lane, int stamps) {
   using C = Cfg<Q0, Q1, Q2, R1, R2>;
   constexpr int GM = 16 / Q0;  // whole groups per 16-row MFMA tile (q0 = 5: three groups, the last tile row idles)
   const int hi = lane >> 4, lo = lane & 15;
@@ -633,10 +671,12 @@ __device__ __forceinline__ void prefix_unit(const float* __restrict__ G0, const 
   const uint32_t i0_end = i0_begin + kPrefixGroups < p0 ? i0_begin + kPrefixGroups : p0;
   // any work at all?  (one lane per i0 of the slice)
   const uint32_t my = i0_begin + lane;
-  // which groups hold an id: their counters when the grouping is complete, else the stamps the decode step of this call
-  // left (the unit then runs next to the spread step, before the counters exist; epochs[0] is stable until the place step)
+  // which groups hold an id: their counters when the grouping is complete (stamps == 0), else the stamps the decode step of
+  // this call left -- the unit then runs next to the spread step (1: the call's number is epochs[0] + 1, stable until the
+  // place step) or next to the place step (2: epochs[1], which the spread step wrote), before the counters exist
+  const uint32_t want = stamps == 0 ? 0u : (uint32_t)(stamps == 1 ? plan.epochs[0] + 1ull : plan.epochs[1]);
   const bool mine = lane < kPrefixGroups && my < i0_end &&
-                    (stamps ? plan.gstamp[i1 * p0 + my] == (uint32_t)(plan.epochs[0] + 1ull) : plan.counts[i1 * p0 + my] != 0u);
+                    (stamps != 0 ? plan.gstamp[i1 * p0 + my] == want : plan.counts[i1 * p0 + my] != 0u);
   const unsigned long long live = __ballot(mine);
   if (!live) return;
   const float* g1 = G1 + (size_t)i1 * C::ROW1;
@@ -680,23 +720,23 @@ __device__ __forceinline__ void prefix_unit(const float* __restrict__ G0, const 
 template <int Q0, int Q1, int Q2, int R1, int R2>
 __global__ __launch_bounds__(64) void fast3_prefix_kernel(const float* __restrict__ G0, const float* __restrict__ G1,
                                                           uint32_t p0, uint32_t stamps, GroupPlan plan) {
-  prefix_unit<Q0, Q1, Q2, R1, R2>(G0, G1, p0, plan, blockIdx.x, blockIdx.y, (int)threadIdx.x, stamps != 0u);
+  prefix_unit<Q0, Q1, Q2, R1, R2>(G0, G1, p0, plan, blockIdx.x, blockIdx.y, (int)threadIdx.x, (int)stamps);
 }
 
-// Does the prefix unit fit the 128 registers of a 1024-thread workgroup next to the spread step?  At rank 32 the G1 row a
-// unit keeps as B operands is 64-80 registers: q = 4,5,5 / 5,5,4 / 4,4,8 spilled 20-72 bytes per lane there (q = 8,4,4 --
-// the papers100M shape -- has room).  Those shapes launch their prefix products between the decode and the spread step.
+// The prefix products ride in the spread AND the place launch, half of the units in each (they need the cores and the decode
+// step's stamps, nothing the grouping computes later): latency-bound kernels share the machine instead of queueing.  (All
+// of them next to the spread step: 17.7 us for a launch whose two halves take 11 and 8.6 us alone.)  At rank 32 a unit
+// keeps 64-80 registers of G1 row -- more than a 1024-thread workgroup has next to the spread step (q = 4,5,5 / 5,5,4 /
+// 4,4,8 spilled 20-72 bytes per lane there; q = 8,4,4, the papers100M shape, has room): those shapes put every unit into
+// the place launch (512-thread workgroups).
 template <int Q0, int Q1, int Q2, int R1, int R2>
 struct PrefixRides {
   static constexpr bool value = R1 < 32 || Q0 >= 8;
 };
 
-// The spread step and the prefix products in one launch (the products need the cores and the decode step's stamps, nothing
-// the grouping computes later): workgroups [0, slices) spread their slice, the rest take kSortThreads / 64 prefix units
-// each -- two latency-bound kernels share the machine instead of queueing.
 template <int Q0, int Q1, int Q2, int R1, int R2>
 __global__ __launch_bounds__(kSortThreads) void fast3_spread_prefix_kernel(uint32_t slices, uint32_t nnz, uint32_t per_slice,
-                                                                          uint32_t shift, uint32_t ranges,
+                                                                          uint32_t shift, uint32_t ranges, uint32_t unit_end,
                                                                           const float* __restrict__ G0,
                                                                           const float* __restrict__ G1, uint32_t p0,
                                                                           uint32_t p1, GroupPlan plan) {
@@ -708,9 +748,27 @@ __global__ __launch_bounds__(kSortThreads) void fast3_spread_prefix_kernel(uint3
   }
   const uint32_t blocks0 = (p0 + kPrefixGroups - 1) / kPrefixGroups;
   const uint32_t unit = (blockIdx.x - slices) * (kSortThreads / kWave) + (threadIdx.x >> 6);
-  if (unit >= blocks0 * p1) return;
+  if (unit >= unit_end) return;
   if constexpr (PrefixRides<Q0, Q1, Q2, R1, R2>::value)
-    prefix_unit<Q0, Q1, Q2, R1, R2>(G0, G1, p0, plan, unit % blocks0, unit / blocks0, (int)(threadIdx.x & 63), true);
+    prefix_unit<Q0, Q1, Q2, R1, R2>(G0, G1, p0, plan, unit % blocks0, unit / blocks0, (int)(threadIdx.x & 63), 1);
+}
+
+template <int Q0, int Q1, int Q2, int R1, int R2>
+__global__ __launch_bounds__(kRangeThreads) void fast3_place_prefix_kernel(uint32_t ranges, uint32_t nnz, uint32_t max_chunks,
+                                                                          uint32_t G, uint32_t shift, uint32_t unit_begin,
+                                                                          const float* __restrict__ G0,
+                                                                          const float* __restrict__ G1, uint32_t p0,
+                                                                          uint32_t p1, GroupPlan plan) {
+  extern __shared__ uint32_t lds_s[];
+  __shared__ uint64_t red[2 * (kRangeThreads / kWave + 1)];
+  if (blockIdx.x < ranges) {
+    place_range(blockIdx.x, ranges, G, shift, nnz, max_chunks, plan, lds_s, red);
+    return;
+  }
+  const uint32_t blocks0 = (p0 + kPrefixGroups - 1) / kPrefixGroups;
+  const uint32_t unit = unit_begin + (blockIdx.x - ranges) * (kRangeThreads / kWave) + (threadIdx.x >> 6);
+  if (unit >= blocks0 * p1) return;
+  prefix_unit<Q0, Q1, Q2, R1, R2>(G0, G1, p0, plan, unit % blocks0, unit / blocks0, (int)(threadIdx.x & 63), 2);
 }
 
 // ---------------------------------------------------------------------------------
@@ -2109,9 +2167,11 @@ bool fast3_wide(const DevShape& s) { return wide(s); }
 static int64_t num_groups(const DevShape& s) { return (int64_t)s.p[0] * s.p[1]; }
 
 // the grouping pass: slices of the id list; ranges of 2^shift groups each
-static int sort_slices(int64_t nnz) {
+static int chain_cus();
+static int sort_slices(int64_t nnz) {   // one 1024-thread workgroup per slice, at most one per CU (a CU takes one at a time)
   const int64_t s = (nnz + kSliceIds - 1) / kSliceIds;
-  return (int)(s < 1 ? 1 : (s > kMaxSlices ? kMaxSlices : s));
+  const int64_t most = chain_cus() < kMaxSlices ? chain_cus() : kMaxSlices;
+  return (int)(s < 1 ? 1 : (s > most ? most : s));
 }
 static int sort_shift(int64_t G) {
   int shift = 0;
@@ -2370,8 +2430,8 @@ int64_t fast3_workspace_bytes(const DevShape& s, int32_t op, int64_t nnz, int64_
 
 // fill plan->{i2s, vals, counts, gpre, ctab} from the ids
 static int run_prefix(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, hipStream_t st);
-static int run_spread_prefix(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int64_t nnz, int slices, uint32_t per_slice,
-                             int ranges, int shift, hipStream_t st);
+static int run_spread_place_prefix(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int64_t nnz, int slices,
+                                   uint32_t per_slice, int ranges, int shift, hipStream_t st);
 
 static int group_ids(const DevShape& s, const CorePtrs& cores, const int64_t* indices, const int64_t* rowidx,
                      const int64_t* offsets, int64_t nnz, const int32_t* nnz_dev, int64_t B, float* zero_out,
@@ -2388,13 +2448,10 @@ static int group_ids(const DevShape& s, const CorePtrs& cores, const int64_t* in
                      (uint32_t)s.p[2], (uint32_t)shift, (uint32_t)ranges, *plan);
   int rc = check_hip(hipGetLastError(), "fast3_decode_kernel");
   if (rc) return rc;
-  if (with_prefix && !wide(s)) {
-    rc = run_spread_prefix(s, cores, *plan, nnz, slices, per_slice, ranges, shift, st);
-  } else {
-    hipLaunchKernelGGL(fast3_spread_kernel, dim3((unsigned)slices), dim3(kSortThreads), 0, st, (uint32_t)nnz, per_slice,
-                       (uint32_t)shift, (uint32_t)ranges, *plan);
-    rc = check_hip(hipGetLastError(), "fast3_spread_kernel");
-  }
+  if (with_prefix && !wide(s)) return run_spread_place_prefix(s, cores, *plan, nnz, slices, per_slice, ranges, shift, st);
+  hipLaunchKernelGGL(fast3_spread_kernel, dim3((unsigned)slices), dim3(kSortThreads), 0, st, (uint32_t)nnz, per_slice,
+                     (uint32_t)shift, (uint32_t)ranges, *plan);
+  rc = check_hip(hipGetLastError(), "fast3_spread_kernel");
   if (rc) return rc;
   hipLaunchKernelGGL(fast3_place_kernel, dim3((unsigned)ranges), dim3(kRangeThreads), span * 16, st, (uint32_t)nnz,
                      (uint32_t)max_chunks(s, nnz), (uint32_t)G, (uint32_t)shift, *plan);
@@ -2418,6 +2475,7 @@ static int prepare(const DevShape& s, const CorePtrs& cores, bool bwd, const int
   if (plan_state <= 1 && header == nullptr) return fail(TTEMB_E_WORKSPACE, "fast path needs the workspace header");
   plan->epochs = reinterpret_cast<uint64_t*>(header);
   plan->rcount = plan->epochs ? plan->epochs + 2 : nullptr;
+  static_assert(16 + (int64_t)kCountBanks * kMaxRanges * 8 <= kFast3HeaderBytes, "the header holds the epoch words and every bank of range counters");
   const bool external = plan_buf != nullptr && plan_bytes >= fast3_plan_bytes(s, nnz);
   if (plan_state != 0 && !external) return fail(TTEMB_E_BADARG, "this call needs a plan buffer of ttemb_plan_bytes() bytes");
   const bool reuse = plan_state >= 2;
@@ -2494,29 +2552,34 @@ static int run_prefix(const DevShape& s, const CorePtrs& cores, const GroupPlan&
   return fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
 }
 
+// spread step + first half of the prefix units, then place step + the rest
 template <int Q0, int Q1, int Q2, int R1, int R2>
-static int run_spread_prefix_t(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int64_t nnz, int slices,
-                               uint32_t per_slice, int ranges, int shift, hipStream_t st) {
-  unsigned units = (unsigned)((s.p[0] + kPrefixGroups - 1) / kPrefixGroups) * (unsigned)s.p[1];
-  const unsigned per_wg = kSortThreads / kWave;
-  if constexpr (!PrefixRides<Q0, Q1, Q2, R1, R2>::value) {   // a launch of its own, on this call's stamps
-    hipLaunchKernelGGL((fast3_prefix_kernel<Q0, Q1, Q2, R1, R2>),
-                       dim3((unsigned)((s.p[0] + kPrefixGroups - 1) / kPrefixGroups), (unsigned)s.p[1]), dim3(64), 0, st,
-                       cores.c[0], cores.c[1], (uint32_t)s.p[0], 1u, plan);
-    int rc = check_hip(hipGetLastError(), "fast3_prefix_kernel");
-    if (rc) return rc;
-    units = 0;
-  }
-  hipLaunchKernelGGL((fast3_spread_prefix_kernel<Q0, Q1, Q2, R1, R2>), dim3((unsigned)slices + (units + per_wg - 1) / per_wg),
-                     dim3(kSortThreads), 0, st, (uint32_t)slices, (uint32_t)nnz, per_slice, (uint32_t)shift, (uint32_t)ranges,
+static int run_spread_place_prefix_t(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int64_t nnz, int slices,
+                                     uint32_t per_slice, int ranges, int shift, hipStream_t st) {
+  const unsigned units = (unsigned)((s.p[0] + kPrefixGroups - 1) / kPrefixGroups) * (unsigned)s.p[1];
+  // A CU takes ONE 1024-thread workgroup at a time: a spread launch of more workgroups than CUs runs its surplus as a second
+  // round (split 50 %: 200 + 70 workgroups on 256 CUs, 17.3 us against 11.8 at 25 %).  A quarter of the units rides with the
+  // spread step -- what fits the CUs its slices leave free -- the rest with the place step (409 600 ids, spread + place:
+  // 25.6 / 25.2 / 30.1 / 30.0 / 29.6 us at 0 / 25 / 50 / 75 / 100 %; as launches of their own 10.7 + 11.2 + 8.8).
+  const unsigned per_a = kSortThreads / kWave, per_b = kRangeThreads / kWave;
+  const unsigned room = chain_cus() > slices ? (unsigned)(chain_cus() - slices) * per_a : 0u;
+  unsigned first = PrefixRides<Q0, Q1, Q2, R1, R2>::value ? units / 4 : 0u;
+  first = first > room ? room : first;
+  hipLaunchKernelGGL((fast3_spread_prefix_kernel<Q0, Q1, Q2, R1, R2>), dim3((unsigned)slices + (first + per_a - 1) / per_a),
+                     dim3(kSortThreads), 0, st, (uint32_t)slices, (uint32_t)nnz, per_slice, (uint32_t)shift, (uint32_t)ranges, first,
                      cores.c[0], cores.c[1], (uint32_t)s.p[0], (uint32_t)s.p[1], plan);
-  return check_hip(hipGetLastError(), "fast3_spread_prefix_kernel");
+  int rc = check_hip(hipGetLastError(), "fast3_spread_prefix_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL((fast3_place_prefix_kernel<Q0, Q1, Q2, R1, R2>), dim3((unsigned)ranges + (units - first + per_b - 1) / per_b),
+                     dim3(kRangeThreads), ((size_t)16 << shift), st, (uint32_t)ranges, (uint32_t)nnz, (uint32_t)max_chunks(s, nnz),
+                     (uint32_t)num_groups(s), (uint32_t)shift, first, cores.c[0], cores.c[1], (uint32_t)s.p[0], (uint32_t)s.p[1], plan);
+  return check_hip(hipGetLastError(), "fast3_place_prefix_kernel");
 }
 
-static int run_spread_prefix(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int64_t nnz, int slices, uint32_t per_slice,
-                             int ranges, int shift, hipStream_t st) {
+static int run_spread_place_prefix(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int64_t nnz, int slices,
+                                   uint32_t per_slice, int ranges, int shift, hipStream_t st) {
   if (classify(s)) {
-#define TTEMB_X(a, b, c, d, e) if (shape_is(s, a, b, c, d, e)) return run_spread_prefix_t<a, b, c, d, e>(s, cores, plan, nnz, slices, per_slice, ranges, shift, st);
+#define TTEMB_X(a, b, c, d, e) if (shape_is(s, a, b, c, d, e)) return run_spread_place_prefix_t<a, b, c, d, e>(s, cores, plan, nnz, slices, per_slice, ranges, shift, st);
     TTEMB_FAST3_SHAPES(TTEMB_X)
 #undef TTEMB_X
   }

@@ -11,7 +11,7 @@
  * override (ttemb_set_path), the piece limits (ttemb_set_piece_limits) and the event
  * profiler (ttemb_profile_enable).  A caller that never touches them has none.
  *
- * The workspace: every op leaves the first 8 KB of its workspace alone except the grouped
+ * The workspace: every op leaves the first 40 KB of its workspace alone except the grouped
  * lookup, which keeps a call counter and a few pre-tagged counters there (in DEVICE memory, so
  * that a replayed HIP graph counts on).  Whatever those bytes hold is valid -- a fresh or
  * recycled buffer costs the first call a slower counting step, never a wrong result -- so

@@ -59,21 +59,25 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_dp_step_world2(tmp_path):
-    world = 2
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 8])   # 8: the size of the node the scaling bench runs on (BASELINE configs[3] / [4])
+def test_dp_step(tmp_path, world):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     r = [torch.load(os.path.join(tmp_path, f"rank{k}.pt")) for k in range(world)]
     for t in range(3):
-        assert torch.equal(r[0]["start"][t], r[1]["start"][t])  # broadcast made replicas identical
-        mean_g = (r[0]["grads"][t] + r[1]["grads"][t]) / world
+        for k in range(1, world):
+            assert torch.equal(r[0]["start"][t], r[k]["start"][t])  # broadcast made replicas identical
+        mean_g = sum(r[k]["grads"][t] for k in range(world)) / world
         want = r[0]["start"][t] - 0.5 * mean_g
         for k in range(world):
-            np.testing.assert_allclose(r[k]["end"][t].numpy(), want.numpy(), rtol=1e-6, atol=1e-7)
-        assert torch.equal(r[0]["end"][t], r[1]["end"][t])  # replicas stay bit-identical
+            np.testing.assert_allclose(r[k]["end"][t].numpy(), want.numpy(), rtol=1e-5, atol=1e-6)
+            assert torch.equal(r[0]["end"][t], r[k]["end"][t])  # replicas stay bit-identical
         want2 = r[0]["end"][t] - 0.5 * mean_g                # the deferred (overlap=True) second step
         for k in range(world):
-            np.testing.assert_allclose(r[k]["end2"][t].numpy(), want2.numpy(), rtol=1e-6, atol=1e-7)
-        assert torch.equal(r[0]["end2"][t], r[1]["end2"][t])
+            np.testing.assert_allclose(r[k]["end2"][t].numpy(), want2.numpy(), rtol=1e-5, atol=1e-6)
+            assert torch.equal(r[0]["end2"][t], r[k]["end2"][t])
 
 
 def test_flat_bucket_layout():
