@@ -37,14 +37,14 @@ def main():
     ap.add_argument("--n", type=int, nargs="+", default=[409600])
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--dist", default="uniform", choices=["uniform", "windows", "arange", "grouped"])
-    ap.add_argument("--path", default="auto")
+    ap.add_argument("--path", default="auto", choices=["auto", "generic", "fast3", "per_bag"])
     ap.add_argument("--what", default="both", choices=["both", "fwd", "bwd"])
     ap.add_argument("--no-rowidx", action="store_true", help="ids + offsets only, as the module passes them (the per-bag kernels need this form)")
     ap.add_argument("--split", action="store_true", help="two-phase forward (ttemb_forward_group, then ttemb_forward_lookup): the grouping steps and the prefix products as launches of their own")
     a = ap.parse_args()
     p, q, R, n_emb = CFG[a.cfg]
     D = int(np.prod(q))
-    nat.set_path({"auto": 0, "generic": 1, "fast3": 2}[a.path])
+    nat.set_path({"auto": 0, "generic": 1, "fast3": 2, "per_bag": 3}[a.path])
     shape = nat.make_shape(p, q, R)
     rng = np.random.default_rng(0)
     cores = [torch.tensor((rng.standard_normal((p[t], R[t] * q[t] * R[t + 1])) * 0.3).astype(np.float32)).cuda()
