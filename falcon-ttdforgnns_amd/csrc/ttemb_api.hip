@@ -4,9 +4,12 @@
 #include "ttemb_common.h"
 #include "ttemb_cache.h"
 
+#include <dlfcn.h>
+
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace ttemb {
@@ -572,6 +575,46 @@ static int backward_into(const DevShape& ds, const CorePtrs& cp, const int64_t* 
 
 using namespace ttemb;
 
+// roctx ranges around the entry points (what the reference's drivers get from torch.profiler around the extension calls,
+// sage_profiler.py): with TTEMB_ROCTX=1 in the environment every lookup / cache entry point is bracketed by
+// roctxRangePush / roctxRangePop, so a rocprofv3 --marker-trace timeline shows the calls above their kernels.  The marker
+// library is looked up at run time (librocprofiler-sdk-roctx.so, else libroctx64.so): no link dependency, and nothing
+// but one relaxed load per call when the variable is not set.
+namespace {
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    const char* e = getenv("TTEMB_ROCTX");
+    if (e == nullptr || e[0] == '0' || e[0] == '\0') return;
+    for (const char* lib : {"librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
+      void* h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+      if (h == nullptr) continue;
+      push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+      pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+      if (push != nullptr && pop != nullptr) return;
+      push = nullptr;
+      pop = nullptr;
+    }
+  }
+};
+const Roctx& roctx() {
+  static const Roctx r;
+  return r;
+}
+struct ApiRange {
+  bool on;
+  explicit ApiRange(const char* name) : on(roctx().push != nullptr) {
+    if (on) roctx().push(name);
+  }
+  ~ApiRange() {
+    if (on) roctx().pop();
+  }
+  ApiRange(const ApiRange&) = delete;
+  ApiRange& operator=(const ApiRange&) = delete;
+};
+}  // namespace
+
 extern "C" {
 
 int ttemb_abi_version(void) { return TTEMB_ABI_VERSION; }
@@ -745,6 +788,7 @@ int ttemb_forward(const ttemb_shape_t* shape, const float* const* cores, const i
                   const int64_t* rowidx, const int64_t* offsets, int64_t nnz,
                   const int32_t* nnz_dev, int64_t B, float* output, void* workspace,
                   int64_t workspace_bytes, void* plan, int64_t plan_bytes, void* stream) {
+  ApiRange api_range("ttemb_forward");
   return forward_phase(0, shape, cores, indices, rowidx, offsets, nnz, nnz_dev, B, output, workspace, workspace_bytes, plan,
                        plan_bytes, stream);
 }
@@ -753,6 +797,7 @@ int ttemb_forward_group(const ttemb_shape_t* shape, const float* const* cores, c
                         const int64_t* rowidx, const int64_t* offsets, int64_t nnz,
                         const int32_t* nnz_dev, int64_t B, float* output, void* workspace,
                         int64_t workspace_bytes, void* plan, int64_t plan_bytes, void* stream) {
+  ApiRange api_range("ttemb_forward_group");
   return forward_phase(1, shape, cores, indices, rowidx, offsets, nnz, nnz_dev, B, output, workspace, workspace_bytes, plan,
                        plan_bytes, stream);
 }
@@ -761,6 +806,7 @@ int ttemb_forward_lookup(const ttemb_shape_t* shape, const float* const* cores, 
                          const int64_t* rowidx, const int64_t* offsets, int64_t nnz,
                          const int32_t* nnz_dev, int64_t B, float* output, void* workspace,
                          int64_t workspace_bytes, void* plan, int64_t plan_bytes, void* stream) {
+  ApiRange api_range("ttemb_forward_lookup");
   return forward_phase(2, shape, cores, indices, rowidx, offsets, nnz, nnz_dev, B, output, workspace, workspace_bytes, plan,
                        plan_bytes, stream);
 }
@@ -770,6 +816,7 @@ int ttemb_backward_dense(const ttemb_shape_t* shape, const float* const* cores,
                          const int32_t* nnz_dev, int64_t B, const float* d_output,
                          float* const* d_cores, void* workspace, int64_t workspace_bytes,
                          const void* plan, int64_t plan_bytes, void* stream) {
+  ApiRange api_range("ttemb_backward_dense");
   DevShape ds;
   int rc = make_dev_shape(shape, &ds);
   if (rc) return rc;
@@ -876,6 +923,7 @@ int ttemb_backward_sgd(const ttemb_shape_t* shape, float* const* cores, const in
                        const int64_t* rowidx, const int64_t* offsets, int64_t nnz, const int32_t* nnz_dev, int64_t B,
                        const float* d_output, float lr, void* workspace, int64_t workspace_bytes,
                        const void* plan, int64_t plan_bytes, void* stream) {
+  ApiRange api_range("ttemb_backward_sgd");
   return fused_backward(shape, cores, nullptr, indices, rowidx, offsets, nnz, nnz_dev, B, d_output, lr, 0.f,
                         workspace, workspace_bytes, plan, plan_bytes, stream);
 }
@@ -885,18 +933,21 @@ int ttemb_backward_adagrad(const ttemb_shape_t* shape, float* const* cores, floa
                            const int32_t* nnz_dev, int64_t B, const float* d_output, float lr,
                            float eps, void* workspace, int64_t workspace_bytes, const void* plan,
                            int64_t plan_bytes, void* stream) {
+  ApiRange api_range("ttemb_backward_adagrad");
   if (opt_state == nullptr) return fail(TTEMB_E_BADARG, "opt_state is null");
   return fused_backward(shape, cores, opt_state, indices, rowidx, offsets, nnz, nnz_dev, B, d_output, lr, eps,
                         workspace, workspace_bytes, plan, plan_bytes, stream);
 }
 
 int ttemb_sgd_step(float* weights, const float* grads, int64_t n, float lr, void* stream) {
+  ApiRange api_range("ttemb_sgd_step");
   if (n > 0 && (weights == nullptr || grads == nullptr)) return fail(TTEMB_E_BADARG, "null buffer");
   return run_sgd(weights, grads, n, lr, reinterpret_cast<hipStream_t>(stream));
 }
 
 int ttemb_adagrad_step(float* weights, float* state, const float* grads, int64_t n, float lr,
                        float eps, void* stream) {
+  ApiRange api_range("ttemb_adagrad_step");
   if (n > 0 && (weights == nullptr || grads == nullptr || state == nullptr)) return fail(TTEMB_E_BADARG, "null buffer");
   return run_adagrad(weights, state, grads, n, lr, eps, reinterpret_cast<hipStream_t>(stream));
 }
@@ -912,17 +963,20 @@ static int cache_update(const int64_t* indices, int64_t nnz, int64_t* hashtbl, i
 
 int ttemb_cache_update(const int64_t* indices, int64_t nnz, int64_t* hashtbl, int64_t* cache_freq,
                        int64_t H, void* stream) {
+  ApiRange api_range("ttemb_cache_update");
   return cache_update(indices, nnz, hashtbl, cache_freq, H, false, stream);
 }
 
 int ttemb_cache_update_one_sweep(const int64_t* indices, int64_t nnz, int64_t* hashtbl, int64_t* cache_freq,
                                  int64_t H, void* stream) {
+  ApiRange api_range("ttemb_cache_update_one_sweep");
   return cache_update(indices, nnz, hashtbl, cache_freq, H, true, stream);
 }
 
 int ttemb_cache_populate(const ttemb_shape_t* shape, const float* const* cores, int64_t* hashtbl,
                          int64_t* cache_freq, int32_t* cache_state, int64_t H, float* cache_weight,
                          int64_t C, void* workspace, int64_t workspace_bytes, void* stream) {
+  ApiRange api_range("ttemb_cache_populate");
   DevShape ds;
   int rc = make_dev_shape(shape, &ds);
   if (rc) return rc;
@@ -978,6 +1032,7 @@ int ttemb_preprocess(const int64_t* indices, const int64_t* offsets, int64_t nnz
                      int64_t* indices_out, int64_t* rowidx_out, int32_t* cache_loc_out,
                      int32_t* nnz_tt_dev, int32_t* dup_stamp, int32_t epoch, void* workspace, int64_t workspace_bytes,
                      void* stream) {
+  ApiRange api_range("ttemb_preprocess");
   (void)epoch;   // ABI 1 took a per-call epoch for the stamps; position stamps need none
   return preprocess_impl(indices, offsets, nnz, B, warmup, const_cast<int64_t*>(hashtbl), nullptr, cache_state, H, indices_out,
                          rowidx_out, cache_loc_out, nnz_tt_dev, dup_stamp, workspace, workspace_bytes, stream);
@@ -987,6 +1042,7 @@ int ttemb_preprocess_update(const int64_t* indices, const int64_t* offsets, int6
                             int64_t* cache_freq, const int32_t* cache_state, int64_t H, int64_t* indices_out,
                             int64_t* rowidx_out, int32_t* cache_loc_out, int32_t* nnz_tt_dev, int32_t* dup_stamp,
                             void* workspace, int64_t workspace_bytes, void* stream) {
+  ApiRange api_range("ttemb_preprocess_update");
   if (H <= 0 || !hashtbl || !cache_freq) return fail(TTEMB_E_BADARG, "ttemb_preprocess_update needs the hash table and its counters");
   return preprocess_impl(indices, offsets, nnz, B, 0, hashtbl, cache_freq, cache_state, H, indices_out, rowidx_out,
                          cache_loc_out, nnz_tt_dev, dup_stamp, workspace, workspace_bytes, stream);
@@ -1002,6 +1058,7 @@ static int check_cache_args(const void* loc, const void* rowidx, int64_t start, 
 int ttemb_cache_forward(const int32_t* cache_loc, const int64_t* rowidx, const int64_t* offsets, int64_t start,
                         const int32_t* start_dev, int64_t nnz, const float* cache_weight, int64_t D,
                         float* output, void* stream) {
+  ApiRange api_range("ttemb_cache_forward");
   int rc = check_cache_args(cache_loc, rowidx, start, nnz, D);
   if (rc) return rc;
   if (nnz > 0 && (!cache_weight || !output)) return fail(TTEMB_E_BADARG, "null buffer");
@@ -1012,6 +1069,7 @@ int ttemb_cache_forward(const int32_t* cache_loc, const int64_t* rowidx, const i
 int ttemb_cache_backward_sgd(const int32_t* cache_loc, const int64_t* rowidx, int64_t start,
                              const int32_t* start_dev, int64_t nnz, const float* d_output, int64_t D,
                              float lr, float* cache_weight, const int32_t* dup_dev, void* stream) {
+  ApiRange api_range("ttemb_cache_backward_sgd");
   int rc = check_cache_args(cache_loc, rowidx, start, nnz, D);
   if (rc) return rc;
   if (nnz > 0 && (!cache_weight || !d_output)) return fail(TTEMB_E_BADARG, "null buffer");
@@ -1022,6 +1080,7 @@ int ttemb_cache_backward_sgd(const int32_t* cache_loc, const int64_t* rowidx, in
 int ttemb_cache_backward_dense(const int32_t* cache_loc, const int64_t* rowidx, int64_t start,
                                const int32_t* start_dev, int64_t nnz, const float* d_output, int64_t D,
                                int64_t C, float* d_cache_weight, const int32_t* dup_dev, void* stream) {
+  ApiRange api_range("ttemb_cache_backward_dense");
   int rc = check_cache_args(cache_loc, rowidx, start, nnz, D);
   if (rc) return rc;
   if (C < 0) return fail(TTEMB_E_BADARG, "negative cache rows");
@@ -1040,6 +1099,7 @@ int ttemb_cache_backward_rowwise_adagrad(const int32_t* cache_loc, const int64_t
                                          const int32_t* start_dev, int64_t nnz, const float* d_output,
                                          int64_t D, float lr, float eps, float* cache_state_sum,
                                          float* cache_weight, void* stream) {
+  ApiRange api_range("ttemb_cache_backward_rowwise_adagrad");
   int rc = check_cache_args(cache_loc, rowidx, start, nnz, D);
   if (rc) return rc;
   if (nnz > 0 && (!cache_weight || !d_output || !cache_state_sum)) return fail(TTEMB_E_BADARG, "null buffer");

@@ -11,6 +11,10 @@
  * override (ttemb_set_path), the piece limits (ttemb_set_piece_limits) and the event
  * profiler (ttemb_profile_enable).  A caller that never touches them has none.
  *
+ * Tracing: with TTEMB_ROCTX=1 in the environment every lookup / cache entry point is bracketed by a roctx range
+ * (roctxRangePush / Pop from librocprofiler-sdk-roctx.so or libroctx64.so, looked up at run time), so a
+ * `rocprofv3 --marker-trace --kernel-trace` timeline shows the calls above their kernels.
+ *
  * The workspace: every op leaves the first 40 KB of its workspace alone except the grouped
  * lookup, which keeps a call counter and a few pre-tagged counters there (in DEVICE memory, so
  * that a replayed HIP graph counts on).  Whatever those bytes hold is valid -- a fresh or
