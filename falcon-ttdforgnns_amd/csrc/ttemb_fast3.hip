@@ -154,7 +154,7 @@ constexpr int kSortThreads = 1024;       // decode / spread: one workgroup per s
 #ifndef TTEMB_RANGE_THREADS
 #define TTEMB_RANGE_THREADS 512
 #endif
-constexpr int kRangeThreads = TTEMB_RANGE_THREADS;   // count / place: one workgroup per range of groups
+constexpr int kRangeThreads = TTEMB_RANGE_THREADS;   // place: one workgroup per range of groups
 #ifndef TTEMB_SORT_SLICE
 #define TTEMB_SORT_SLICE 2048
 #endif
