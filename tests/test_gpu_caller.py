@@ -243,3 +243,39 @@ def test_roctx_ranges_do_not_disturb_a_call(tmp_path):
         assert r.returncode == 0, r.stderr[-2000:]
         sums.append(float(r.stdout.strip().splitlines()[-1]))
     assert sums[0] == sums[1]
+
+
+@pytest.mark.parametrize("sparse", [True, False])
+def test_module_call_in_pieces_matches_the_uncut_call(sparse):
+    """The drop-in class on a call that is cut into pieces (diagnostic limits standing in for 2^24 rows / 2 GiB): same
+    rows, and the same cores after the in-backward update (sparse) / the same .grad (dense), as the uncut call."""
+    import ttemb_native as nat
+    from FBTT.tt_embeddings_ops import TTEmbeddingBag
+    torch.manual_seed(9)
+    p, q, r = [125, 140, 140], [4, 5, 5], [16, 16]
+    mk = lambda: TTEmbeddingBag(2449029, 100, r, p, q, sparse=sparse, use_cache=False, weight_dist="normal", learning_rate=0.1)
+    a, b = mk(), mk()
+    for ca, cb in zip(a.tt_cores, b.tt_cores):
+        ca.data.mul_(300.0)
+        cb.data.copy_(ca.data)
+    rng = np.random.default_rng(9)
+    n = 30000
+    ids = torch.tensor(rng.integers(0, 2449029, size=n)).cuda()
+    cuts = np.sort(rng.integers(0, n + 1, size=n - 1))          # ragged bags, some empty
+    offs = torch.tensor(np.concatenate([[0], cuts, [n]])).cuda()
+    d = (torch.rand(n, 100, device="cuda") - 0.5) * 0.05
+    out_a = a(ids, offs)
+    out_a.backward(d)
+    nat.set_piece_limits(5000, 7000)
+    try:
+        out_b = b(ids, offs)
+        out_b.backward(d)
+        torch.cuda.synchronize()
+    finally:
+        nat.set_piece_limits(0, 0)
+    torch.testing.assert_close(out_b, out_a, rtol=1e-5, atol=1e-6)
+    for ca, cb in zip(a.tt_cores, b.tt_cores):
+        if sparse:
+            torch.testing.assert_close(cb.data, ca.data, rtol=1e-4, atol=1e-6)
+        else:
+            torch.testing.assert_close(cb.grad, ca.grad, rtol=1e-4, atol=1e-4 * float(ca.grad.abs().max()))

@@ -17,6 +17,7 @@ FOUR = [([2, 4, 4, 4], [1, 16, 16, 16, 1]), ([4, 2, 4, 4], [1, 16, 16, 16, 1]), 
 seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 nat.set_path(nat.PATH_FAST3)
+shared_ws = nat.Workspace()   # half of the cases share ONE workspace: tables of every shape take turns on its header words
 t_end = time.time() + seconds
 t_note = time.time() + 30.0
 n_cases = n_bad = 0
@@ -56,11 +57,15 @@ while time.time() < t_end:
     cores = [(rng.standard_normal((p[t], R[t] * q[t] * R[t + 1])) * 0.3).astype(np.float32) for t in range(len(p))]
     d_out = ((rng.random((B, D)) - 0.5) * 0.2).astype(np.float32)
     shape = nat.make_shape(p, q, R)
-    ws = nat.Workspace()
+    ws = shared_ws if rng.random() < 0.5 else nat.Workspace()
+    # a third of the cases are cut into pieces (by rows, by ids or both), as a call past one row window would be
+    cut = int(rng.integers(0, 3)) == 0
+    nat.set_piece_limits(int(rng.choice([0, max(1, B // 7), max(1, B // 40)])) if cut else 0,
+                         int(rng.choice([0, max(1, nnz // 9), max(1, nnz // 30)])) if cut else 0)   # at most ~70 pieces
     c = [torch.from_numpy(x).cuda() for x in cores]
     ti, to = torch.from_numpy(idx).cuda(), torch.from_numpy(offsets).cuda()
     out = torch.full((B, D), float("nan"), device="cuda")
-    plan = nat.new_plan(shape, nnz, ti.device)
+    plan = nat.new_plan(shape, nnz, ti.device)   # (None for a call in pieces)
     nat.forward(shape, c, ti, None, to, nnz, None, B, out, ws, plan)
     grads = [torch.full_like(x, float("nan")) for x in c]
     nat.backward_dense(shape, c, ti, None, nnz, None, B, torch.from_numpy(d_out).cuda(), grads, ws, plan, to)
@@ -80,6 +85,6 @@ while time.time() < t_end:
         t_note = time.time() + 30.0
     if not ok:
         n_bad += 1
-        print(f"FAIL case {case}: shape {sh} p {p} nnz {nnz} B {B} mode {mode}", flush=True)
+        print(f"FAIL case {case}: shape {sh} p {p} nnz {nnz} B {B} mode {mode} cut {cut}", flush=True)
 print(f"{n_cases} cases, {n_bad} failures")
 sys.exit(1 if n_bad else 0)
