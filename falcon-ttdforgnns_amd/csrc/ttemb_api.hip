@@ -272,6 +272,127 @@ static Merged4 merge_first_two(const DevShape& s, int64_t nnz, int64_t B, bool p
   return m;
 }
 
+// ---------------------------------------------------------------------------------
+// Ranks off the instantiated list on the grouped path: zero-padded cores.
+// A 3-core table with ranks (r1, r2) IS the table with ranks (R, R), R >= r1, r2, whose cores carry zeros in the added rank
+// positions: every row is the same number for number (the added terms are products with zero), and the gradient with respect
+// to an original entry is the same sum.  So any rank in [2, 256] -- tuning_SAGE.py:213 searches exactly that interval --
+// rides on the grouped MFMA kernels of the next instantiated rank of its q shape (8 / 16 / 32; 64 / 128 / 256 for the wide
+// chain): per call the cores are copied into padded form (a few hundred KB to a few MB: one small launch), the grouped
+// kernels run on the padded table, and the backward keeps the original sub-block of the padded gradient.  The extra flops
+// ((R / r)^2 on the first contraction) are small change next to what the per-bag kernels pay at large batches (no prefix
+// reuse, float atomics per id): rank 12 at 65 536 ids -- 0.48 ms per-bag -- runs like rank 16.
+// ---------------------------------------------------------------------------------
+struct Padded3 {
+  bool on;
+  DevShape sp;               // the padded 3-core shape
+  int64_t core_bytes[3];     // bytes of every padded core, 256-aligned
+  int64_t cores_total;       // their sum
+};
+
+static Padded3 pad_ranks(const DevShape& s, int64_t nnz, int64_t B, bool have_offsets) {
+  Padded3 pd;
+  memset(&pd, 0, sizeof(pd));
+  const int path = current_path();
+  if (s.T != 3 || path == TTEMB_PATH_GENERIC || path == TTEMB_PATH_PER_BAG || fast3_supported(s)) return pd;
+  const int need = s.R[1] > s.R[2] ? s.R[1] : s.R[2];
+  for (int R : {8, 16, 32, 64, 128, 256}) {
+    if (R < need) continue;
+    ttemb_shape_t t;
+    memset(&t, 0, sizeof(t));
+    t.T = 3;
+    for (int k = 0; k < 3; ++k) { t.p[k] = s.p[k]; t.q[k] = s.q[k]; }
+    t.R[0] = 1; t.R[1] = R; t.R[2] = R; t.R[3] = 1;
+    DevShape d;
+    if (make_dev_shape(&t, &d) != TTEMB_OK || !fast3_supported(d)) continue;
+    if (!use_fast3(d, nnz, B, have_offsets)) return pd;   // (a larger rank of the list would pay even later)
+    pd.on = true;
+    pd.sp = d;
+    for (int k = 0; k < 3; ++k) {
+      pd.core_bytes[k] = align256((int64_t)d.p[k] * d.row_len[k] * 4);
+      pd.cores_total += pd.core_bytes[k];
+    }
+    return pd;
+  }
+  return pd;
+}
+
+// dst[row][a][j][b] (ranks Ra x Rb) = src[row][a][j][b] inside the original ranks (ra x rb), 0 outside -- and back
+struct PadJob {
+  const float* src[3];
+  float* dst[3];
+  int p[3], q[3], ra[3], rb[3], Ra[3], Rb[3];
+};
+__global__ __launch_bounds__(256) void pad_cores_kernel(PadJob j) {
+  const int t = blockIdx.y;
+  const long long n = (long long)j.p[t] * j.Ra[t] * j.q[t] * j.Rb[t];
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+    const int b = (int)(e % j.Rb[t]);
+    long long r = e / j.Rb[t];
+    const int jj = (int)(r % j.q[t]);
+    r /= j.q[t];
+    const int a = (int)(r % j.Ra[t]);
+    const long long row = r / j.Ra[t];
+    j.dst[t][e] = (a < j.ra[t] && b < j.rb[t]) ? j.src[t][((row * j.ra[t] + a) * j.q[t] + jj) * j.rb[t] + b] : 0.f;
+  }
+}
+// the original sub-block of a padded gradient: src is padded (Ra x Rb), dst original (ra x rb)
+__global__ __launch_bounds__(256) void unpad_cores_kernel(PadJob j) {
+  const int t = blockIdx.y;
+  const long long n = (long long)j.p[t] * j.ra[t] * j.q[t] * j.rb[t];
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+    const int b = (int)(e % j.rb[t]);
+    long long r = e / j.rb[t];
+    const int jj = (int)(r % j.q[t]);
+    r /= j.q[t];
+    const int a = (int)(r % j.ra[t]);
+    const long long row = r / j.ra[t];
+    j.dst[t][e] = j.src[t][((row * j.Ra[t] + a) * j.q[t] + jj) * j.Rb[t] + b];
+  }
+}
+static PadJob pad_job(const DevShape& s, const Padded3& pd) {
+  PadJob j;
+  memset(&j, 0, sizeof(j));
+  for (int t = 0; t < 3; ++t) {
+    j.p[t] = s.p[t]; j.q[t] = s.q[t];
+    j.ra[t] = s.R[t]; j.rb[t] = s.R[t + 1];
+    j.Ra[t] = pd.sp.R[t]; j.Rb[t] = pd.sp.R[t + 1];
+  }
+  return j;
+}
+// padded copies of the cores at `buf` (pd.cores_total bytes); *cp3 receives their pointers
+static int build_padded_cores(const DevShape& s, const Padded3& pd, const CorePtrs& cp, char* buf, CorePtrs* cp3, hipStream_t st) {
+  PadJob j = pad_job(s, pd);
+  memset(cp3, 0, sizeof(*cp3));
+  int64_t off = 0, most = 0;
+  for (int t = 0; t < 3; ++t) {
+    j.src[t] = cp.c[t];
+    j.dst[t] = reinterpret_cast<float*>(buf + off);
+    cp3->c[t] = j.dst[t];
+    off += pd.core_bytes[t];
+    const int64_t n = (int64_t)pd.sp.p[t] * pd.sp.row_len[t];
+    most = n > most ? n : most;
+  }
+  int64_t blocks = (most + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+  hipLaunchKernelGGL(pad_cores_kernel, dim3((unsigned)blocks, 3), dim3(256), 0, st, j);
+  return check_hip(hipGetLastError(), "pad_cores_kernel");
+}
+static int unpad_grads(const DevShape& s, const Padded3& pd, const CorePtrsMut& padded, const CorePtrsMut& dst, hipStream_t st) {
+  PadJob j = pad_job(s, pd);
+  int64_t most = 0;
+  for (int t = 0; t < 3; ++t) {
+    j.src[t] = padded.c[t];
+    j.dst[t] = dst.c[t];
+    const int64_t n = (int64_t)s.p[t] * s.row_len[t];
+    most = n > most ? n : most;
+  }
+  int64_t blocks = (most + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+  hipLaunchKernelGGL(unpad_cores_kernel, dim3((unsigned)blocks, 3), dim3(256), 0, st, j);
+  return check_hip(hipGetLastError(), "unpad_cores_kernel");
+}
+
 // V[(ia, ib)] = A[ia] (rows x K) . Bm[ib] (K x n): one workgroup per pair
 __global__ __launch_bounds__(256) void merge_pair_kernel(const float* __restrict__ A, const float* __restrict__ Bm, int pb, int rows,
                                                          int K, int n, float* __restrict__ V) {
@@ -563,6 +684,26 @@ static int backward_into(const DevShape& ds, const CorePtrs& cp, const int64_t* 
                        m4.pb, m4.rows, m4.K, m4.n, dst.c[m4.a], dst.c[m4.a + 1]);
     return check_hip(hipGetLastError(), "split_pair_kernel");
   }
+  const Padded3 pd = pad_ranks(ds, nnz, B, offsets != nullptr);
+  if (pd.on) {   // ranks off the list: grouped backward on the padded cores, then the original sub-block of its gradient
+    if (update != nullptr) return fail(TTEMB_E_BADARG, "internal: a padded table writes gradients, the step follows");
+    if (ws == nullptr || ws_bytes < 2 * pd.cores_total) return fail(TTEMB_E_WORKSPACE, "backward needs room for the padded cores");
+    char* wp = reinterpret_cast<char*>(ws);
+    CorePtrs cp3;
+    int rc = build_padded_cores(ds, pd, cp, wp, &cp3, st);
+    if (rc) return rc;
+    CorePtrsMut d3;
+    memset(&d3, 0, sizeof(d3));
+    int64_t off = pd.cores_total;
+    for (int t = 0; t < 3; ++t) {
+      d3.c[t] = reinterpret_cast<float*>(wp + off);
+      off += pd.core_bytes[t];
+    }
+    rc = launch_backward_fast3(pd.sp, cp3, indices, rowidx, offsets, nnz, nnz_dev, B, d_output, d3, wp + 2 * pd.cores_total,
+                               ws_bytes - 2 * pd.cores_total, plan, plan_bytes, st, nullptr, header);
+    if (rc) return rc;
+    return unpad_grads(ds, pd, d3, dst, st);
+  }
   if (current_path() == TTEMB_PATH_FAST3) return fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
   int rc = launch_zero_cores(ds, dst, st);
   if (rc) return rc;
@@ -656,6 +797,11 @@ int64_t ttemb_workspace_bytes(const ttemb_shape_t* shape, int32_t op, int64_t nn
   const bool f3 = use_fast3(ds, op == TTEMB_OP_CACHE_POPULATE ? B : nnz, B);
   const Merged4 m4 = op == TTEMB_OP_CACHE_POPULATE ? Merged4{} : merge_first_two(ds, nnz, B, true);
   // every lookup op's workspace begins with the header the grouped path keeps its few persistent words in
+  const Padded3 pd = (op == TTEMB_OP_CACHE_POPULATE || f3 || m4.on) ? Padded3{} : pad_ranks(ds, nnz, B, true);
+  if (pd.on && op == TTEMB_OP_FORWARD)
+    return kFast3HeaderBytes + align256(nnz * 8) + pd.cores_total + fast3_workspace_bytes(pd.sp, op, nnz, B);
+  if (pd.on && op == TTEMB_OP_BACKWARD)
+    return kFast3HeaderBytes + grad_scratch_bytes(ds) + align256(nnz * 8) + 2 * pd.cores_total + fast3_workspace_bytes(pd.sp, op, nnz, B);
   switch (op) {
     case TTEMB_OP_FORWARD:
       if (m4.on) return kFast3HeaderBytes + align256(nnz * 8) + m4.v_bytes + (m4.per_bag ? 0 : fast3_workspace_bytes(m4.s3, op, nnz, B));
@@ -686,6 +832,8 @@ int ttemb_kernel_family(const ttemb_shape_t* shape, int64_t nnz, int64_t B, int3
   if (use_fast3(ds, nnz, B, ids_with_offsets != 0)) return family3(ds, true);
   const Merged4 m4 = merge_first_two(ds, nnz, B, ids_with_offsets != 0, ids_with_offsets != 0);
   if (m4.on) return family3(m4.s3, !m4.per_bag) | TTEMB_FAMILY_MERGED;
+  const Padded3 pd = pad_ranks(ds, nnz, B, ids_with_offsets != 0);
+  if (pd.on) return family3(pd.sp, true) | TTEMB_FAMILY_PADDED;
   // use_small3 with stand-in pointers: only their null-ness is looked at
   const int64_t* none = nullptr;
   const int64_t* some = reinterpret_cast<const int64_t*>(&ds);
@@ -701,7 +849,9 @@ int64_t ttemb_plan_bytes(const ttemb_shape_t* shape, int64_t nnz) {
   // (a call that runs in pieces keeps no plan -- a plan describes one piece --; neither does a per-bag view)
   if (use_fast3(ds, nnz, 0)) return fast3_fits(ds, nnz, 0) ? fast3_plan_bytes(ds, nnz) : 0;
   const Merged4 m4 = merge_first_two(ds, nnz, 0);
-  return m4.on && fast3_fits(m4.s3, nnz, 0) ? fast3_plan_bytes(m4.s3, nnz) : 0;
+  if (m4.on) return fast3_fits(m4.s3, nnz, 0) ? fast3_plan_bytes(m4.s3, nnz) : 0;
+  const Padded3 pd = pad_ranks(ds, nnz, 0, true);   // ranks off the list: the plan of the padded table
+  return pd.on && fast3_fits(pd.sp, nnz, 0) ? fast3_plan_bytes(pd.sp, nnz) : 0;
 }
 
 }  // extern "C"
@@ -752,6 +902,25 @@ static int forward_phase(int phase, const ttemb_shape_t* shape, const float* con
                                 w4 + head + m4.v_bytes, workspace_bytes - head - m4.v_bytes, plan, plan_bytes, phase, st, header);
   }
   const bool f3 = nnz > 0 && use_fast3(ds, nnz, B, offsets != nullptr);
+  const Padded3 pd = (nnz > 0 && !f3) ? pad_ranks(ds, nnz, B, offsets != nullptr) : Padded3{};
+  if (pd.on) {   // ranks off the instantiated list: the grouped kernels on zero-padded cores; workspace: [row slot | padded cores | grouped]
+    char* wp = reinterpret_cast<char*>(workspace);
+    const int64_t head = align256(nnz * 8);
+    if (wp == nullptr || workspace_bytes < head + pd.cores_total) return fail(TTEMB_E_WORKSPACE, "forward needs room for the padded cores");
+    if (rowidx == nullptr && offsets == nullptr) return fail(TTEMB_E_BADARG, "rowidx and offsets are both null");
+    CorePtrs cp3;
+    memset(&cp3, 0, sizeof(cp3));
+    if (phase != 1) {   // (the id-only half does not read the cores)
+      rc = build_padded_cores(ds, pd, cp, wp + head, &cp3, st);
+      if (rc) return rc;
+    }
+    if (phase != 2 && offsets == nullptr) {
+      rc = launch_zero(output, (size_t)B * ds.D * 4, st, "zero output");
+      if (rc) return rc;
+    }
+    return launch_forward_fast3(pd.sp, cp3, indices, rowidx, offsets, nnz, nnz_dev, B, output, offsets != nullptr,
+                                wp + head + pd.cores_total, workspace_bytes - head - pd.cores_total, plan, plan_bytes, phase, st, header);
+  }
   if (phase == 1 && !f3) return TTEMB_OK;   // the generic kernels have no id-only half: phase 2 is their whole forward
   if (phase == 2 && f3) {
     return launch_forward_fast3(ds, cp, indices, rowidx, offsets, nnz, nnz_dev, B, output, offsets != nullptr, workspace,

@@ -1620,6 +1620,9 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
     // this wavefront's rows of the workgroup's slab: i2 = 8 (q GPW + lane group) + wave, every row of the slab is written by
     // one wavefront (zeros where no id came by); the lane's quad goes back to its place in the [kk][c2] row
     float* tile = plan.g2part + (size_t)blockIdx.x * p2 * C::ROW2;
+#if defined(TTEMB_ABL) && (TTEMB_ABL & 64)   // (ablation 64: the slab rows are not stored -- timing only; the sums stay live)
+    if (nnz == 0xffffffffu)
+#endif
 #pragma unroll
     for (int q = 0; q < FQ; ++q) {
       const uint32_t i2 = (uint32_t)(q * GPW + s_grp) * kFuseWaves + wave;

@@ -239,7 +239,7 @@ def plan_bytes(shape: Shape, nnz: int) -> int:
     return n
 
 
-FAMILY_SCALAR, FAMILY_PER_BAG, FAMILY_PER_BAG_RT, FAMILY_GROUPED, FAMILY_GROUPED_WIDE, FAMILY_MERGED = 0, 1, 2, 3, 4, 16
+FAMILY_SCALAR, FAMILY_PER_BAG, FAMILY_PER_BAG_RT, FAMILY_GROUPED, FAMILY_GROUPED_WIDE, FAMILY_MERGED, FAMILY_PADDED = 0, 1, 2, 3, 4, 16, 32
 
 
 def kernel_family(shape: Shape, nnz: int, B: int, ids_with_offsets: bool = True) -> int:

@@ -116,14 +116,18 @@ int ttemb_set_piece_limits(int64_t rows, int64_t ids);
  *   TTEMB_FAMILY_PER_BAG_RT  the same with run-time (q, ranks): any 3-core shape with q0, q2 <= 16 and q0 q1 <= 64
  *   TTEMB_FAMILY_GROUPED  the grouped chain (ranks <= 32, an instantiated shape)
  *   TTEMB_FAMILY_GROUPED_WIDE  the grouped chain of ranks 64 / 128 / 256
- * | TTEMB_FAMILY_MERGED when a 2- or 4-core table rides on a 3-core view (a virtual core built per call). */
+ * | TTEMB_FAMILY_MERGED when a 2- or 4-core table rides on a 3-core view (a virtual core built per call),
+ * | TTEMB_FAMILY_PADDED when a 3-core table whose ranks are off the instantiated list rides on the grouped kernels of the
+ *   next listed rank through zero-padded copies of its cores (same rows, same gradients: the added rank positions hold
+ *   zeros). */
 enum {
   TTEMB_FAMILY_SCALAR = 0,
   TTEMB_FAMILY_PER_BAG = 1,
   TTEMB_FAMILY_PER_BAG_RT = 2,
   TTEMB_FAMILY_GROUPED = 3,
   TTEMB_FAMILY_GROUPED_WIDE = 4,
-  TTEMB_FAMILY_MERGED = 16
+  TTEMB_FAMILY_MERGED = 16,
+  TTEMB_FAMILY_PADDED = 32
 };
 int ttemb_kernel_family(const ttemb_shape_t* shape, int64_t nnz, int64_t B, int32_t ids_with_offsets);
 

@@ -752,7 +752,7 @@ def _run_ids_offsets(nat, p, q, R, cores, indices, offsets, d_output):
 
 @pytest.mark.parametrize("n_ids", [700, 20000])
 @pytest.mark.parametrize("p,q,r", RT_SHAPES)
-def test_runtime_shape_mfma_kernels(nat, orc, p, q, r, n_ids):
+def test_shapes_off_the_instantiated_list(nat, orc, p, q, r, n_ids):
     """Shapes without a template -- ranks 12 / 24 / 48, q = 2,5,10 / 3,4,8, ranks that are not multiples of 4, a 4-core and
     a 2-core table off the listed shapes -- run the run-time-shape per-bag MFMA kernels at every batch size (the kernel
     family is asked from the library, not assumed) and match the oracle; ragged bags, duplicates, empty bags."""
@@ -762,9 +762,16 @@ def test_runtime_shape_mfma_kernels(nat, orc, p, q, r, n_ids):
     rng = np.random.default_rng(sum(p) + sum(q) + sum(r) + n_ids)
     idx, offsets = _random_bags(rng, int(np.prod(p)), n_ids)
     fam = nat.kernel_family(shape, int(idx.shape[0]), int(offsets.shape[0] - 1), True)
-    assert fam & ~nat.FAMILY_MERGED == nat.FAMILY_PER_BAG_RT, f"kernel family {fam}"
-    assert bool(fam & nat.FAMILY_MERGED) == (T != 3)
-    assert nat.kernel_family(shape, int(idx.shape[0]), int(offsets.shape[0] - 1), False) == nat.FAMILY_SCALAR   # (a row index, no offsets)
+    # past the grouped crossover a 3-core table whose q shape is instantiated at a higher rank rides on the grouped kernels
+    # through zero-padded cores (4,5,5 at 12 -> 16, 24 -> 32, (6, 7) -> 8); everything else runs the run-time-shape kernels
+    padded = T == 3 and tuple(q) == (4, 5, 5) and max(r) <= 32 and idx.shape[0] >= 4096
+    if padded:
+        assert fam == nat.FAMILY_GROUPED | nat.FAMILY_PADDED, f"kernel family {fam}"
+    else:
+        assert fam & ~nat.FAMILY_MERGED == nat.FAMILY_PER_BAG_RT, f"kernel family {fam}"
+        assert bool(fam & nat.FAMILY_MERGED) == (T != 3)
+    assert nat.kernel_family(shape, int(idx.shape[0]), int(offsets.shape[0] - 1), False) in (
+        nat.FAMILY_SCALAR, nat.FAMILY_GROUPED | nat.FAMILY_PADDED)   # (a row index, no offsets: no per-bag kernels)
     cores = [(rng.standard_normal((p[t], R[t] * q[t] * R[t + 1])) * 0.4).astype(np.float32) for t in range(T)]
     want = orc.tt_forward(idx, offsets, cores, p, q, R)
     d_out = ((rng.random(want.shape) - 0.5) * 0.2).astype(np.float32)
@@ -936,3 +943,42 @@ def test_fused_backward_at_the_full_409600_ids_against_the_oracle(nat, orc):
     for t in range(3):
         np.testing.assert_allclose(c[t].cpu().numpy(), cores[t] - np.float32(0.05) * want[t], rtol=0,
                                    atol=1e-5 + 2e-4 * float(np.abs(0.05 * want[t]).max()))
+
+
+@pytest.mark.parametrize("q,r,Rpad", [([4, 5, 5], [12, 12], 16), ([4, 5, 5], [20, 28], 32), ([4, 4, 8], [48, 40], 64),
+                                      ([5, 5, 4], [3, 5], 8), ([5, 5, 4], [100, 100], 128)])
+def test_ranks_off_the_list_ride_on_the_grouped_path(nat, orc, q, r, Rpad):
+    """Any rank in [2, 256] of an instantiated q shape (tuning_SAGE.py:213 searches that interval) runs the grouped MFMA
+    kernels of the next listed rank through zero-padded cores: forward rows, dense gradients (with the forward's plan, as the
+    module reuses it) and the fused SGD step against the oracle on the ORIGINAL cores; unequal ranks, ranks that are not
+    multiples of 4, narrow and wide chains."""
+    p = [40, 50, 60]
+    R = [1] + r + [1]
+    shape = nat.make_shape(p, q, R)
+    rng = np.random.default_rng(sum(r) + Rpad)
+    idx, offsets = _random_bags(rng, int(np.prod(p)), 30000)
+    nnz, B = int(idx.shape[0]), int(offsets.shape[0] - 1)
+    fam = nat.kernel_family(shape, nnz, B, True)
+    want_fam = (nat.FAMILY_GROUPED_WIDE if Rpad >= 64 else nat.FAMILY_GROUPED) | nat.FAMILY_PADDED
+    assert fam == want_fam, f"kernel family {fam}"
+    assert nat.plan_bytes(shape, nnz) > 0
+    cores = [(rng.standard_normal((p[t], R[t] * q[t] * R[t + 1])) * (0.4 if Rpad < 64 else 0.1)).astype(np.float32) for t in range(3)]
+    want = orc.tt_forward(idx, offsets, cores, p, q, R)
+    d_out = ((rng.random(want.shape) - 0.5) * 0.2).astype(np.float32)
+    want_g = orc.tt_dense_backward(idx, offsets, d_out, cores, p, q, R)
+    c = [dev(x) for x in cores]
+    t_idx, t_offs, t_d = dev(idx, torch.int64), dev(offsets, torch.int64), dev(d_out)
+    ws = nat.Workspace()
+    plan = nat.new_plan(shape, nnz, t_idx.device)
+    out = torch.full((B, int(np.prod(q))), float("nan"), device="cuda")
+    nat.forward(shape, c, t_idx, None, t_offs, nnz, None, B, out, ws, plan)
+    grads = [torch.full_like(x, float("nan")) for x in c]
+    nat.backward_dense(shape, c, t_idx, None, nnz, None, B, t_d, grads, ws, plan, t_offs)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(want).max())))
+    assert_grads_close([g.cpu().numpy() for g in grads], want_g, rel=2e-4)
+    nat.backward_sgd(shape, c, t_idx, None, nnz, None, B, t_d, 0.05, ws, plan, t_offs)
+    torch.cuda.synchronize()
+    for t in range(3):
+        np.testing.assert_allclose(c[t].cpu().numpy(), cores[t] - np.float32(0.05) * want_g[t], rtol=0,
+                                   atol=1e-5 + 2e-4 * float(np.abs(0.05 * want_g[t]).max()))
