@@ -353,7 +353,8 @@ __global__ __launch_bounds__(kSortThreads) void fast3_decode_kernel(
     unsigned long long old = atomicAdd(ctr, (unsigned long long)hist[i]);
     uint32_t place = (uint32_t)(old & 0x3ffffffull);
     if ((old & ~0x3ffffffull) != tag) {
-      for (;;) {
+      place = 0;
+      for (int tries = 0; tries < (1 << 16); ++tries) {   // (ends after at most one round per slice of the bank; bounded all the same)
         old = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((old & ~0x3ffffffull) == tag) {
           place = (uint32_t)(atomicAdd(ctr, (unsigned long long)hist[i]) & 0x3ffffffull);
