@@ -385,9 +385,11 @@ def main():
                 with open(os.path.join(ROOT, prof)) as fh:
                     avg = {r["Name"].split("(")[0].replace("void ", "").replace("ttemb::", ""): float(r["AverageNs"]) * 1e-3
                            for r in csv.DictReader(fh)}
+                # (the gather / update kernels are templated on the row's 16-byte pieces per lane: <7> for D = 100)
+                np_ = (D // 4 + 3) // 4
                 rows = hit * N
                 kern = {}
-                for name, bpr in (("cache_forward_kernel", 8 + 4 + 8 * D), ("cache_scatter_add_kernel", 8 + 4 + 12 * D)):
+                for name, bpr in ((f"cache_forward_stream_kernel<{np_}>", 8 + 4 + 8 * D), (f"cache_scatter_add_kernel<{np_}>", 8 + 4 + 12 * D)):
                     if name in avg:
                         gbs = rows * bpr / (avg[name] * 1e-6) / 1e9
                         kern[name] = {"avg_us": round(avg[name], 1), "bytes_per_cached_row": bpr, "gbs": round(gbs, 1),

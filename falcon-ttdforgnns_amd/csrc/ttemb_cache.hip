@@ -454,6 +454,107 @@ __global__ __launch_bounds__(256) void cache_forward_kernel(const int32_t* __res
   }
 }
 
+// The same copy as a STREAM (bag boundaries given, D <= 128): a fixed number of wavefronts per SIMD, each taking steps of 16
+// ids with a stride; the (location, bag) pair of the next step is requested before a step's rows are stored.
+// One wavefront per 32 ids and all of them resident at once (the kernel above) runs the chip in lock step -- every
+// wavefront reads its indices, then every wavefront gathers, then every wavefront stores: 133 MB in 42 us although either
+// stream alone runs at 4-5 TB/s.  Here wavefronts drift apart and the gathers of one overlap the stores of another.
+#ifndef TTEMB_CACHE_WPS
+#define TTEMB_CACHE_WPS 4
+#endif
+constexpr int kStreamWavesPerSimd = TTEMB_CACHE_WPS;
+
+template <int NP>
+struct RowSet {
+  float4 v[NP];
+  int64_t row, o0, o1;
+  bool on;
+};
+
+template <int NP>   // NP = 16-byte pieces of a row per lane (four lanes per row): D <= 16 NP
+__global__ __launch_bounds__(256) void cache_forward_stream_kernel(const int32_t* __restrict__ loc, const int64_t* __restrict__ rowidx,
+                                                                   const int64_t* __restrict__ offsets, int64_t start,
+                                                                   const int32_t* start_dev, int64_t nnz,
+                                                                   const float* __restrict__ weight, int D, float* __restrict__ out) {
+  const int64_t s0 = live_start(start, start_dev, nnz);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b_l = lane >> 2, j_l = lane & 3;
+  const int D4 = D >> 2;
+  const int64_t steps = (nnz - s0 + 15) >> 4, stride = (int64_t)gridDim.x * 4;
+  int64_t step = (int64_t)blockIdx.x * 4 + wave;
+  if (step >= steps) return;
+  struct Idx {
+    int32_t l;
+    int64_t row;
+    bool on;
+  };
+  auto idx_of = [&](int64_t st, Idx& i) {   // past the end: the last id's pair (a valid address), nothing of it is stored
+    const int64_t n = s0 + 16 * st + b_l, last = nnz - 1;
+    i.on = n <= last;   // (st >= steps implies n > last)
+    const int64_t nc = n < last ? n : last;
+    i.l = loc[nc];
+    i.row = rowidx[nc];
+  };
+  auto request = [&](RowSet<NP>& r, const Idx& i) {
+    r.row = i.row;
+    r.on = i.on;
+    r.o0 = offsets[i.row];
+    r.o1 = offsets[i.row + 1];
+    // one address per row: every piece but a lane's last exists (NP = ceil(D4 / 4)) and rides in the immediate offset
+    const float4* w = reinterpret_cast<const float4*>(weight + (int64_t)i.l * D) + j_l;
+#pragma unroll
+    for (int k = 0; k + 1 < NP; ++k) r.v[k] = w[4 * k];
+    r.v[NP - 1] = w[4 * (NP - 1) + j_l < D4 ? 4 * (NP - 1) : D4 - 1 - j_l];
+  };
+  auto emit = [&](const RowSet<NP>& r) {
+    const bool single = r.on && r.o1 - r.o0 == 1;   // the caller's offsets vouch that no TT id shares the row: plain stores
+    float* o = out + r.row * D;
+    if (single) {   // (every piece but a lane's last exists: NP = ceil(D4 / 4))
+#pragma unroll
+      for (int k = 0; k + 1 < NP; ++k) reinterpret_cast<float4*>(o)[4 * k + j_l] = r.v[k];
+      if (4 * (NP - 1) + j_l < D4) reinterpret_cast<float4*>(o)[4 * (NP - 1) + j_l] = r.v[NP - 1];
+    }
+    if (__ballot(r.on && !single) != 0ull) {   // bags of several ids accumulate
+      if (r.on && !single) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+          const int pc = 4 * k + j_l;
+          if (pc < D4) {
+            atomicAdd(&o[4 * pc + 0], r.v[k].x);
+            atomicAdd(&o[4 * pc + 1], r.v[k].y);
+            atomicAdd(&o[4 * pc + 2], r.v[k].z);
+            atomicAdd(&o[4 * pc + 3], r.v[k].w);
+          }
+        }
+      }
+    }
+  };
+  // per step: request the rows | request the pair of the next step | store (waits for the rows, not for the pair).  One
+  // row set: with two the compiler's register sharing made every request wait for the one before anyway, and the
+  // registers are better spent on more wavefronts; the stores of a step are still in flight when the next gather starts.
+  RowSet<NP> r;
+  Idx ia, ib;
+  idx_of(step, ia);
+  for (;;) {
+    request(r, ia);
+    __builtin_amdgcn_sched_barrier(0);
+    idx_of(step + stride, ib);
+    __builtin_amdgcn_sched_barrier(0);
+    emit(r);
+    __builtin_amdgcn_sched_barrier(0);
+    step += stride;
+    if (step >= steps) break;
+    request(r, ib);
+    __builtin_amdgcn_sched_barrier(0);
+    idx_of(step + stride, ia);
+    __builtin_amdgcn_sched_barrier(0);
+    emit(r);
+    __builtin_amdgcn_sched_barrier(0);
+    step += stride;
+    if (step >= steps) break;
+  }
+}
+
 // scale == -lr : cache_backward_sgd ; scale == 1 : cache_backward_dense (target pre-zeroed).
 // Duplicate ids may hit one cache row, so the adds are float atomics -- issued as whole rows of
 // consecutive floats (64 lanes = 256 contiguous bytes per instruction, the full-rate shape).  A wavefront takes
@@ -461,45 +562,97 @@ __global__ __launch_bounds__(256) void cache_forward_kernel(const int32_t* __res
 // requested before the first atomic is issued.
 constexpr int kScatterIds = 8;
 
+template <int NP>   // unique form: 16-byte pieces of a row per lane and pass (four lanes per row)
 __global__ __launch_bounds__(256) void cache_scatter_add_kernel(const int32_t* __restrict__ loc,
                                                                 const int64_t* __restrict__ rowidx,
                                                                 int64_t start, const int32_t* start_dev,
                                                                 int64_t nnz,
                                                                 const float* __restrict__ grad, int D,
                                                                 float scale, float* __restrict__ target,
-                                                                const int32_t* __restrict__ unique_dev) {
+                                                                const int32_t* __restrict__ unique_dev, int stream_blocks) {
   const int64_t s0 = live_start(start, start_dev, nnz);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (unique_dev != nullptr && *unique_dev == 0) {
     // no cache row occurs twice in this call (ttemb_preprocess checked): every row has one writer, so the update is a
-    // plain read-modify-write, four lanes per row with all pieces in flight, 32 ids per wavefront like the forward
+    // plain read-modify-write, four lanes per row.  A stream like cache_forward_stream_kernel's: `stream_blocks`
+    // workgroups take steps of 16 ids with a stride; the rest of the grid (sized for the atomic form below) leaves.
+    if ((int)blockIdx.x >= stream_blocks) return;
     const int b_l = lane >> 2, j_l = lane & 3;
     const int D4 = D >> 2;
-    const int64_t first_u = s0 + ((int64_t)blockIdx.x * 4 + wave) * kIdsPerWave;
+    const int64_t steps = (nnz - s0 + 15) >> 4, stride = (int64_t)stream_blocks * 4;
+    int64_t step = (int64_t)blockIdx.x * 4 + wave;
+    if (step >= steps) return;
+    // (NP pieces per lane and pass: D <= 16 NP in one pass, wider rows in several)
+    struct Pair {
+      float4 g[NP], t[NP];
+      float4* tp;
+      bool on;
+    };
+    struct Idx {
+      int32_t l;
+      int64_t row;
+      bool on;
+    };
+    auto idx_of = [&](int64_t st, Idx& i) {
+      const int64_t n = s0 + 16 * st + b_l, last = nnz - 1;
+      i.on = n <= last;   // (st >= steps implies n > last)
+      const int64_t nc = n < last ? n : last;
+      i.l = loc[nc];
+      i.row = rowidx[nc];
+    };
+    for (int base = 0; base < D4; base += 4 * NP) {
+      auto request = [&](Pair& r, const Idx& i) {
+        // one address per row and table: pieces that exist ride in the immediate offset, the others re-read the row's last
+        const float4* g = reinterpret_cast<const float4*>(grad + i.row * D) + base + j_l;
+        r.tp = reinterpret_cast<float4*>(target + (int64_t)i.l * D);
+        const float4* t = r.tp + base + j_l;
+        r.on = i.on;
+        const int left = D4 - 1 - base - j_l;   // the last piece of the row, counted from this lane's first
 #pragma unroll
-    for (int c = 0; c < kIdsPerWave / 16; ++c) {
-      const int64_t n = first_u + 16 * c + b_l;
-      if (n >= nnz) continue;
-      const float4* g = reinterpret_cast<const float4*>(grad + rowidx[n] * D);
-      float4* t = reinterpret_cast<float4*>(target + (int64_t)loc[n] * D);
-      for (int base = 0; base < D4; base += 32) {
-        float4 gv[8], tv[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int pc = base + 4 * k + j_l;
-          if (pc < D4) {
-            gv[k] = g[pc];
-            tv[k] = t[pc];
+        for (int k = 0; k < NP; ++k) {
+          if (base + 4 * k + 3 < D4) {   // (every lane has it: uniform)
+            r.g[k] = g[4 * k];
+            r.t[k] = t[4 * k];
+          } else {
+            r.g[k] = g[4 * k <= left ? 4 * k : left];
+            r.t[k] = t[4 * k <= left ? 4 * k : left];
           }
         }
+      };
+      auto emit = [&](Pair& r) {
+        if (r.on) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int pc = base + 4 * k + j_l;
-          if (pc < D4) {
-            tv[k].x += gv[k].x * scale; tv[k].y += gv[k].y * scale; tv[k].z += gv[k].z * scale; tv[k].w += gv[k].w * scale;
-            t[pc] = tv[k];
+          for (int k = 0; k < NP; ++k) {
+            const int pc = base + 4 * k + j_l;
+            if (pc < D4) {
+              float4 x = r.t[k];
+              x.x += r.g[k].x * scale; x.y += r.g[k].y * scale; x.z += r.g[k].z * scale; x.w += r.g[k].w * scale;
+              r.tp[pc] = x;
+            }
           }
         }
+      };
+      Pair r;
+      Idx ia, ib;
+      int64_t st = step;
+      idx_of(st, ia);
+      for (;;) {
+        request(r, ia);
+        __builtin_amdgcn_sched_barrier(0);
+        idx_of(st + stride, ib);
+        __builtin_amdgcn_sched_barrier(0);
+        emit(r);
+        __builtin_amdgcn_sched_barrier(0);
+        st += stride;
+        if (st >= steps) break;
+        request(r, ib);
+        __builtin_amdgcn_sched_barrier(0);
+        idx_of(st + stride, ia);
+        __builtin_amdgcn_sched_barrier(0);
+        emit(r);
+        __builtin_amdgcn_sched_barrier(0);
+        st += stride;
+        if (st >= steps) break;
       }
     }
     return;
@@ -571,11 +724,40 @@ static inline unsigned wave_blocks(int64_t nnz) { return (unsigned)((nnz + 3) / 
 static inline unsigned multi_blocks(int64_t nnz) { return (unsigned)((nnz + 4 * kIdsPerWave - 1) / (4 * kIdsPerWave)); }
 static inline unsigned scatter_blocks(int64_t nnz) { return (unsigned)((nnz + 4 * kScatterIds - 1) / (4 * kScatterIds)); }
 
+static unsigned stream_blocks_for(int64_t span) {   // four wavefronts per workgroup, kStreamWavesPerSimd per SIMD, no more than steps
+  const int64_t steps = (span + 15) / 16;
+  int64_t blocks = (int64_t)device_cus() * kStreamWavesPerSimd;
+  if (blocks * 4 > steps) blocks = (steps + 3) / 4;
+  return (unsigned)(blocks < 1 ? 1 : blocks);
+}
+
 int launch_cache_forward(const int32_t* loc, const int64_t* rowidx, const int64_t* offsets, int64_t start,
                          const int32_t* start_dev, int64_t nnz, const float* weight, int64_t D,
                          float* out, hipStream_t st) {
   const int64_t span = start_dev ? nnz : nnz - start;
   if (span <= 0) return TTEMB_OK;
+  if (offsets != nullptr && D <= 128) {   // the pipelined copy (the cached range may turn out shorter than `span`: fewer steps)
+    const dim3 grid(stream_blocks_for(span));
+    const int np = (int)((D / 4 + 3) / 4);   // pieces per lane
+#define TTEMB_FWD_STREAM(NP)                                                                                                   \
+  case NP:                                                                                                                     \
+    hipLaunchKernelGGL(cache_forward_stream_kernel<NP>, grid, dim3(256), 0, st, loc, rowidx, offsets, start, start_dev, nnz, \
+                       weight, (int)D, out);                                                                                   \
+    break;
+    switch (np) {
+      TTEMB_FWD_STREAM(1)
+      TTEMB_FWD_STREAM(2)
+      TTEMB_FWD_STREAM(3)
+      TTEMB_FWD_STREAM(4)
+      TTEMB_FWD_STREAM(5)
+      TTEMB_FWD_STREAM(6)
+      TTEMB_FWD_STREAM(7)
+      default:
+      TTEMB_FWD_STREAM(8)
+    }
+#undef TTEMB_FWD_STREAM
+    return check_hip(hipGetLastError(), "cache_forward_stream_kernel");
+  }
   hipLaunchKernelGGL(cache_forward_kernel, dim3(multi_blocks(span)), dim3(256), 0, st, loc, rowidx, offsets,
                      start, start_dev, nnz, weight, (int)D, out);
   return check_hip(hipGetLastError(), "cache_forward_kernel");
@@ -586,8 +768,26 @@ int launch_cache_scatter_add(const int32_t* loc, const int64_t* rowidx, int64_t 
                              float scale, float* target, const int32_t* unique_dev, hipStream_t st) {
   const int64_t span = start_dev ? nnz : nnz - start;
   if (span <= 0) return TTEMB_OK;
-  hipLaunchKernelGGL(cache_scatter_add_kernel, dim3(scatter_blocks(span)), dim3(256), 0, st, loc, rowidx,
-                     start, start_dev, nnz, grad, (int)D, scale, target, unique_dev);
+  unsigned blocks = scatter_blocks(span), sb = stream_blocks_for(span);
+  if (sb > blocks) blocks = sb;
+  const int np = D >= 128 ? 8 : (int)((D / 4 + 3) / 4);
+#define TTEMB_SCATTER(NP)                                                                                              \
+  case NP:                                                                                                             \
+    hipLaunchKernelGGL(cache_scatter_add_kernel<NP>, dim3(blocks), dim3(256), 0, st, loc, rowidx, start, start_dev, nnz, \
+                       grad, (int)D, scale, target, unique_dev, (int)sb);                                              \
+    break;
+  switch (np) {
+    TTEMB_SCATTER(1)
+    TTEMB_SCATTER(2)
+    TTEMB_SCATTER(3)
+    TTEMB_SCATTER(4)
+    TTEMB_SCATTER(5)
+    TTEMB_SCATTER(6)
+    TTEMB_SCATTER(7)
+    default:
+    TTEMB_SCATTER(8)
+  }
+#undef TTEMB_SCATTER
   return check_hip(hipGetLastError(), "cache_scatter_add_kernel");
 }
 

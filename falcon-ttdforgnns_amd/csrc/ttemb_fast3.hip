@@ -221,6 +221,9 @@ struct GroupPlan {           // device pointers into the caller's plan buffer / 
   uint32_t* epi_live;        // [slices][p1] sparse form only: 1 when the slice of that i1 holds an id (its slab exists)
   uint32_t* wrows;           // wide-rank chain: [p1][stride] the rows (i0, a) of every i1 whose group holds an id (wide3_rows_kernel)
   uint32_t* wnrows;          // [p1] their number
+#ifdef TTEMB_X8
+  uint32_t* g2x;             // [p2][2][ROW2] the last core split into bf16 planes (ttemb_x8.inc), rebuilt by every forward
+#endif
 };
 
 __device__ __forceinline__ uint64_t pack_count(uint32_t c) {   // ids in the low word, chunks of <= kChunk ids in the high word
@@ -848,14 +851,8 @@ __global__ __launch_bounds__(kChainWaves * 64) void fast3_forward_kernel(const f
 
   // Pipeline of one wavefront (k = the chunk being multiplied):
   //     multiply chunk k out of LDS, rows -> LDS -> registers | G2 rows of k+1: registers -> LDS | offsets of k+2 from
-  //     its (i2, row) pairs | store the rows of k | load the G2 rows (and P) of k+2 | load the pairs of k+3
+  //     its i2 | store the rows of k | load the G2 rows (and P) of k+2 | load the i2 of k+3 and the output rows of k+1
   // Stores are issued only after everything the next steps wait for has been consumed, so no wait sits behind a store.
-  auto fetch_meta = [&](const uint4& d, uint32_t& i2, uint32_t& val) {
-    const uint32_t len = d.z & 0xffu;   // lanes past the chunk's length read 0: G2 row 0 stands in, nothing of theirs is stored
-    const uint32_t at = uniform(d.x), bytes = uniform(len * 4u);   // (loop-carried words may sit in vector registers)
-    i2 = buf_load1u(make_rsrc(plan.i2s + at, bytes), 4u * (uint32_t)b_l);
-    val = buf_load1u(make_rsrc(plan.vals + at, bytes), 4u * (uint32_t)b_l);
-  };
   float4 pre_g[NLG], pre_p[NLP];
   auto request = [&](uint32_t row, const uint4& d) {   // row: byte offset of the lane's G2 row
 #pragma unroll
@@ -887,23 +884,33 @@ __global__ __launch_bounds__(kChainWaves * 64) void fast3_forward_kernel(const f
     }
   };
 
-  // ---- prologue: chunk 0 into LDS, rows of chunk 1 and the pairs of chunk 2 in flight ----
+  // ---- prologue: chunk 0 into LDS, rows of chunk 1 and the i2 of chunk 2 in flight, descriptors three chunks ahead ----
+  // Nothing a step requests outlives the next step: i2 of chunk c+3 and the output rows of chunk c+1 are requested at the end
+  // of step c and consumed in step c+1.  (With (i2, row) pairs requested two chunks ahead the row word lived two steps, the
+  // rotation of its registers copied a freshly loaded value, and that copy -- s_waitcnt vmcnt(0) at the top of every step --
+  // drained the loads the step before had just issued; a descriptor loaded and used in the same step was a second wait.)
+  auto fetch_i2 = [&](const uint4& d) {   // lanes past the chunk's length read 0: G2 row 0 stands in, nothing of theirs is stored
+    return buf_load1u(make_rsrc(plan.i2s + uniform(d.x), uniform((d.z & 0xffu) * 4u)), 4u * (uint32_t)b_l);
+  };
+  auto fetch_val = [&](const uint4& d) {
+    return buf_load1u(make_rsrc(plan.vals + uniform(d.x), uniform((d.z & 0xffu) * 4u)), 4u * (uint32_t)b_l);
+  };
   uint4 d_cur = load_desc(ctab, c0, c1);
   uint4 d_nxt = load_desc(ctab, c0 + 1, c1);   // past c1: an empty chunk
   uint4 d_nn = load_desc(ctab, c0 + 2, c1);
-  uint32_t i2_a, val_cur, i2_b, val_nxt;
-  fetch_meta(d_cur, i2_a, val_cur);
-  fetch_meta(d_nxt, i2_b, val_nxt);
-  {   // a share may begin inside a group: its first chunk needs P whatever its flags say
-    uint4 d0 = d_cur;
+  uint4 d_n3 = load_desc(ctab, c0 + 3, c1);
+  uint32_t i2_nn, val_cur;
+  {
+    const uint32_t i2_a = fetch_i2(d_cur), i2_b = fetch_i2(d_nxt);
+    uint4 d0 = d_cur;   // a share may begin inside a group: its first chunk needs P whatever its flags say
     d0.z |= kFirstBit;
     request(__umul24(i2_a, (uint32_t)(C::ROW2 * 4)), d0);   // i2 < p2 <= 4096
+    stage(true);
+    __builtin_amdgcn_sched_barrier(0);
+    request(__umul24(i2_b, (uint32_t)(C::ROW2 * 4)), d_nxt);
   }
-  stage(true);
-  __builtin_amdgcn_sched_barrier(0);
-  request(__umul24(i2_b, (uint32_t)(C::ROW2 * 4)), d_nxt);
-  uint32_t i2_nn, val_nn;
-  fetch_meta(d_nn, i2_nn, val_nn);
+  i2_nn = fetch_i2(d_nn);
+  val_cur = fetch_val(d_cur);
 
   for (uint32_t c = c0;; ++c) {
     const uint32_t len = d_cur.z & 0xffu;
@@ -975,7 +982,7 @@ __global__ __launch_bounds__(kChainWaves * 64) void fast3_forward_kernel(const f
     //      pair here, in front of the stores: behind them its wait would cover every store as well) ----
     stage((d_nxt.z & kFirstBit) != 0u);
     const uint32_t row_nn = __umul24(i2_nn, (uint32_t)(C::ROW2 * 4));
-    asm volatile("" ::"v"(row_nn), "v"(val_nxt));
+    asm volatile("" ::"v"(row_nn));
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- 16-byte global stores, four lanes per row: no load is waited for behind these stores ----
@@ -1003,16 +1010,20 @@ __global__ __launch_bounds__(kChainWaves * 64) void fast3_forward_kernel(const f
       }
     }
     if (c + 1 >= c1) break;
-    // ---- loads of the chunk after next, pairs of the one after that ----
+    // ---- loads of the chunk after next, i2 of the one after that, output rows of the next ----
     request(row_nn, d_nn);
+    i2_nn = fetch_i2(d_n3);
+    val_cur = fetch_val(d_nxt);
     d_cur = d_nxt;
     d_nxt = d_nn;
-    val_cur = val_nxt;
-    val_nxt = val_nn;
-    d_nn = load_desc(ctab, c + 3, c1);
-    fetch_meta(d_nn, i2_nn, val_nn);
+    d_nn = d_n3;
+    d_n3 = load_desc(ctab, c + 4, c1);
   }
 }
+
+#ifdef TTEMB_X8   // experiment (slower: see the header of the file): the forward on the bf16 matrix pipe, fp32 operands split three ways
+#include "ttemb_x8.inc"
+#endif
 
 // ---------------------------------------------------------------------------------
 // backward, atomics-free formulation (four kernels)
@@ -2271,6 +2282,12 @@ static bool shared_slab(const DevShape& s) { return (int64_t)s.p[2] * s.row_len[
 #define TTEMB_FWD_WGS 4
 #endif
 constexpr int kBwdWgsPerCu = TTEMB_BWD_WGS, kFwdWgsPerCu = TTEMB_FWD_WGS;
+#ifdef TTEMB_X8
+#ifndef TTEMB_X8_WGS
+#define TTEMB_X8_WGS 2
+#endif
+constexpr int kX8WgsPerCu = TTEMB_X8_WGS;   // what the kernel's registers allow (__launch_bounds__ in ttemb_x8.inc)
+#endif
 static int chain_cus() { return device_cus(); }
 static int chain_grid(const void* kernel, size_t lds, int wgs_per_cu, LdsGate* gate, unsigned* grid) {
   int rc = allow_big_lds(kernel, lds, gate, "chain kernel");
@@ -2397,6 +2414,12 @@ static int64_t carve_workspace(const DevShape& s, int64_t nnz, bool bwd, bool pl
       pl->rpub = rp;
     }
   }
+#ifdef TTEMB_X8
+  {   // the split last core of the bf16 forward (ttemb_x8.inc)
+    uint32_t* gx = (uint32_t*)take((int64_t)s.p[2] * s.row_len[2] * 8);
+    if (pl) pl->g2x = gx;
+  }
+#endif
   if (wide(s)) {   // the lists of non-empty rows the compacted GEMMs walk (rebuilt from the plan's counts by every call)
     uint32_t* wr = (uint32_t*)take((int64_t)s.p[1] * wide_rows_stride(s) * 4);
     uint32_t* wn = (uint32_t*)take((int64_t)s.p[1] * 4);
@@ -2594,12 +2617,39 @@ template <int Q0, int Q1, int Q2, int R1, int R2>
 static int run_forward_direct(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int64_t nnz, int64_t B,
                               float* output, hipStream_t st);
 
+#ifdef TTEMB_X8
+static bool x8_enabled() {   // experiment switch: TTEMB_X8=1 takes the split-bf16 forward (ttemb_x8.inc)
+  static const bool on = [] { const char* e = getenv("TTEMB_X8"); return e != nullptr && e[0] == '1'; }();
+  return on;
+}
+#endif
+
 template <int Q0, int Q1, int Q2, int R1, int R2>
 static int run_forward(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int64_t nnz, int64_t B,
                        float* output, hipStream_t st) {
   using C = Cfg<Q0, Q1, Q2, R1, R2>;
 #ifdef TTEMB_FWD_DIRECT   // experiment: the LDS-free forward of the wide ranks on a narrow-rank shape (slower there, see ttemb_wide3.inc)
   if constexpr (DirectCfg<Q0, Q1, Q2, R1, R2>::ok) return run_forward_direct<Q0, Q1, Q2, R1, R2>(s, cores, plan, nnz, B, output, st);
+#endif
+#ifdef TTEMB_X8
+  if constexpr (X8Cfg<Q0, Q1, Q2, R1, R2>::ok) {
+    if (x8_enabled()) {
+      using X = X8Cfg<Q0, Q1, Q2, R1, R2>;
+      const size_t lds8 = (size_t)kChainWaves * X::WAVE_DW * sizeof(float);
+      static LdsGate lds8_ok;
+      unsigned grid8 = 0;
+      int rc8 = chain_grid(reinterpret_cast<const void*>(fast3_forward_x8_kernel<Q0, Q1, Q2, R1, R2>), lds8, kX8WgsPerCu, &lds8_ok, &grid8);
+      if (rc8) return rc8;
+      const unsigned elems = (unsigned)(s.p[2] * s.row_len[2]);
+      hipLaunchKernelGGL(x8_split_g2_kernel, dim3((elems + 255u) / 256u), dim3(256), 0, st, cores.c[2], (uint32_t)s.p[2], (uint32_t)Q2,
+                         (uint32_t)R2, plan.g2x);
+      profile_begin(0, st);
+      hipLaunchKernelGGL((fast3_forward_x8_kernel<Q0, Q1, Q2, R1, R2>), dim3(grid8), dim3(kChainWaves * 64), lds8, st, plan,
+                         (uint32_t)num_groups(s), (uint32_t)s.p[2], (uint32_t)nnz, output, (uint32_t)(B * s.D * 4));
+      profile_end(0, st);
+      return check_hip(hipGetLastError(), "fast3_forward_x8_kernel");
+    }
+  }
 #endif
   const size_t lds = (size_t)kChainWaves * C::WAVE_FLOATS * sizeof(float);
   static LdsGate lds_ok;
