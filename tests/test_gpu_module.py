@@ -888,6 +888,58 @@ def test_cache_live_step_with_and_without_the_fused_probe_pass(ops):
         np.testing.assert_array_equal(a.cache_freq.cpu().numpy()[both], b.cache_freq.cpu().numpy()[both])
 
 
+@pytest.mark.parametrize("D", [4, 12, 16, 36, 100, 128, 256])
+@pytest.mark.parametrize("unique", [True, False])
+def test_cache_gather_and_update_kernels_over_row_widths(orc, D, unique):
+    """ttemb_cache_forward / _backward_sgd / _backward_dense at the C ABI against the oracle, for row widths that take every
+    instantiation of the streamed kernels (1-8 sixteen-byte pieces per lane; D = 256: the general forward, the update in
+    two passes): a cached range that starts inside the list and is no multiple of a 16-id step, bags of one id (plain
+    stores) and of several (accumulating), cache rows that repeat (atomic update) or not (read-modify-write)."""
+    import ttemb_native as nat
+    rng = np.random.default_rng(100 + D + (1 if unique else 0))
+    C, B = 5000, 3001
+    lens = rng.choice([1, 1, 1, 2, 3], size=B)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    nnz = int(offs[-1])
+    rowidx = np.repeat(np.arange(B), lens).astype(np.int64)
+    start = nnz // 3 + 5                                  # the cached ids are the tail of the partitioned list
+    start += 1 if (nnz - start) % 16 == 0 else 0          # (never a whole number of 16-id steps)
+    n_c = nnz - start
+    loc = np.full(nnz, -1, dtype=np.int32)
+    loc[start:] = rng.choice(C, size=n_c, replace=not unique).astype(np.int32)
+    # the partition keeps the TT ids in front: their rows are whatever, the cached tail's rows are a shuffled subset of the bags
+    rows_tail = rng.permutation(rowidx)[:n_c] if not unique else rng.permutation(rowidx)[:n_c]
+    rowidx_p = rowidx.copy()
+    rowidx_p[start:] = np.sort(rows_tail)[::-1]           # (CUB order: the rejected items fill the tail backwards)
+    w = rng.standard_normal((C, D)).astype(np.float32)
+    out0 = rng.standard_normal((B, D)).astype(np.float32)
+    dev = lambda a: torch.tensor(a).cuda()
+    t_loc, t_row, t_off, t_w = dev(loc), dev(rowidx_p), dev(offs), dev(w)
+    # forward: rows of one-id bags are overwritten (the caller's offsets vouch nothing else writes them), the others accumulate
+    single = lens[rowidx_p[start:]] == 1
+    want = out0.copy()
+    seen_single = np.zeros(B, dtype=bool)
+    seen_single[rowidx_p[start:][single]] = True
+    want[seen_single] = 0.0
+    orc.cache_forward(want, loc[start:], rowidx_p[start:], w)
+    t_out = dev(out0)
+    nat.cache_forward(t_loc, t_row, start, None, nnz, t_w, t_out, offsets=t_off)
+    np.testing.assert_allclose(t_out.cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+    # the same with the start of the cached range on the device (the module's form)
+    t_out2 = dev(out0)
+    nat.cache_forward(t_loc, t_row, 0, torch.tensor([start], dtype=torch.int32).cuda(), nnz, t_w, t_out2, offsets=t_off)
+    np.testing.assert_allclose(t_out2.cpu().numpy(), want, rtol=1e-5, atol=1e-5)   # (atomic sums: not bit-equal to the first call)
+    # backward: dense gradient and the SGD step, with the "no cache row repeats" word as the preprocess pass would leave it
+    d_out = rng.standard_normal((B, D)).astype(np.float32)
+    dup = torch.tensor([n_c, 0 if unique else 1], dtype=torch.int32).cuda()
+    g = torch.empty(C, D, dtype=torch.float32, device="cuda")
+    nat.cache_backward_dense(t_loc, t_row, start, None, nnz, dev(d_out), g, dup_dev=dup[1:])
+    np.testing.assert_allclose(g.cpu().numpy(), orc.cache_backward_dense(d_out, loc[start:], rowidx_p[start:], C, D), rtol=1e-5, atol=1e-5)
+    t_w2 = dev(w)
+    nat.cache_backward_sgd(t_loc, t_row, start, None, nnz, dev(d_out), 0.05, t_w2, dup_dev=dup[1:])
+    np.testing.assert_allclose(t_w2.cpu().numpy(), orc.cache_backward_sgd(d_out, loc[start:], rowidx_p[start:], 0.05, w), rtol=1e-5, atol=1e-5)
+
+
 def test_capture_guards(ops):
     """A captured lookup refuses to run once what it baked in no longer holds: a cache gone live, a changed eps, re-allocated
     cores; during warm-up it keeps the LFU statistics going."""
