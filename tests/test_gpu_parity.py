@@ -552,6 +552,48 @@ def test_wide_rank_chain_on_frontiers_that_leave_groups_empty(nat, orc, shape, k
         nat.set_path(nat.PATH_AUTO)
 
 
+@pytest.mark.parametrize("shape", [(5, 5, 4, 128, 128), (4, 4, 8, 256, 256)])
+def test_wide_rank_gemms_keep_fp32_accuracy(nat, shape):
+    """The GEMMs of the wide-rank chain carry their fp32 products on the bf16 matrix pipe (operands split into three
+    bf16 planes, eight of nine partial products, ttemb_wide3.inc).  Against a float64 restatement the forward and the
+    dense gradients must be as close as fp32 arithmetic is -- a few 1e-7 of the largest value, where a two-plane split
+    would sit at 1e-5 and plain bf16 at 1e-3."""
+    q, R = list(shape[:3]), [1, shape[3], shape[4], 1]
+    rng = np.random.default_rng(4242 + sum(shape))
+    p = [13, 5, 40]
+    cores = [(rng.standard_normal((p[t], R[t] * q[t] * R[t + 1])) * (0.3 if t != 1 else 0.05)).astype(np.float32) for t in range(3)]
+    n = int(np.prod(p))
+    idx = rng.integers(0, n, size=3000).astype(np.int64)
+    offsets = np.arange(idx.size + 1, dtype=np.int64)
+    c64 = [c.astype(np.float64) for c in cores]
+    i0, i1, i2 = idx // (p[1] * p[2]), (idx // p[2]) % p[1], idx % p[2]
+    a = c64[0][i0].reshape(-1, q[0], R[1])
+    b = c64[1][i1].reshape(-1, R[1], q[1], R[2])
+    c = c64[2][i2].reshape(-1, R[2], q[2])
+    pre = np.einsum("nar,nrbs->nabs", a, b)
+    want = np.einsum("nabs,nsc->nabc", pre, c).reshape(idx.size, -1)
+    nat.set_path(nat.PATH_FAST3)
+    try:
+        out, _ = run_forward(nat, p, q, R, cores, idx, offsets)
+        err = float(np.abs(out.astype(np.float64) - want).max()) / float(np.abs(want).max())
+        assert err < 2e-6, err
+        d_out = ((rng.random(want.shape) - 0.5) * 0.2).astype(np.float32)
+        grads = run_backward_dense(nat, p, q, R, cores, idx, offsets, d_out)
+        d64 = d_out.astype(np.float64).reshape(idx.size, q[0], q[1], q[2])
+        g2 = np.zeros_like(c64[2])
+        np.add.at(g2, i2, np.einsum("nabs,nabc->nsc", pre, d64).reshape(idx.size, -1))
+        dpre = np.einsum("nabc,nsc->nabs", d64, c)
+        g1 = np.zeros_like(c64[1])
+        np.add.at(g1, i1, np.einsum("nar,nabs->nrbs", a, dpre).reshape(idx.size, -1))
+        g0 = np.zeros_like(c64[0])
+        np.add.at(g0, i0, np.einsum("nabs,nrbs->nar", dpre, b).reshape(idx.size, -1))
+        for got, ref in zip(grads, (g0, g1, g2)):
+            e = float(np.abs(got.astype(np.float64) - ref).max()) / float(np.abs(ref).max())
+            assert e < 5e-6, e
+    finally:
+        nat.set_path(nat.PATH_AUTO)
+
+
 @pytest.mark.parametrize("name", [n for n in RANK_CASES if any(f"r{r}" in n for r in (64, 128, 256))])
 def test_rank_sweep_golden_on_the_wide_rank_chain(nat, name):
     """The rank 64 / 128 / 256 points of the reference's rank sweep, forced onto the grouped wide-rank chain, against the
