@@ -113,6 +113,111 @@ def matrix_leg(nat, name, n_ids, dist_kind, iters=50):
     return r
 
 
+def papers_roofline_leg(nat, n_ids=819200, iters=20):
+    """BASELINE.json configs[4]'s table on ONE GPU (p = 500,560,400, q = 8,4,4, ranks 32,32; SURVEY.md section 8d cfg-E):
+    the chain is priced against the fp32 MFMA peak (141.8 flop/B nominal, far past the ridge).  Kernel times are HIP-event
+    brackets inside the library (live); HBM traffic and MFMA-busy come from committed counter passes of the same workload."""
+    p, q, ranks, n_emb = SHAPES["papers100M_r32"]
+    R = [1] + ranks + [1]
+    Dp = int(np.prod(q))
+    rng = np.random.default_rng(5)
+    ids = rng.choice(n_emb, size=n_ids, replace=False).astype(np.int64)
+    groups = int(np.unique(ids // p[2]).shape[0])   # (i0, i1) prefixes the frontier touches: P is formed once per group
+    f0 = 2 * q[0] * ranks[0] * q[1] * ranks[1]
+    f1 = 2 * q[0] * q[1] * ranks[1] * q[2]
+    shape = nat.make_shape(p, q, R)
+    cores = [torch.from_numpy((rng.standard_normal((p[t], R[t] * q[t] * R[t + 1])) * 0.05).astype(np.float32)).cuda() for t in range(3)]
+    idx, offs = torch.from_numpy(ids).cuda(), torch.arange(n_ids + 1, dtype=torch.int64, device="cuda")
+    out = torch.empty(n_ids, Dp, device="cuda")
+    d_out = (torch.rand(n_ids, Dp, device="cuda") - 0.5) * 0.1
+    ws, plan = nat.Workspace(), nat.new_plan(shape, n_ids, idx.device)
+    t = {k: [] for k in ("group", "fwd", "bwd", "chunk", "epi", "fin")}
+    for it in range(iters + 3):
+        if it == 3:
+            nat.profile_enable(True)
+        nat.forward(shape, cores, idx, None, offs, n_ids, None, n_ids, out, ws, plan)
+        nat.backward_sgd(shape, cores, idx, None, n_ids, None, n_ids, d_out, 1e-12, ws, plan, offs)
+        if it >= 3:
+            for k, slot in (("group", 3), ("fwd", 0), ("bwd", 1), ("chunk", 2), ("epi", 8), ("fin", 9)):
+                t[k].append(nat.profile_read(slot))
+    nat.profile_enable(False)
+    torch.cuda.synchronize()
+    m = {k: float(np.median(v)) for k, v in t.items()}   # ms
+    fwd_ms, bwd_ms = m["group"] + m["fwd"], m["bwd"]
+    nominal_f, nominal_b = n_ids * (f0 + f1), n_ids * (3 * f0 + 2 * f1)
+    executed_f = groups * f0 + n_ids * f1                 # P once per group
+    executed_b = groups * 2 * f0 + n_ids * 2 * f1         # dG0 / dG1 products per group, dP / E per id (P is the forward's)
+    tfl = lambda fl, ms: fl / (ms * 1e-3) / 1e12
+    r = {"bound": "mfma", "workload": "papers100M r32 (p = 500,560,400 q = 8,4,4), %d unique uniform ids on one GPU, fwd + fused-SGD bwd at the C ABI" % n_ids,
+         "groups_touched": groups, "ids_per_group": round(n_ids / groups, 2),
+         "kernel_ms": {k: round(v, 4) for k, v in m.items()},
+         "fwd_ms_incl_grouping": round(fwd_ms, 4), "bwd_ms": round(bwd_ms, 4),
+         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+         "fwd_nominal_tflops": round(tfl(nominal_f, fwd_ms), 2), "fwd_executed_tflops": round(tfl(executed_f, fwd_ms), 2),
+         "bwd_nominal_tflops": round(tfl(nominal_b, bwd_ms), 2), "bwd_executed_tflops": round(tfl(executed_b, bwd_ms), 2),
+         "achieved": round(tfl(executed_f + executed_b, fwd_ms + bwd_ms), 2),
+         "frac": round(tfl(executed_f + executed_b, fwd_ms + bwd_ms) / PEAK_F32_MFMA_TFLOPS, 4),
+         "frac_nominal": round(tfl(nominal_f + nominal_b, fwd_ms + bwd_ms) / PEAK_F32_MFMA_TFLOPS, 4),
+         "algorithmic_hbm_bytes": n_ids * 2 * (8 + 4 * Dp)}
+    for key, src in (("traffic", "profiles/r04_papers_traffic.json"), ("mfma_busy", "profiles/r04_papers_mfma_util.json")):
+        try:
+            with open(os.path.join(ROOT, src)) as fh:
+                kern = json.load(fh)["kernels"]
+            r[key] = {k: (v["hbm_bytes"] if key == "traffic" else v["mfma_util"]) for k, v in kern.items()}
+            r[key + "_source"] = src
+        except (OSError, KeyError, ValueError):
+            r[key] = None
+    return r
+
+
+def ref_papers_invocation_leg(n_ids=819200, steps=12):
+    """The reference's own papers100M run (run_script.sh:408-431): p = 400,500,600, q = 4,4,8, ranks 16,16, --sparse,
+    --use-cached --cache-size 5 (gnn_model.py:98-100: 5 % of the nodes cached, hash table of num_nodes slots), batch 4096.
+    One step = forward + backward with the fused update through the class with the cache LIVE; frontiers are 200-id
+    windows with Zipf-distributed starts (cfg-C's generator) so that the cache has something to hit."""
+    from FBTT.tt_embeddings_ops import TTEmbeddingBag
+    p, q, r, n_emb, Dp = [400, 500, 600], [4, 4, 8], [16, 16], 111059956, 128
+    rng = np.random.default_rng(9)
+    n_win = n_emb // 200
+    hot_win = rng.choice(n_win, size=40000, replace=False)   # 8 M ids' worth of recurring windows
+
+    def frontier():
+        k = n_ids // 200
+        st = np.concatenate([rng.choice(hot_win, size=k // 2, replace=False), rng.choice(n_win, size=k - k // 2, replace=False)])
+        st = np.unique(st)
+        return torch.from_numpy((st[:, None] * 200 + np.arange(200)[None, :]).reshape(-1).astype(np.int64)).cuda()
+
+    emb = TTEmbeddingBag(n_emb, Dp, r, p, q, sparse=True, use_cache=True, cache_size=int(0.05 * n_emb), hashtbl_size=n_emb,
+                         weight_dist="normal", learning_rate=0.01, batch_count=14000)
+    for _ in range(8):
+        emb.update_cache(frontier())
+    emb.cache_populate()
+    test = [frontier() for _ in range(4)]
+    keys = emb.hashtbl[emb.cache_state >= 0]
+    hit = float(np.mean([float(torch.isin(b, keys).float().mean()) for b in test[:2]]))
+    del keys
+    times = []
+    for i in range(steps + 3):
+        b = test[i % len(test)]
+        offs = torch.arange(b.numel() + 1, dtype=torch.int64, device="cuda")
+        d = torch.full((b.numel(), Dp), 1e-3, device="cuda")
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        emb(b, offs).backward(d)
+        torch.cuda.synchronize()
+        if i >= 3:
+            times.append(time.perf_counter() - t1)
+    dt = float(np.median(times))
+    n = int(np.mean([b.numel() for b in test]))
+    res = {"what": "run_script.sh:408-431 (final-papers): p = 400,500,600 q = 4,4,8 ranks 16,16, sparse, LFU cache 5 % live; "
+                   "fwd + bwd + fused update through the class, host-timed per step (sync on both sides)",
+           "ids": n, "ms_per_step": round(dt * 1e3, 4), "lookups_per_s": round(n / dt, 1), "hit_rate": round(hit, 3),
+           "cache_rows": int(emb.cache_weight.shape[0]), "hash_slots": int(emb.hashtbl.numel())}
+    del emb
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -212,13 +317,15 @@ def main():
     # fp32-MFMA ridge (157.3 TF / 8 TB/s = 19.7): it is priced against HBM.
     # Every rank runs these steps (they contain the collective); rank 0 reports its own kernel times.
     nat.profile_enable(True)
-    fwd_ms, bwd_ms, chunk_ms, group_ms = [], [], [], []
+    fwd_ms, bwd_ms, chunk_ms, group_ms, epi_ms, fin_ms = [], [], [], [], [], []
     for i in range(10):
         step(i)
         fwd_ms.append(nat.profile_read(0))
         bwd_ms.append(nat.profile_read(1))
         chunk_ms.append(nat.profile_read(2))
         group_ms.append(nat.profile_read(3))
+        epi_ms.append(nat.profile_read(8))
+        fin_ms.append(nat.profile_read(9))
     nat.profile_enable(False)
     fence()
 
@@ -234,7 +341,7 @@ def main():
         achieved = N * row_bytes / (dom_ms * 1e-3) / 1e9
         # HBM bytes per launch of that kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read from
         # inside the process): NOT measured by this run -- the files are named in the line -- valid for the default workload
-        traffic_src, busy_src = "profiles/r03_traffic.json", "profiles/r03_mfma_util.json"
+        traffic_src, busy_src = "profiles/r04_traffic.json", "profiles/r04_mfma_util.json"
         traffic = None
         try:
             if N == 409600 and args.path == "auto":
@@ -264,6 +371,7 @@ def main():
                     "traffic_gbs": None if traffic is None else round(traffic / (dom_ms * 1e-3) / 1e9, 1),
                     "fwd_kernel_ms": round(fwd, 4), "bwd_chunk_kernel_ms": round(chunk, 4),
                     "bwd_chain_ms": round(bwd, 4), "grouping_ms": round(group, 4),
+                    "bwd_epilogue_kernel_ms": round(float(np.mean(epi_ms)), 4), "bwd_finalize_kernel_ms": round(float(np.mean(fin_ms)), 4),
                     # chain level, nominal flops (executed flops are lower: P is formed once per group)
                     "fwd_chain_nominal_tflops": round(tf(FWD_FLOPS, fwd + group), 3),
                     "fwd_chain_mfma_frac": round(tf(FWD_FLOPS, fwd + group) / PEAK_F32_MFMA_TFLOPS, 4),
@@ -334,6 +442,34 @@ def main():
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t1) / 20
             local = {"ids": N, "ms_per_step": round(dt * 1e3, 4), "lookups_per_s": round(N / dt, 1)}
+        # The step N > 1 runs, on ONE GPU: dense gradients straight into the flat bucket, TTDataParallel.step (no collective at
+        # world 1), one fused SGD launch over the flat weights -- so that a multi-GPU value divides by a like-for-like
+        # single-GPU one (the headline N = 1 line is the fused in-backward update: a different step)
+        dp1 = None
+        if world == 1 and not args.no_extras:
+            emb_d = TTEmbeddingBag(N_EMB, D, RANKS, P, Q, sparse=False, use_cache=False, weight_dist="normal",
+                                   learning_rate=0.01, batch_count=N)
+            dp_d = TTDataParallel(emb_d)
+
+            def dstep(i):
+                emb_d(id_sets[i % n_sets], offsets).backward(d_out)
+                dp_d.step(overlap=True)
+
+            for i in range(10):
+                dstep(i)
+            dp_d.flush()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(100):
+                dstep(i)
+            dp_d.flush()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / 100
+            dp1 = {"ids": N, "ms_per_step": round(dt * 1e3, 4), "lookups_per_s": round(N / dt, 1),
+                   "what": "the data-parallel step at world size 1: sparse=False, gradients into the bucket, "
+                           "TTDataParallel.step(overlap=True), fused SGD over the flat weights, no collective; "
+                           "the like-for-like N = 1 for `--gpus N` values (which run this step plus one all-reduce)"}
+            del dp_d, emb_d
         # BASELINE.json configs[2]: the same step with the LFU row cache live (10 % of the rows cached, frontiers of
         # 200-id windows whose starts follow a Zipf law so that hot regions recur -- SURVEY.md §8d cfg-C), after a
         # counting epoch and cache_populate(); the hit rate is reported next to the step time
@@ -376,31 +512,29 @@ def main():
             torch.cuda.synchronize()
             dt_off = (time.perf_counter() - t1) / len(test)
             cached["cache_off_same_frontiers_ms"] = round(dt_off * 1e3, 4)
-            # HBM-bound gather / update kernels of the cached rows, from the committed rocprofv3 summary of the same workload
-            # (tools/cache_bench.py under tools/prof_cache.sh): algorithmic bytes per cached row -- forward 8 + 4 + 4 D read +
-            # 4 D written = 812 B, backward 8 + 4 + 4 D gradient + 4 D row read + 4 D written = 1 212 B -- over the kernel time
-            prof = "profiles/r03_cache_kernel_stats.csv"
-            try:
-                import csv
-                with open(os.path.join(ROOT, prof)) as fh:
-                    avg = {r["Name"].split("(")[0].replace("void ", "").replace("ttemb::", ""): float(r["AverageNs"]) * 1e-3
-                           for r in csv.DictReader(fh)}
-                # (the gather / update kernels are templated on the row's 16-byte pieces per lane: <7> for D = 100)
-                np_ = (D // 4 + 3) // 4
-                rows = hit * N
-                kern = {}
-                for name, bpr in ((f"cache_forward_stream_kernel<{np_}>", 8 + 4 + 8 * D), (f"cache_scatter_add_kernel<{np_}>", 8 + 4 + 12 * D)):
-                    if name in avg:
-                        gbs = rows * bpr / (avg[name] * 1e-6) / 1e9
-                        kern[name] = {"avg_us": round(avg[name], 1), "bytes_per_cached_row": bpr, "gbs": round(gbs, 1),
-                                      "frac_of_hbm_peak": round(gbs / PEAK_HBM_GBS, 3)}
-                for name in ("cache_lookup_kernel<true>", "partition_scatter_kernel"):
-                    if name in avg:
-                        kern[name] = {"avg_us": round(avg[name], 1), "what": "per id of the batch, cached or not"}
-                cached["kernels"] = kern
-                cached["kernels_source"] = prof
-            except (OSError, KeyError, ValueError):
-                pass
+            # HBM-bound gather / update kernels of the cached rows and the two kernels every id pays, timed LIVE (HIP-event
+            # brackets inside the library, profile slots 4-7) over the same frontiers.  Algorithmic bytes per cached row:
+            # forward 8 + 4 + 4 D read + 4 D written = 812 B, backward 8 + 4 + 4 D gradient + 4 D row read + 4 D written = 1 212 B
+            nat.profile_enable(True)
+            kt = {4: [], 5: [], 6: [], 7: []}
+            hits = []
+            for b in test[:12]:
+                cemb(b, offsets).backward(d_out)
+                for slot in kt:
+                    kt[slot].append(nat.profile_read(slot))
+                hits.append(float(torch.isin(b, keys).float().mean()))
+            nat.profile_enable(False)
+            rows = float(np.mean(hits)) * N
+            kern = {}
+            for slot, name, bpr in ((6, "cached_row_gather", 8 + 4 + 8 * D), (7, "cached_row_update", 8 + 4 + 12 * D)):
+                us = float(np.median(kt[slot])) * 1e3
+                gbs = rows * bpr / (us * 1e-6) / 1e9
+                kern[name] = {"avg_us": round(us, 1), "bytes_per_cached_row": bpr, "gbs": round(gbs, 1),
+                              "frac_of_hbm_peak": round(gbs / PEAK_HBM_GBS, 3)}
+            for slot, name in ((4, "probe_pass_with_lfu_update"), (5, "partition_scatter")):
+                kern[name] = {"avg_us": round(float(np.median(kt[slot])) * 1e3, 1), "what": "per id of the batch, cached or not"}
+            cached["kernels"] = kern
+            cached["kernels_source"] = "live: HIP events around the kernels in this run (ttemb_profile_read slots 4-7), 12 steps"
             # A cached row moves 2 024 B of HBM traffic per step (forward + update) and takes one more probe than a TT row,
             # whose marginal cost on this hardware is lower (the TT step grows by ~0.34 ns per id, the cached rows' two
             # kernels cost ~0.56 ns per row at the 3.1-3.6 TB/s random 400-byte rows sustain): no hit rate pays for the cache
@@ -468,7 +602,11 @@ def main():
                       "papers100M_r32_819200": matrix_leg(nat, "papers100M_r32", 819200, "uniform", iters=20),
                       "papers100M_r32_4096": matrix_leg(nat, "papers100M_r32", 4096, "uniform"),
                       "arxiv_r8_full_graph": matrix_leg(nat, "arxiv_r8", 169343, "arange"),
-                      "arxiv_r8_256": matrix_leg(nat, "arxiv_r8", 256, "uniform")}
+                      "arxiv_r8_256": matrix_leg(nat, "arxiv_r8", 256, "uniform"),
+                      "papers100M_ref_q448_r16_cache5_819200": ref_papers_invocation_leg()}
+        papers = None
+        if world == 1 and not args.no_extras:
+            papers = papers_roofline_leg(nat)
         sweep = None
         if world == 1 and not args.no_extras:
             sweep = {"how": "products table (p = 125,140,140), 409600 unique uniform ids, C-ABI calls as in `matrix`, median of 10"}
@@ -485,8 +623,8 @@ def main():
                                    "2048-seed batch = 409600 unique uniform ids per GPU, bag length 1",
                        "p": P, "q": Q, "tt_ranks": RANKS, "num_embeddings": N_EMB, "ids_per_gpu_step": N,
                        "parallelism": f"dp{world}", "kernel_path": args.path},
-            "dist": dist_info, "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_2048": cpu2048, "matrix": matrix, "rank_sweep": sweep, "batch2048_step": small, "metis_like_step": local,
-            "cache_on_step": cached, "sage_epoch": epoch,
+            "dist": dist_info, "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_2048": cpu2048, "matrix": matrix, "papers_roofline": papers, "rank_sweep": sweep, "batch2048_step": small, "metis_like_step": local,
+            "dp_mode_1gpu": dp1, "cache_on_step": cached, "sage_epoch": epoch,
         }
     if world > 1:
         dist.barrier()

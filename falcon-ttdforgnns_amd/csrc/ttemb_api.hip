@@ -58,9 +58,61 @@ int device_cus() {
 
 int current_path() { return g_path.load(); }
 
+// ---- device-side faults (a bounded wait of the grouping pass that ran out: report_fault in ttemb_fast3.hip) ----
+// One pinned, device-visible host word per process, allocated at the first grouped lookup that is not being captured and
+// never freed (its address is baked into captured graphs).  The kernel that gives up stores its reason there; every lookup
+// entry point looks at it first (a plain host read, no synchronisation), so the fault surfaces as TTEMB_E_HIP on the next
+// call the host makes after the store has landed -- at the latest on the one after a synchronisation -- and is then
+// cleared.  The results of the faulted call itself are NaN (poisoned plan), whether or not anyone asks.
+static std::atomic<uint32_t*> g_fault_host{nullptr};
+static std::atomic<uint32_t*> g_fault_dev{nullptr};
+static std::atomic<int> g_fault_state{0};   // 0 = not tried, 1 = being set up, 2 = ready, 3 = not available
+
+uint32_t* fault_word(hipStream_t st) {
+  int state = g_fault_state.load(std::memory_order_acquire);
+  if (state == 2) return g_fault_dev.load(std::memory_order_relaxed);
+  if (state == 3) return nullptr;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+    (void)hipGetLastError();
+    return nullptr;   // no allocation during a capture; this graph reports through its NaN results only
+  }
+  int expect = 0;
+  if (!g_fault_state.compare_exchange_strong(expect, 1)) return nullptr;   // another thread is setting it up: this call goes without
+  void* host = nullptr;
+  void* dev = nullptr;
+  if (hipHostMalloc(&host, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess || host == nullptr ||
+      hipHostGetDevicePointer(&dev, host, 0) != hipSuccess || dev == nullptr) {
+    (void)hipGetLastError();
+    g_fault_state.store(3, std::memory_order_release);
+    return nullptr;
+  }
+  memset(host, 0, 64);
+  g_fault_host.store(reinterpret_cast<uint32_t*>(host), std::memory_order_relaxed);
+  g_fault_dev.store(reinterpret_cast<uint32_t*>(dev), std::memory_order_relaxed);
+  g_fault_state.store(2, std::memory_order_release);
+  return reinterpret_cast<uint32_t*>(dev);
+}
+
+int pending_device_fault() {
+  if (g_fault_state.load(std::memory_order_acquire) != 2) return TTEMB_OK;
+  volatile uint32_t* w = g_fault_host.load(std::memory_order_relaxed);
+  const uint32_t code = *w;
+  if (code == 0u) return TTEMB_OK;
+  *w = 0u;
+  return fail(TTEMB_E_HIP,
+              "an earlier grouped lookup gave up waiting on the device (%s): the rows / gradients of that call are NaN, "
+              "not wrong numbers.  The GPU is shared or throttled beyond what the grouping pass tolerates; rerun the step",
+              code == 1u ? "range counter take-over in the decode step" : "look-back of the place step");
+}
+
 static std::atomic<bool> g_prof_on{false};
-static hipEvent_t g_prof_ev[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
-static std::atomic<bool> g_prof_valid[4] = {{false}, {false}, {false}, {false}};
+// slots: 0 forward chain kernel | 1 all backward chain kernels | 2 backward chunk kernel | 3 grouping pass (+ prefix products) |
+//        4 cache probe pass (lookup, + LFU update when fused) | 5 partition scatter | 6 cached-row gather | 7 cached-row update |
+//        8 group epilogue kernel | 9 finalize kernel
+constexpr int kProfSlots = 10;
+static hipEvent_t g_prof_ev[kProfSlots][2] = {};
+static std::atomic<bool> g_prof_valid[kProfSlots] = {};
 
 void profile_begin(int which, hipStream_t st) {
   if (!g_prof_on) return;
@@ -773,13 +825,20 @@ int ttemb_set_piece_limits(int64_t rows, int64_t ids) {
   return TTEMB_OK;
 }
 
+int ttemb_set_spin_limit(int64_t tries) {
+  fast3_set_spin_limit(tries);
+  return TTEMB_OK;
+}
+
+int ttemb_status(void) { return pending_device_fault(); }
+
 int ttemb_profile_enable(int32_t on) {
   g_prof_on.store(on != 0);
   return TTEMB_OK;
 }
 
 int ttemb_profile_read(int32_t which, float* ms_host) {
-  if (which < 0 || which > 3 || ms_host == nullptr) return fail(TTEMB_E_BADARG, "bad profile slot");
+  if (which < 0 || which >= kProfSlots || ms_host == nullptr) return fail(TTEMB_E_BADARG, "bad profile slot");
   if (!g_prof_valid[which]) return fail(TTEMB_E_BADARG, "no profiled launch recorded for slot %d", which);
   int rc = check_hip(hipEventSynchronize(g_prof_ev[which][1]), "hipEventSynchronize");
   if (rc) return rc;
@@ -862,7 +921,9 @@ static int forward_phase(int phase, const ttemb_shape_t* shape, const float* con
                          const int32_t* nnz_dev, int64_t B, float* output, void* workspace,
                          int64_t workspace_bytes, void* plan, int64_t plan_bytes, void* stream) {
   DevShape ds;
-  int rc = make_dev_shape(shape, &ds);
+  int rc = pending_device_fault();
+  if (rc) return rc;
+  rc = make_dev_shape(shape, &ds);
   if (rc) return rc;
   rc = check_lookup_args(cores, indices, nnz, B);
   if (rc) return rc;
@@ -987,7 +1048,9 @@ int ttemb_backward_dense(const ttemb_shape_t* shape, const float* const* cores,
                          const void* plan, int64_t plan_bytes, void* stream) {
   ApiRange api_range("ttemb_backward_dense");
   DevShape ds;
-  int rc = make_dev_shape(shape, &ds);
+  int rc = pending_device_fault();
+  if (rc) return rc;
+  rc = make_dev_shape(shape, &ds);
   if (rc) return rc;
   rc = check_lookup_args(cores, indices, nnz, B);
   if (rc) return rc;
@@ -1022,7 +1085,9 @@ static int fused_backward(const ttemb_shape_t* shape, float* const* cores, float
                           void* workspace, int64_t workspace_bytes, const void* plan, int64_t plan_bytes,
                           void* stream) {
   DevShape ds;
-  int rc = make_dev_shape(shape, &ds);
+  int rc = pending_device_fault();
+  if (rc) return rc;
+  rc = make_dev_shape(shape, &ds);
   if (rc) return rc;
   rc = check_lookup_args(cores, indices, nnz, B);
   if (rc) return rc;

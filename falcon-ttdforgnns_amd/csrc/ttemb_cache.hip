@@ -355,16 +355,20 @@ int launch_partition(const int64_t* indices, const int64_t* offsets, int64_t nnz
   base += align256(nnz * 4);
   int32_t* blockcnt = reinterpret_cast<int32_t*>(base);
   const int64_t blocks = part_blocks(nnz);
+  profile_begin(4, st);
   if (freq != nullptr)   // the LFU update of the same ids rides in the probe pass
     hipLaunchKernelGGL(cache_lookup_kernel<true>, dim3((unsigned)blocks), dim3(kPartThreads), 0, st, indices, nnz,
                        hashtbl, freq, state, (uint32_t)H, loc, blockcnt, dup_stamp, nnz_tt_dev);
   else
     hipLaunchKernelGGL(cache_lookup_kernel<false>, dim3((unsigned)blocks), dim3(kPartThreads), 0, st, indices, nnz,
                        hashtbl, freq, state, (uint32_t)H, loc, blockcnt, dup_stamp, nnz_tt_dev);
+  profile_end(4, st);
   int rc = check_hip(hipGetLastError(), "cache_lookup_kernel");
   if (rc) return rc;
+  profile_begin(5, st);
   hipLaunchKernelGGL(partition_scatter_kernel, dim3((unsigned)blocks), dim3(kPartThreads), 0, st, nnz, B, offsets,
                      blockcnt, indices, loc, indices_out, rowidx_out, loc_out, nnz_tt_dev, dup_stamp);
+  profile_end(5, st);
   return check_hip(hipGetLastError(), "partition_scatter_kernel");
 }
 
@@ -739,6 +743,7 @@ int launch_cache_forward(const int32_t* loc, const int64_t* rowidx, const int64_
   if (offsets != nullptr && D <= 128) {   // the pipelined copy (the cached range may turn out shorter than `span`: fewer steps)
     const dim3 grid(stream_blocks_for(span));
     const int np = (int)((D / 4 + 3) / 4);   // pieces per lane
+    profile_begin(6, st);
 #define TTEMB_FWD_STREAM(NP)                                                                                                   \
   case NP:                                                                                                                     \
     hipLaunchKernelGGL(cache_forward_stream_kernel<NP>, grid, dim3(256), 0, st, loc, rowidx, offsets, start, start_dev, nnz, \
@@ -756,6 +761,7 @@ int launch_cache_forward(const int32_t* loc, const int64_t* rowidx, const int64_
       TTEMB_FWD_STREAM(8)
     }
 #undef TTEMB_FWD_STREAM
+    profile_end(6, st);
     return check_hip(hipGetLastError(), "cache_forward_stream_kernel");
   }
   hipLaunchKernelGGL(cache_forward_kernel, dim3(multi_blocks(span)), dim3(256), 0, st, loc, rowidx, offsets,
@@ -771,6 +777,7 @@ int launch_cache_scatter_add(const int32_t* loc, const int64_t* rowidx, int64_t 
   unsigned blocks = scatter_blocks(span), sb = stream_blocks_for(span);
   if (sb > blocks) blocks = sb;
   const int np = D >= 128 ? 8 : (int)((D / 4 + 3) / 4);
+  profile_begin(7, st);
 #define TTEMB_SCATTER(NP)                                                                                              \
   case NP:                                                                                                             \
     hipLaunchKernelGGL(cache_scatter_add_kernel<NP>, dim3(blocks), dim3(256), 0, st, loc, rowidx, start, start_dev, nnz, \
@@ -788,6 +795,7 @@ int launch_cache_scatter_add(const int32_t* loc, const int64_t* rowidx, int64_t 
     TTEMB_SCATTER(8)
   }
 #undef TTEMB_SCATTER
+  profile_end(7, st);
   return check_hip(hipGetLastError(), "cache_scatter_add_kernel");
 }
 

@@ -71,6 +71,12 @@ bool fast3_pays(const DevShape& s, int64_t nnz);
 bool fast3_fits(const DevShape& s, int64_t nnz, int64_t B);   // the call fits one 32-bit row window / one grouping pass
 bool fast3_fits_in_pieces(const DevShape& s, int64_t nnz, int64_t B);   // ... or runs as several pieces (needs `offsets`)
 void fast3_set_piece_limits(int64_t rows, int64_t ids);                  // diagnostic: smaller pieces than the hardware's
+void fast3_set_spin_limit(int64_t tries);                                // diagnostic: tries of the grouping pass's bounded waits
+// The pinned host word a device-side wait that ran out reports to (ttemb_api.hip): its device address for the kernels
+// (null when it cannot be had: no such memory, or a stream that is being captured before the first eager call), and the
+// host-side check every lookup entry point starts with -- TTEMB_E_HIP once per reported fault.
+uint32_t* fault_word(hipStream_t st);
+int pending_device_fault();
 int64_t fast3_workspace_bytes(const DevShape& s, int32_t op, int64_t nnz, int64_t B);
 int64_t fast3_plan_bytes(const DevShape& s, int64_t nnz);
 // phase: 0 = whole forward, 1 = id-only half (grouping into `plan`), 2 = lookup on a plan grouped by phase 1.

@@ -209,8 +209,8 @@ struct GroupPlan {           // device pointers into the caller's plan buffer / 
   uint32_t* i2s;             // [nnz] grouped: last index digit of the id
   uint32_t* vals;            // [nnz] grouped: output row | kMultiBit
   uint32_t* counts;          // [G+1] ids per group; entry G = number of groups that hold an id
-  uint64_t* gpre;            // [G+1] low word: first grouped position of the group; high word: its first chunk.
-                             //       entry G = (live ids, chunks)
+  uint64_t* gpre;            // [G+3] low word: first grouped position of the group; high word: its first chunk.
+                             //       entry G = (live ids, chunks), G+1 = the plan's tag, G+2 = its fault word (plan_poisoned)
   uint4* ctab;               // [max_chunks] chunk descriptors
   float* ptab;               // [G][M2*R2] prefix product P = G0[i0] . G1[i1] of every non-empty group
   float* etab;               // [nnz][ROW2] dG2 contribution rows, in grouped order
@@ -221,10 +221,48 @@ struct GroupPlan {           // device pointers into the caller's plan buffer / 
   uint32_t* epi_live;        // [slices][p1] sparse form only: 1 when the slice of that i1 holds an id (its slab exists)
   uint32_t* wrows;           // wide-rank chain: [p1][stride] the rows (i0, a) of every i1 whose group holds an id (wide3_rows_kernel)
   uint32_t* wnrows;          // [p1] their number
-#ifdef TTEMB_X8
-  uint32_t* g2x;             // [p2][2][ROW2] the last core split into bf16 planes (ttemb_x8.inc), rebuilt by every forward
-#endif
+  uint32_t* fault_host;      // pinned host word (device address) a bounded wait that ran out reports to, or null
+  uint32_t spin_limit;       // tries of the bounded waits of the grouping pass (ttemb_set_spin_limit; 0 = none: every wait expires)
 };
+
+// ---------------------------------------------------------------------------------
+// A bounded wait that runs out must not become plausible numbers (the reference checks its launches with AT_CUDA_CHECK,
+// tt_embeddings_cuda.cu:1666,1742,1845; its kernels cannot time out, this grouping pass can).  Two words behind the plan's
+// group table: gpre[G + 1] = the TAG of the call that built the plan (written by the place step with the chunk total),
+// gpre[G + 2] = (tag | reason) of a wait that expired while it was built.  A plan whose two tags agree is POISONED: every
+// kernel that would walk its chunk table leaves instead, the forward fills the output window with NaN, the finalize kernel
+// emits NaN for every gradient element (fused modes: NaN weights) -- and the pinned host word makes the next API call of
+// the process return TTEMB_E_HIP (ttemb_status() asks for it directly).  Tags carry the call's number with the top bit set,
+// like every word of the grouping pass: what a recycled buffer held never reads as a fault.
+// ---------------------------------------------------------------------------------
+constexpr uint32_t kFaultTakeOver = 1u, kFaultLookBack = 2u;
+__device__ __forceinline__ uint64_t plan_tag(uint64_t call) { return ((call & ((1ull << 39) - 1ull)) | (1ull << 39)) << 24; }
+__device__ __forceinline__ void report_fault(const GroupPlan& plan, uint32_t G, uint64_t call, uint32_t code) {
+  __hip_atomic_store(&plan.gpre[G + 2u], plan_tag(call) | code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (plan.fault_host != nullptr) __hip_atomic_store(plan.fault_host, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// wave-uniform (scalar loads next to the chunk total every chain kernel reads first)
+__device__ __forceinline__ bool plan_poisoned(const GroupPlan& plan, uint32_t G) {
+  const desc_ptr w = (desc_ptr)plan.gpre;
+  const uint32_t t_lo = w[2u * G + 2u], t_hi = w[2u * G + 3u], f_lo = w[2u * G + 4u], f_hi = w[2u * G + 5u];
+  return t_hi == f_hi && ((t_lo ^ f_lo) >> 24) == 0u && (t_hi >> 31) != 0u;
+}
+
+// The forward of a poisoned plan: the call's whole output window reads NaN (every wavefront of the grid takes a strided
+// share; the buffer descriptor clips).  `gw` of `nwaves` wavefronts.
+__device__ __forceinline__ void poison_output(const GroupPlan& plan, float* out, uint32_t out_bytes, uint32_t row_floats, uint32_t gw,
+                                              uint32_t nwaves, int lane) {
+  if (plan.piece != nullptr) {
+    out += plan.piece->rowbase * (long long)row_floats;
+    out_bytes = (uint32_t)plan.piece->window_bytes;
+  }
+  const rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)out_bytes, 0x00020000);
+  const uint32_t qnan = 0x7fc00000u;
+  u32x4 v;
+  v.x = v.y = v.z = v.w = qnan;
+  for (uint64_t off = ((uint64_t)gw * 64u + (uint32_t)lane) * 16u; off < out_bytes; off += (uint64_t)nwaves * 1024u)
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)(uint32_t)off, 0, 0);
+}
 
 __device__ __forceinline__ uint64_t pack_count(uint32_t c) {   // ids in the low word, chunks of <= kChunk ids in the high word
   return (uint64_t)c | ((uint64_t)((c + kChunk - 1) / kChunk) << 32);
@@ -357,17 +395,21 @@ __global__ __launch_bounds__(kSortThreads) void fast3_decode_kernel(
     uint32_t place = (uint32_t)(old & 0x3ffffffull);
     if ((old & ~0x3ffffffull) != tag) {
       place = 0;
-      for (int tries = 0; tries < (1 << 16); ++tries) {   // (ends after at most one round per slice of the bank; bounded all the same)
+      bool taken = false;
+      for (uint32_t tries = 0; tries < plan.spin_limit; ++tries) {   // (ends after at most one round per slice of the bank; bounded all the same)
         old = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((old & ~0x3ffffffull) == tag) {
           place = (uint32_t)(atomicAdd(ctr, (unsigned long long)hist[i]) & 0x3ffffffull);
+          taken = true;
           break;
         }
         if (atomicCAS(ctr, old, tag | hist[i]) == old) {
           place = 0;   // the first slice of this call in the range
+          taken = true;
           break;
         }
       }
+      if (!taken) report_fault(plan, p0 * p1, plan.epochs[0] + 1ull, kFaultTakeOver);   // the slice has no place: the plan is poisoned
     }
     dst[i] = place;
   }
@@ -451,7 +493,8 @@ __global__ __launch_bounds__(kSortThreads) void fast3_spread_kernel(uint32_t nnz
 //      place launch cost ~5 us + the launch gap; a look-back BEFORE the scatter waited for the slowest histogram);
 //   4. chunk descriptors and group starts, one thread per group (a chunk's descriptor depends on its group's numbers only).
 // Workgroups are dispatched in index order and wait only for lower indices, so the wait cannot starve what it waits for;
-// it is bounded all the same (a wait that runs out leaves a wrong chunk table, never a hung device).
+// it is bounded all the same: a wait that runs out poisons the plan and reports (report_fault) -- never a hung device, never
+// a plausible wrong table.
 constexpr uint64_t kEpochMask = (1ull << 40) - 1ull;
 static_assert(kMaxRanges <= kRangeThreads, "the look-back reads one published word per thread");
 __device__ __forceinline__ void place_range(const uint32_t range, const uint32_t ranges, uint32_t G, uint32_t shift,
@@ -529,14 +572,18 @@ __device__ __forceinline__ void place_range(const uint32_t range, const uint32_t
   if (threadIdx.x < range) {
     const bool want_live = range == ranges - 1;
     uint64_t v = 0, w = epoch << 24;
-    for (uint32_t spin = 0; spin < (1u << 16); ++spin) {
+    for (uint32_t spin = 0; spin < plan.spin_limit; ++spin) {
       v = __hip_atomic_load(&plan.rpub[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (want_live) w = __hip_atomic_load(&plan.rpub[ranges + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if ((v >> 24) == epoch && (w >> 24) == epoch) break;
       __builtin_amdgcn_s_sleep(8);
     }
-    before = (v >> 24) == epoch ? (v & 0xffffffull) : 0ull;
-    live_before = (w >> 24) == epoch ? (w & 0xffffffull) : 0ull;
+    const bool seen = (v >> 24) == epoch && (w >> 24) == epoch;
+    before = seen ? (v & 0xffffffull) : 0ull;
+    live_before = seen ? (w & 0xffffffull) : 0ull;
+    // the wait ran out: this range's chunk numbers are wrong.  The plan is poisoned (nobody walks its chunk table) and
+    // the host hears of it -- never a plausible table
+    if (!seen) report_fault(plan, G, plan.epochs[1], kFaultLookBack);
   }
 #pragma unroll
   for (int d = kWave / 2; d > 0; d >>= 1) {
@@ -572,6 +619,7 @@ __device__ __forceinline__ void place_range(const uint32_t range, const uint32_t
   if (threadIdx.x == 0) {
     if (range == ranges - 1) {
       plan.gpre[G] = (uint64_t)n1 | ((chunk_base + chunks_here) << 32);   // (live ids, chunks)
+      plan.gpre[G + 1u] = epoch << 24;   // the plan's tag (= plan_tag(epochs[1])): a fault word with this tag poisons it
       // how many groups hold an id at all: the backward's epilogue / finalize pick their sparse or dense form by it
       plan.counts[G] = (uint32_t)live_all + live_here;
     }
@@ -831,6 +879,10 @@ __global__ __launch_bounds__(kChainWaves * 64) void fast3_forward_kernel(const f
   const desc_ptr ctab = (desc_ptr)plan.ctab;
   const uint32_t nchunks = ((desc_ptr)plan.gpre)[2u * G + 1u];
   const uint32_t nwaves = gridDim.x * kChainWaves, gw = blockIdx.x * kChainWaves + wave;
+  if (plan_poisoned(plan, G)) {   // a bounded wait of the grouping pass ran out: NaN rows, never a walk over a wrong table
+    poison_output(plan, out, out_bytes, (uint32_t)C::D, gw, nwaves, lane);
+    return;
+  }
   const uint32_t per = (nchunks + nwaves - 1) / nwaves;
   const uint32_t c0 = gw * per;
   if (c0 >= nchunks) return;
@@ -1021,9 +1073,6 @@ __global__ __launch_bounds__(kChainWaves * 64) void fast3_forward_kernel(const f
   }
 }
 
-#ifdef TTEMB_X8   // experiment (slower: see the header of the file): the forward on the bf16 matrix pipe, fp32 operands split three ways
-#include "ttemb_x8.inc"
-#endif
 
 // ---------------------------------------------------------------------------------
 // backward, atomics-free formulation (four kernels)
@@ -1116,6 +1165,7 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
   const desc_ptr ctab = (desc_ptr)plan.ctab;
   const uint32_t nchunks = ((desc_ptr)plan.gpre)[2u * G + 1u];
   const uint32_t nwaves = gridDim.x * NW, gw = blockIdx.x * NW + wave;
+  if (plan_poisoned(plan, G)) return;   // (the whole grid: the finalize kernel then emits NaN for every gradient element)
   const uint32_t per = (nchunks + nwaves - 1) / nwaves;
   const uint32_t c0 = gw * per;
   bool have = c0 < nchunks;   // a wavefront without work leaves (FUSE: keeps meeting the barriers with empty chunks)
@@ -1666,6 +1716,7 @@ __global__ __launch_bounds__(NWB * 64) void fast3_dg2_reduce_kernel(GroupPlan pl
   constexpr int F4 = ROW2 / 4;      // float4 per row
   constexpr int SUB = kWave / F4;   // rows handled per load instruction
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (plan_poisoned(plan, (uint32_t)G)) return;
   const uint32_t total = (uint32_t)plan.gpre[G];
   const uint32_t s0 = blockIdx.x * kRowsB;
   const uint32_t n_rows = s0 >= total ? 0u : (s0 + kRowsB < total ? kRowsB : total - s0);
@@ -2037,6 +2088,8 @@ __global__ __launch_bounds__(256) void fast3_finalize_kernel(GroupPlan plan, int
   const int n0 = p0 * row0;
   // the form the epilogue kernel took; the wide-rank chain (all_parts) writes every dG1 slab and the dG0 parts of the non-empty groups
   const bool sparse_any = sparse_groups(plan, (uint32_t)(p0 * p1));
+  // a poisoned plan (a bounded wait of the grouping pass ran out): every element this kernel produces is NaN
+  const float poison = plan_poisoned(plan, (uint32_t)(p0 * p1)) ? __uint_as_float(0x7fc00000u) : 0.f;
   const bool sparse = all_parts ? true : sparse_any;          // dG0 parts: skip the groups without ids by their counts
   const bool sparse_g1 = all_parts ? false : sparse_any;      // dG1 slabs: skip the slices without ids by their flags
   // dG1 has few terms per output (one per slice): one thread per FOUR consecutive outputs (16-byte loads; a row of G1 is a
@@ -2062,10 +2115,10 @@ __global__ __launch_bounds__(256) void fast3_finalize_kernel(GroupPlan plan, int
       tot.z += (v[0].z + v[1].z) + (v[2].z + v[3].z);
       tot.w += (v[0].w + v[1].w) + (v[2].w + v[3].w);
     }
-    finalize_emit(upd, 1, dG1, o + 0, tot.x);
-    finalize_emit(upd, 1, dG1, o + 1, tot.y);
-    finalize_emit(upd, 1, dG1, o + 2, tot.z);
-    finalize_emit(upd, 1, dG1, o + 3, tot.w);
+    finalize_emit(upd, 1, dG1, o + 0, tot.x + poison);
+    finalize_emit(upd, 1, dG1, o + 1, tot.y + poison);
+    finalize_emit(upd, 1, dG1, o + 2, tot.z + poison);
+    finalize_emit(upd, 1, dG1, o + 3, tot.w + poison);
     return;
   }
   const int e = blockIdx.x * 32 + x;
@@ -2106,7 +2159,7 @@ __global__ __launch_bounds__(256) void fast3_finalize_kernel(GroupPlan plan, int
   part[y][x] = s;
   __syncthreads();
   if (y == 0) {
-    float tot = 0.f;
+    float tot = poison;
 #pragma unroll
     for (int k = 0; k < 8; ++k) tot += part[k][x];
     if (e < g2_floats) {  // the slabs hold rows as [kk][c2] (see fast3_bwd_chunk_kernel); dG2 rows are [c2][kk]
@@ -2220,6 +2273,14 @@ static bool fits_shape(const DevShape& s) {
   return num_groups(s) * (int64_t)s.q[0] * s.q[1] * s.R[2] * 4 < lim && s.p[2] <= 4096 && s.p[1] < 65536 &&
          num_groups(s) <= (int64_t)kMaxRanges * 4096;   // the grouping pass: <= 512 ranges of <= 4096 groups (64 KB of LDS)
 }
+// DIAGNOSTIC (ttemb_set_spin_limit): tries of the grouping pass's bounded waits; 0 = the default, negative = none at all
+// (every wait expires: how a test reaches the fault path)
+static std::atomic<int64_t> g_spin_limit{0};
+void fast3_set_spin_limit(int64_t tries) { g_spin_limit.store(tries); }
+static uint32_t spin_limit() {
+  const int64_t t = g_spin_limit.load();
+  return t == 0 ? (1u << 16) : (t < 0 ? 0u : (t > 0x7fffffffll ? 0x7fffffffu : (uint32_t)t));
+}
 // DIAGNOSTIC (ttemb_set_piece_limits): tests cut small calls into pieces with it; 0 = the hardware's limits
 static std::atomic<int64_t> g_piece_rows{0}, g_piece_ids{0};
 void fast3_set_piece_limits(int64_t rows, int64_t ids) {
@@ -2282,12 +2343,6 @@ static bool shared_slab(const DevShape& s) { return (int64_t)s.p[2] * s.row_len[
 #define TTEMB_FWD_WGS 4
 #endif
 constexpr int kBwdWgsPerCu = TTEMB_BWD_WGS, kFwdWgsPerCu = TTEMB_FWD_WGS;
-#ifdef TTEMB_X8
-#ifndef TTEMB_X8_WGS
-#define TTEMB_X8_WGS 2
-#endif
-constexpr int kX8WgsPerCu = TTEMB_X8_WGS;   // what the kernel's registers allow (__launch_bounds__ in ttemb_x8.inc)
-#endif
 static int chain_cus() { return device_cus(); }
 static int chain_grid(const void* kernel, size_t lds, int wgs_per_cu, LdsGate* gate, unsigned* grid) {
   int rc = allow_big_lds(kernel, lds, gate, "chain kernel");
@@ -2361,7 +2416,7 @@ static int64_t max_chunks(const DevShape& s, int64_t nnz) {
 
 int64_t fast3_plan_bytes(const DevShape& s, int64_t nnz) {
   const int64_t G = num_groups(s);
-  return 2 * align256(nnz * 4) + align256((G + 1) * 4) + align256((G + 1) * 8) + align256(max_chunks(s, nnz) * 16) +
+  return 2 * align256(nnz * 4) + align256((G + 1) * 4) + align256((G + 3) * 8) + align256(max_chunks(s, nnz) * 16) +
          align256(G * (int64_t)s.q[0] * s.q[1] * s.R[2] * 4);
 }
 
@@ -2374,7 +2429,7 @@ static void carve_plan_part(const DevShape& s, int64_t nnz, char* base, GroupPla
   pl->counts = (uint32_t*)base;
   base += align256((G + 1) * 4);
   pl->gpre = (uint64_t*)base;
-  base += align256((G + 1) * 8);
+  base += align256((G + 3) * 8);   // (+ the plan's tag and its fault word)
   pl->ctab = (uint4*)base;
   base += align256(max_chunks(s, nnz) * 16);
   pl->ptab = (float*)base;
@@ -2414,12 +2469,6 @@ static int64_t carve_workspace(const DevShape& s, int64_t nnz, bool bwd, bool pl
       pl->rpub = rp;
     }
   }
-#ifdef TTEMB_X8
-  {   // the split last core of the bf16 forward (ttemb_x8.inc)
-    uint32_t* gx = (uint32_t*)take((int64_t)s.p[2] * s.row_len[2] * 8);
-    if (pl) pl->g2x = gx;
-  }
-#endif
   if (wide(s)) {   // the lists of non-empty rows the compacted GEMMs walk (rebuilt from the plan's counts by every call)
     uint32_t* wr = (uint32_t*)take((int64_t)s.p[1] * wide_rows_stride(s) * 4);
     uint32_t* wn = (uint32_t*)take((int64_t)s.p[1] * 4);
@@ -2496,6 +2545,8 @@ static int prepare(const DevShape& s, const CorePtrs& cores, bool bwd, const int
                    void* header, const Piece* piece = nullptr) {
   memset(plan, 0, sizeof(*plan));
   plan->piece = piece;
+  plan->fault_host = fault_word(st);
+  plan->spin_limit = spin_limit();
   // the words that outlive a call -- the grouping pass's epoch and its pre-tagged range counters -- sit in the header of
   // the caller's workspace (kFast3HeaderBytes, at the same address for every op on that workspace): tables carved per call
   // would be overwritten by the next call's other tables (the backward's gradients land where the forward grouped)
@@ -2617,12 +2668,6 @@ template <int Q0, int Q1, int Q2, int R1, int R2>
 static int run_forward_direct(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int64_t nnz, int64_t B,
                               float* output, hipStream_t st);
 
-#ifdef TTEMB_X8
-static bool x8_enabled() {   // experiment switch: TTEMB_X8=1 takes the split-bf16 forward (ttemb_x8.inc)
-  static const bool on = [] { const char* e = getenv("TTEMB_X8"); return e != nullptr && e[0] == '1'; }();
-  return on;
-}
-#endif
 
 template <int Q0, int Q1, int Q2, int R1, int R2>
 static int run_forward(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int64_t nnz, int64_t B,
@@ -2630,26 +2675,6 @@ static int run_forward(const DevShape& s, const CorePtrs& cores, const GroupPlan
   using C = Cfg<Q0, Q1, Q2, R1, R2>;
 #ifdef TTEMB_FWD_DIRECT   // experiment: the LDS-free forward of the wide ranks on a narrow-rank shape (slower there, see ttemb_wide3.inc)
   if constexpr (DirectCfg<Q0, Q1, Q2, R1, R2>::ok) return run_forward_direct<Q0, Q1, Q2, R1, R2>(s, cores, plan, nnz, B, output, st);
-#endif
-#ifdef TTEMB_X8
-  if constexpr (X8Cfg<Q0, Q1, Q2, R1, R2>::ok) {
-    if (x8_enabled()) {
-      using X = X8Cfg<Q0, Q1, Q2, R1, R2>;
-      const size_t lds8 = (size_t)kChainWaves * X::WAVE_DW * sizeof(float);
-      static LdsGate lds8_ok;
-      unsigned grid8 = 0;
-      int rc8 = chain_grid(reinterpret_cast<const void*>(fast3_forward_x8_kernel<Q0, Q1, Q2, R1, R2>), lds8, kX8WgsPerCu, &lds8_ok, &grid8);
-      if (rc8) return rc8;
-      const unsigned elems = (unsigned)(s.p[2] * s.row_len[2]);
-      hipLaunchKernelGGL(x8_split_g2_kernel, dim3((elems + 255u) / 256u), dim3(256), 0, st, cores.c[2], (uint32_t)s.p[2], (uint32_t)Q2,
-                         (uint32_t)R2, plan.g2x);
-      profile_begin(0, st);
-      hipLaunchKernelGGL((fast3_forward_x8_kernel<Q0, Q1, Q2, R1, R2>), dim3(grid8), dim3(kChainWaves * 64), lds8, st, plan,
-                         (uint32_t)num_groups(s), (uint32_t)s.p[2], (uint32_t)nnz, output, (uint32_t)(B * s.D * 4));
-      profile_end(0, st);
-      return check_hip(hipGetLastError(), "fast3_forward_x8_kernel");
-    }
-  }
 #endif
   const size_t lds = (size_t)kChainWaves * C::WAVE_FLOATS * sizeof(float);
   static LdsGate lds_ok;
@@ -2861,15 +2886,19 @@ static int run_backward(const DevShape& s, const CorePtrs& cores, const GroupPla
   if (rc) return rc;
   const int gpw = epi_groups_per_wave(s), slices = epi_slices(s);
   constexpr int EW = EpiCfg<Q0, Q1, Q2, R1, R2>::WAVES;
+  profile_begin(8, st);
   hipLaunchKernelGGL((fast3_group_epilogue_kernel<Q0, Q1, Q2, R1, R2>), dim3((unsigned)((slices + EW - 1) / EW), (unsigned)s.p[1]),
                      dim3(EW * 64), 0, st, cores.c[0], cores.c[1], (uint32_t)s.p[0], (uint32_t)s.p[1], (uint32_t)gpw, (uint32_t)slices, plan);
+  profile_end(8, st);
   rc = check_hip(hipGetLastError(), "fast3_group_epilogue_kernel");
   if (rc) return rc;
   {
     const int g2_floats = s.p[2] * C::ROW2, g1_floats = s.p[1] * C::ROW1;
     const int wgs = (g2_floats + s.p[0] * C::ROW0 + 31) / 32 + (g1_floats + 1023) / 1024;   // dG2 | dG0, then dG1
+    profile_begin(9, st);
     hipLaunchKernelGGL(fast3_finalize_kernel, dim3((unsigned)wgs), dim3(256), 0, st, plan, (int)slab_count(s, nnz), slices,
                        s.p[0], s.p[1], g2_floats, (int)C::ROW0, g1_floats, Q2, R2, d_cores.c[0], d_cores.c[1], d_cores.c[2], upd, 0);
+    profile_end(9, st);
   }
   profile_end(1, st);
   return check_hip(hipGetLastError(), "fast3_finalize_kernel");

@@ -28,7 +28,7 @@ PATH_AUTO, PATH_GENERIC, PATH_FAST3, PATH_PER_BAG = 0, 1, 2, 3
 # every symbol include/ttemb.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = (
     "ttemb_abi_version", "ttemb_last_error", "ttemb_workspace_bytes", "ttemb_plan_bytes", "ttemb_set_path",
-    "ttemb_profile_enable", "ttemb_profile_read", "ttemb_kernel_family", "ttemb_set_piece_limits",
+    "ttemb_profile_enable", "ttemb_profile_read", "ttemb_kernel_family", "ttemb_set_piece_limits", "ttemb_status", "ttemb_set_spin_limit",
     "ttemb_forward", "ttemb_forward_group", "ttemb_forward_lookup", "ttemb_backward_dense", "ttemb_backward_sgd", "ttemb_backward_adagrad",
     "ttemb_sgd_step", "ttemb_adagrad_step", "ttemb_cache_update", "ttemb_cache_update_one_sweep", "ttemb_cache_populate",
     "ttemb_preprocess", "ttemb_preprocess_update", "ttemb_cache_forward", "ttemb_cache_backward_sgd",
@@ -76,6 +76,8 @@ def _load() -> ctypes.CDLL:
     lib.ttemb_profile_read.argtypes = [i32, ctypes.POINTER(ctypes.c_float)]
     lib.ttemb_kernel_family.argtypes = [shp, i64, i64, i32]
     lib.ttemb_set_piece_limits.argtypes = [i64, i64]
+    lib.ttemb_set_spin_limit.argtypes = [i64]
+    lib.ttemb_status.argtypes = []
     lib.ttemb_plan_bytes.restype = i64
     lib.ttemb_plan_bytes.argtypes = [shp, i64]
     lib.ttemb_forward.argtypes = [shp, vp, vp, vp, vp, i64, vp, i64, vp, vp, i64, vp, i64, vp]
@@ -249,6 +251,17 @@ def kernel_family(shape: Shape, nnz: int, B: int, ids_with_offsets: bool = True)
     if rc < 0:
         _check(rc)
     return rc
+
+
+def set_spin_limit(tries: int = 0) -> None:
+    """Diagnostic: tries of the grouping pass's bounded device-side waits (0 = default, negative = none: every wait expires)."""
+    _check(LIB.ttemb_set_spin_limit(tries))
+
+
+def status() -> None:
+    """Raise ``RuntimeError`` when a device-side wait of an earlier grouped lookup ran out (its results are NaN); consumes
+    the fault.  The caller synchronises first when it wants the answer for everything it has enqueued."""
+    _check(LIB.ttemb_status())
 
 
 def set_piece_limits(rows: int = 0, ids: int = 0) -> None:

@@ -8,8 +8,9 @@
  * opaque `hipStream_t` passed as `void*`, a caller-provided workspace.  No allocation,
  * no host synchronisation unless a function says so, and no state in the library between
  * calls except process-wide DIAGNOSTIC switches that never change a result: the kernel-family
- * override (ttemb_set_path), the piece limits (ttemb_set_piece_limits) and the event
- * profiler (ttemb_profile_enable).  A caller that never touches them has none.
+ * override (ttemb_set_path), the piece limits (ttemb_set_piece_limits), the spin limit (ttemb_set_spin_limit) and the
+ * event profiler (ttemb_profile_enable) -- and one pinned host word through which a device-side wait that ran out is
+ * reported (ttemb_status).  A caller that never touches them has none.
  *
  * Tracing: with TTEMB_ROCTX=1 in the environment every lookup / cache entry point is bracketed by a roctx range
  * (roctxRangePush / Pop from librocprofiler-sdk-roctx.so or libroctx64.so, looked up at run time), so a
@@ -108,6 +109,22 @@ int ttemb_set_path(int32_t path);
  * tests can cut a small call into many pieces.  Never changes a result. */
 int ttemb_set_piece_limits(int64_t rows, int64_t ids);
 
+/* Device-side faults.  The grouping pass of the grouped lookup has two BOUNDED waits between workgroups (the take-over of a
+ * range counter that carries another call's tag, and the place step's look back at the chunk totals of the ranges before
+ * it).  They cannot run out on a GPU that runs the launch's workgroups together; under CU masking, profiler
+ * serialisation or several processes time-sliced on one GPU they can.  A wait that runs out never becomes plausible
+ * numbers (the reference's kernels cannot time out; it checks its launches with AT_CUDA_CHECK,
+ * FBTT/tt_embeddings_cuda.cu:1666,1742,1845):
+ *   - the call's plan is POISONED on the device: the forward writes NaN into its whole output window, a backward on that
+ *     plan writes NaN gradients (fused modes: NaN weights); no kernel walks the chunk table;
+ *   - the reason is stored to a pinned host word, and the next ttemb_forward* / ttemb_backward* call of the process that
+ *     sees it returns TTEMB_E_HIP with a message (once per fault; no synchronisation is added for this).
+ * ttemb_status() is that check as a call of its own, for callers that synchronise: 0, or TTEMB_E_HIP (and the fault is
+ * consumed).  ttemb_set_spin_limit is a DIAGNOSTIC, process-wide: tries of those waits (0 = the default of 65 536;
+ * negative = none at all, every wait expires -- how tests reach the fault path). */
+int ttemb_status(void);
+int ttemb_set_spin_limit(int64_t tries);
+
 /* Which kernels a lookup of `nnz` ids in `B` bags on this table would run, under the current ttemb_set_path: a
  * DIAGNOSTIC for tests, benchmarks and tuners (tuning_SAGE.py searches ranks in [2, 256]) -- it launches nothing.
  * `ids_with_offsets` != 0: the ids come with their bag boundaries and no row index (what TTEmbeddingBag.forward passes).
@@ -135,8 +152,10 @@ int ttemb_kernel_family(const ttemb_shape_t* shape, int64_t nnz, int64_t B, int3
  * main chain kernel of every ttemb_forward / ttemb_backward_* call is bracketed by
  * hipEvents on the call's stream.  ttemb_profile_read waits for the most recent bracket of
  * `which` (0 = forward chain kernel, 1 = all backward chain kernels, 2 = the backward chunk
- * kernel alone, 3 = the id-grouping pass including the prefix-product kernel) and returns its duration in
- * milliseconds.  Off by default; costs two event records per call when on. */
+ * kernel alone, 3 = the id-grouping pass including the prefix-product kernel, 4 = the cache probe pass of
+ * ttemb_preprocess / ttemb_preprocess_update, 5 = its partition scatter, 6 = the cached-row gather of ttemb_cache_forward,
+ * 7 = the cached-row update of ttemb_cache_backward_*, 8 = the group epilogue kernel of the backward, 9 = its finalize
+ * kernel) and returns its duration in milliseconds.  Off by default; costs two event records per bracket when on. */
 int ttemb_profile_enable(int32_t on);
 int ttemb_profile_read(int32_t which, float* ms_host);
 

@@ -29,6 +29,7 @@ def _kernel_family_back_to_auto():
     if mod is not None:
         mod.set_path(mod.PATH_AUTO)
         mod.set_piece_limits(0, 0)
+        mod.set_spin_limit(0)
 
 
 def pytest_configure(config):

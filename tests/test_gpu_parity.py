@@ -1024,3 +1024,68 @@ def test_ranks_off_the_list_ride_on_the_grouped_path(nat, orc, q, r, Rpad):
     for t in range(3):
         np.testing.assert_allclose(c[t].cpu().numpy(), cores[t] - np.float32(0.05) * want_g[t], rtol=0,
                                    atol=1e-5 + 2e-4 * float(np.abs(0.05 * want_g[t]).max()))
+
+
+# ---------------------------------------------------------------------------------------
+# a bounded device-side wait that runs out fails loud (include/ttemb.h: ttemb_status / ttemb_set_spin_limit)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("wide", [False, True])
+def test_an_expired_wait_gives_nan_and_an_error_never_plausible_numbers(nat, orc, wide):
+    """ttemb_set_spin_limit(-1): every bounded wait of the grouping pass expires (the look-back of every range but the first;
+    on a fresh workspace the counter take-over too).  The forward must give NaN rows, a backward on that plan NaN gradients
+    (fused SGD: NaN weights), the next call TTEMB_E_HIP -- and the call after that, with the default limit, the oracle's
+    numbers again on the same workspace."""
+    p, q = [125, 140, 140], ([5, 5, 4] if wide else [4, 5, 5])
+    R = [1, 64, 64, 1] if wide else [1, 16, 16, 1]
+    rng = np.random.default_rng(11)
+    cores = seeded_cores(p, q, R, 5, 0.3)
+    n = 20000
+    ids = rng.choice(p[0] * p[1] * p[2], size=n, replace=False).astype(np.int64)
+    offs = np.arange(n + 1, dtype=np.int64)
+    shape = nat.make_shape(p, q, R)
+    nat.set_path(nat.PATH_FAST3)
+    assert nat.kernel_family(shape, n, n) in (nat.FAMILY_GROUPED, nat.FAMILY_GROUPED_WIDE)
+    ws = nat.Workspace()
+    c = [dev(x) for x in cores]
+    idx, o = dev(ids), dev(offs)
+    D = int(np.prod(q))
+    plan = torch.empty(nat.plan_bytes(shape, n), dtype=torch.uint8, device="cuda")
+    out = torch.zeros((n, D), device="cuda")
+    nat.status()   # nothing pending
+    nat.set_spin_limit(-1)
+    nat.forward(shape, c, idx, None, o, n, None, n, out, ws, plan=plan)
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(out).all()), "a forward whose grouping pass gave up must not return numbers"
+    # the backward on the poisoned plan: NaN gradients (dense) ...
+    d_out = torch.ones((n, D), device="cuda")
+    grads = [torch.zeros_like(x) for x in c]
+    with pytest.raises(RuntimeError, match="gave up waiting"):
+        nat.backward_dense(shape, c, idx, None, n, None, n, d_out, grads, ws, plan=plan, offsets=o)   # the fault surfaces here, once
+    nat.backward_dense(shape, c, idx, None, n, None, n, d_out, grads, ws, plan=plan, offsets=o)
+    torch.cuda.synchronize()
+    for g in grads:
+        assert bool(torch.isnan(g).all()), "gradients of a poisoned plan must be NaN"
+    # ... and NaN weights in the fused mode (on a copy)
+    c2 = [x.clone() for x in c]
+    nat.backward_sgd(shape, c2, idx, None, n, None, n, d_out, 0.1, ws, plan=plan, offsets=o)
+    torch.cuda.synchronize()
+    assert all(bool(torch.isnan(x).all()) for x in c2)
+    nat.status()   # the backwards walked no wait: nothing new
+    # a backward that regroups under the limit reports again
+    nat.backward_dense(shape, c, idx, None, n, None, n, d_out, grads, ws, offsets=o)
+    torch.cuda.synchronize()
+    assert all(bool(torch.isnan(g).all()) for g in grads)
+    with pytest.raises(RuntimeError, match="gave up waiting"):
+        nat.status()
+    nat.status()   # consumed
+    # default limit, same workspace and plan buffer: the oracle's rows and gradients
+    nat.set_spin_limit(0)
+    nat.forward(shape, c, idx, None, o, n, None, n, out, ws, plan=plan)
+    nat.backward_dense(shape, c, idx, None, n, None, n, d_out, grads, ws, plan=plan, offsets=o)
+    torch.cuda.synchronize()
+    want = orc.tt_forward(ids, offs, cores, p, q, R)
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-5, atol=1e-4)
+    want_g = orc.tt_dense_backward(ids, offs, np.ones((n, D), dtype=np.float32), cores, p, q, R)
+    tol = 2e-4 if wide else 1e-4   # (split-bf16 GEMMs of the wide chain: fp32-grade, see test_wide_rank_gemms_keep_fp32_accuracy)
+    assert_grads_close([g.cpu().numpy() for g in grads], want_g, rel=tol)
+    nat.status()

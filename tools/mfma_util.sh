@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box): tools/mfma_util.sh <out.json>
+# usage (on the GPU box): [TRAFFIC_KBENCH_ARGS="--cfg papers --n 819200 --no-rowidx"] tools/mfma_util.sh <out.json>
 # One counter-only rocprofv3 pass (SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CYCLES, GRBM_GUI_ACTIVE, SQ_WAVES) over
 # tools/kbench.py --iters 5, plus a kernel-trace pass for the durations; MFMA-pipe utilisation of a kernel =
 # MFMA busy cycles summed over the 1024 SIMDs / (duration x 2.4 GHz x 1024).
@@ -7,12 +7,13 @@ out=$(cd $GRAFT_REPO_ROOT && realpath -m "$1")
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/pmc_mfma $R/gpurun_out/pmc_mfma_t
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d $R/gpurun_out/pmc_mfma -- python3 $R/tools/kbench.py --iters 5 > $R/gpurun_out/pmc_mfma.log 2>&1 || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/pmc_mfma_t -- python3 $R/tools/kbench.py --iters 5 > $R/gpurun_out/pmc_mfma_t.log 2>&1 || exit 1
-python3 - "$R" "$out" <<'PY'
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d $R/gpurun_out/pmc_mfma -- python3 $R/tools/kbench.py --iters 5 $TRAFFIC_KBENCH_ARGS > $R/gpurun_out/pmc_mfma.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/pmc_mfma_t -- python3 $R/tools/kbench.py --iters 5 $TRAFFIC_KBENCH_ARGS > $R/gpurun_out/pmc_mfma_t.log 2>&1 || exit 1
+python3 - "$R" "$out" "$TRAFFIC_KBENCH_ARGS" <<'PY'
 import csv, glob, json, sys
 from collections import defaultdict
 R, out = sys.argv[1], sys.argv[2]
+what = sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] else "(products r16, 409600 unique uniform ids)"
 acc = defaultdict(lambda: defaultdict(list))
 for path in glob.glob(f"{R}/gpurun_out/pmc_mfma/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(path)):
@@ -25,7 +26,7 @@ for path in glob.glob(f"{R}/gpurun_out/pmc_mfma_t/**/*kernel_stats.csv", recursi
         if "ttemb" in r["Name"]:
             dur[r["Name"].split("(")[0].replace("void ttemb::", "").replace("ttemb::", "").split("<")[0]] = float(r["AverageNs"]) / 1e3
 res = {"_how": "tools/mfma_util.sh: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES (counters only) and a "
-               "separate --kernel-trace --stats pass over tools/kbench.py --iters 5 (products r16, 409600 unique uniform ids). "
+               "separate --kernel-trace --stats pass over tools/kbench.py --iters 5 " + what + ". "
                "mfma_util = MFMA busy cycles (summed over SIMDs) / (duration x 2.4 GHz x 1024 SIMDs).", "kernels": {}}
 for k, cs in sorted(acc.items()):
     e = {c: round(sum(v) / len(v), 1) for c, v in cs.items()}

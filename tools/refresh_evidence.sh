@@ -7,10 +7,10 @@ tag=${1:-evidence}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$tag
 mkdir -p $O
-bash $R/tools/traffic.sh profiles/r03_traffic.json > $O/traffic.log 2>&1 || exit 1
-cp $R/profiles/r03_traffic.json $O/
-bash $R/tools/mfma_util.sh profiles/r03_mfma_util.json > $O/mfma.log 2>&1 || exit 1
-cp $R/profiles/r03_mfma_util.json $O/
+bash $R/tools/traffic.sh profiles/r04_traffic.json > $O/traffic.log 2>&1 || exit 1
+cp $R/profiles/r04_traffic.json $O/
+bash $R/tools/mfma_util.sh profiles/r04_mfma_util.json > $O/mfma.log 2>&1 || exit 1
+cp $R/profiles/r04_mfma_util.json $O/
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $O/bench_profiled.json 2> $O/bench_profiled.err || exit 1
 cp $O/prof/*/*kernel_stats.csv $O/bench_kernel_stats.csv
