@@ -883,9 +883,9 @@ int ttemb_kernel_family(const ttemb_shape_t* shape, int64_t nnz, int64_t B, int3
   int rc = make_dev_shape(shape, &ds);
   if (rc) return rc;
   if (nnz < 0 || B < 0) return fail(TTEMB_E_BADARG, "negative size");
-  auto family3 = [](const DevShape& s, bool grouped) {
-    if (grouped) return fast3_wide(s) ? TTEMB_FAMILY_GROUPED_WIDE : TTEMB_FAMILY_GROUPED;
-    return small3_templated_shape(s) ? TTEMB_FAMILY_PER_BAG : TTEMB_FAMILY_PER_BAG_RT;
+  auto family3 = [nnz, B](const DevShape& s, bool grouped) {
+    if (grouped) return fast3_wide(s) ? (int)TTEMB_FAMILY_GROUPED_WIDE : (TTEMB_FAMILY_GROUPED | (fast3_prefix_in_chain(s, nnz, B) ? TTEMB_FAMILY_PREFIX_IN_CHAIN : 0));
+    return small3_templated_shape(s) ? (int)TTEMB_FAMILY_PER_BAG : (int)TTEMB_FAMILY_PER_BAG_RT;
   };
   // (without the bag boundaries a call past one row window cannot be cut into pieces)
   if (use_fast3(ds, nnz, B, ids_with_offsets != 0)) return family3(ds, true);

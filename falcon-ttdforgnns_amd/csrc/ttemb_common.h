@@ -68,6 +68,7 @@ int launch_zero_cores(const DevShape& s, const CorePtrsMut& d_cores, hipStream_t
 // fast 3-core path (ttemb_fast3.hip)
 bool fast3_supported(const DevShape& s);
 bool fast3_pays(const DevShape& s, int64_t nnz);
+bool fast3_prefix_in_chain(const DevShape& s, int64_t nnz, int64_t B);   // a whole forward of this size forms P inside its chain kernel
 bool fast3_fits(const DevShape& s, int64_t nnz, int64_t B);   // the call fits one 32-bit row window / one grouping pass
 bool fast3_fits_in_pieces(const DevShape& s, int64_t nnz, int64_t B);   // ... or runs as several pieces (needs `offsets`)
 void fast3_set_piece_limits(int64_t rows, int64_t ids);                  // diagnostic: smaller pieces than the hardware's

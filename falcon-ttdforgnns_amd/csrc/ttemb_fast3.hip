@@ -1075,6 +1075,307 @@ __global__ __launch_bounds__(kChainWaves * 64) void fast3_forward_kernel(const f
 
 
 // ---------------------------------------------------------------------------------
+// forward, prefix products formed IN the chain kernel: frontiers with few ids per group
+//
+// With 23 ids per group (the products frontier) forming P = G0[i0] . G1[i1] once per group in a launch of its own and
+// reading it back is cheap; with 3 ids per group (819 200 ids on the papers100M table: 280 000 groups) that table is a
+// 1.1 GB write and a 1.1 GB read around 0.4 GB of output rows -- the prefix launch took 363 us at 48 TFLOP/s and the chain
+// kernel 333 us on 60 us of MFMA work.  Here a wavefront forms the P of a BATCH of 16 / q0 consecutive groups (one full
+// 16-row MFMA tile: the rows of G0[i0 .. i0 + 16/q0), the B operand is G1[i1] held in registers for as long as the
+// wavefront stays inside one i1 -- its share of the chunk table covers a fraction of one) when it meets the batch's first
+// chunk, keeps the batch's products in LDS for the chunks that follow, and stores them to the plan's table on the way (the
+// backward of the same call reads them there: fire-and-forget stores).  Groups are numbered i1 * p0 + i0, so a batch is
+// p0-aligned by construction; a batch whose other groups hold no id computes their P for nothing (<= half the tile on a
+// uniform papers100M frontier at 95 % occupancy: 5 %).  The A operand of a batch (q0 r1 floats per group, L2-resident) is
+// requested with the G2 rows of the batch's first chunk, two steps ahead.
+// ---------------------------------------------------------------------------------
+template <int Q0, int Q1, int Q2, int R1, int R2>
+struct PFuseCfg {
+  using C = Cfg<Q0, Q1, Q2, R1, R2>;
+  static constexpr int GM = 16 / Q0;          // groups per batch
+  // q0 > 8: one group per tile -- nothing to batch; q = 4,4,8 / 5,5,4 at rank 32 spill 64-76 bytes per lane under the
+  // two-wavefront bound (G1[i1] alone is 64 registers there).  Those shapes keep the prefix launch.
+  static constexpr bool ok = GM >= 2 && !(R1 == 32 && ((Q0 == 4 && Q1 == 4 && Q2 == 8) || (Q0 == 5 && Q1 == 5 && Q2 == 4)));
+  // A staged P is M2 rows of r2 floats, UNPADDED (a padded row cost the q = 4,4,8 rank-16 shape its third workgroup per CU):
+  // the 16-byte quads of row m are XOR-swizzled by swz(m) instead, so that the A-operand reads (lane lo = row, 4 s + hi =
+  // column) of eight consecutive rows fall on eight different bank groups.  Rows past M2 of the last row tile are read
+  // from whatever follows the slot (inside the wavefront's region) and discarded.
+  static constexpr int QR = R2 / 4;                              // quads per row
+  static constexpr int RPB = R2 >= 32 ? 1 : 32 / R2;             // rows per sweep of the 32 banks
+  static constexpr int SLOT_FLOATS = C::M2 * R2;
+  static constexpr int WAVE_FLOATS = GM * SLOT_FLOATS + C::BO_FLOATS;
+  static_assert(C::BO_FLOATS >= (C::MT2 * 16 - C::M2) * R2, "the last slot's padded rows are read inside the wavefront's region");
+  __device__ static constexpr int swz(int m) { return 4 * ((m / RPB) % QR); }
+};
+
+// (two wavefronts per SIMD at least: left to itself the compiler gave the rank-32 instances 256 VGPRs + accumulation
+// registers -- ONE wavefront per SIMD, 695 us on the papers100M frontier)
+template <int Q0, int Q1, int Q2, int R1, int R2>
+__global__ __launch_bounds__(kChainWaves * 64, 2) void fast3_forward_pfuse_kernel(
+    const float* __restrict__ G0, const float* __restrict__ G1, const float* __restrict__ G2, GroupPlan plan, uint32_t G, uint32_t p0,
+    uint64_t p0_magic, uint32_t p2, uint32_t nnz, float* __restrict__ out, uint32_t out_bytes) {
+  using C = Cfg<Q0, Q1, Q2, R1, R2>;
+  using PC = PFuseCfg<Q0, Q1, Q2, R1, R2>;
+  constexpr int GM = PC::GM;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = uniform(threadIdx.x >> 6);
+  const int hi = lane >> 4, lo = lane & 15;
+  const int b_l = lane >> 2, j_l = lane & 3;   // this lane's id inside a chunk, and which pieces of its rows
+  float* pbuf = smem + wave * PC::WAVE_FLOATS;   // GM slots of SLOT_FLOATS: the prefix products of the current batch
+  float* bbuf = pbuf + GM * PC::SLOT_FLOATS;
+  float* obuf = bbuf;
+
+  const desc_ptr ctab = (desc_ptr)plan.ctab;
+  const uint32_t nchunks = ((desc_ptr)plan.gpre)[2u * G + 1u];
+  const uint32_t nwaves = gridDim.x * kChainWaves, gw = blockIdx.x * kChainWaves + wave;
+  if (plan_poisoned(plan, G)) {   // a bounded wait of the grouping pass ran out: NaN rows, never a walk over a wrong table
+    poison_output(plan, out, out_bytes, (uint32_t)C::D, gw, nwaves, lane);
+    return;
+  }
+  const uint32_t per = (nchunks + nwaves - 1) / nwaves;
+  const uint32_t c0 = gw * per;
+  if (c0 >= nchunks) return;
+  const uint32_t c1 = c0 + per < nchunks ? c0 + per : nchunks;
+
+  constexpr int F4G = C::ROW2 / 4, NLG = (F4G + 3) / 4;     // float4 pieces of a G2 row / per lane
+  constexpr int D4 = C::D / 4, NLO = (D4 + 3) / 4;          // float4 pieces of an output row / per lane
+  constexpr int PF = C::M2 * R2;
+  const rsrc_t r_g2 = make_rsrc(G2, p2 * (uint32_t)C::ROW2 * 4u);
+  const rsrc_t r_g0 = make_rsrc(G0, p0 * (uint32_t)C::ROW0 * 4u);
+  if (plan.piece != nullptr) {   // a piece of a larger call: rows count from the piece's first bag
+    out += plan.piece->rowbase * (long long)C::D;
+    out_bytes = (uint32_t)plan.piece->window_bytes;
+  }
+  const rsrc_t r_out = make_rsrc(out, out_bytes);
+  const uint32_t rowpiece = 16u * (uint32_t)j_l;
+  const uint32_t g_last = (F4G % 4 == 0 || j_l + 4 * (NLG - 1) < F4G) ? rowpiece + 64u * (NLG - 1) : kOobBase;
+  const bool o_has_last = D4 % 4 == 0 || j_l + 4 * (NLO - 1) < D4;
+  // the P product of a batch: A row lo = (group lo / q0 of the batch, core row lo % q0), k = 4 s + hi
+  const uint32_t a_grp = (uint32_t)lo / Q0;                                   // (q0 = 5: row 15 belongs to no group)
+  const uint32_t a_off = (uint32_t)((lo % Q0) * R1 + hi) * 4u;
+
+  // where a chunk's group sits: its i1, the first i0 of its batch, its slot in the batch, and whether the chunk OPENS a batch
+  // (the batch differs from the one requested last; chunks are met in group order, so a batch is opened once per wavefront)
+  struct Grp {
+    uint32_t i1, i0b, slot, first_group;
+    bool fresh;
+  };
+  uint32_t last_batch = 0xffffffffu;
+  auto locate = [&](const uint4& d) {
+    const uint32_t g = uniform(d.y);
+    Grp r;
+    r.i1 = (uint32_t)(((uint64_t)g * p0_magic) >> 40);   // g / p0: exact for g p0 < 2^40 (the host's magic = 2^40 / p0 + 1)
+    const uint32_t i0 = g - r.i1 * p0;
+    r.i0b = i0 / GM * GM;
+    r.slot = i0 - r.i0b;
+    r.first_group = g - r.slot;
+    r.fresh = uniform(d.z & 0xffu) != 0u && r.first_group != last_batch;   // (an empty chunk past the share opens nothing)
+    if (r.fresh) last_batch = r.first_group;
+    return r;
+  };
+
+  float4 pre_g[NLG];
+  float pre_a[C::KS1];
+  auto request = [&](uint32_t row, const Grp& gp) {   // row: byte offset of the lane's G2 row
+#pragma unroll
+    for (int k = 0; k < NLG; ++k)
+      pre_g[k] = k + 1 < NLG ? buf_load4(r_g2, row + rowpiece + 64u * k) : buf_load4(r_g2, row + g_last);
+    // the batch's rows of G0 when the chunk opens one (else the loads fall off the buffer: the instruction stream is fixed)
+    const uint32_t i0a = gp.i0b + a_grp;
+    const uint32_t base = (gp.fresh && a_grp < (uint32_t)GM && i0a < p0) ? i0a * (uint32_t)(C::ROW0 * 4) + a_off : kOobBase;
+#pragma unroll
+    for (int s = 0; s < C::KS1; ++s) pre_a[s] = __uint_as_float(buf_load1u(r_g0, base + 16u * s));
+  };
+  auto stage_rows = [&]() {   // G2 rows: registers -> LDS
+#pragma unroll
+    for (int k = 0; k < NLG; ++k) {
+      const int idx = j_l + 4 * k;
+      if (F4G % 4 == 0 || idx < F4G) *reinterpret_cast<float4*>(bbuf + b_l * C::LDB + 4 * idx) = pre_g[k];
+    }
+  };
+  float bvp[C::KS1][C::NT1];   // G1[i1] as the B operand of the P product
+  uint32_t cur_i1 = 0xffffffffu;
+  auto form_p = [&](const Grp& gp) {   // the chunk opens a batch: its GM prefix products -> LDS slots and the plan's table
+    if (gp.i1 != cur_i1) {   // (once per i1 of the wavefront's share: a share covers a fraction of one)
+      const float* g1 = G1 + (size_t)gp.i1 * C::ROW1;
+#pragma unroll
+      for (int s = 0; s < C::KS1; ++s)
+#pragma unroll
+        for (int nt = 0; nt < C::NT1; ++nt)
+          bvp[s][nt] = (C::N1 % 16 == 0 || 16 * nt + lo < C::N1) ? g1[(4 * s + hi) * C::N1 + 16 * nt + lo] : 0.f;
+      cur_i1 = gp.i1;
+    }
+    // The product is formed TRANSPOSED -- G1[i1]^T (rows n = (j, c2)) times the batch's G0 rows (columns (group, a)) -- with
+    // the very same operand registers, handed to the MFMA the other way round: the accumulator of lane (hi, lo) then holds
+    // P[group lo / q0][a = lo % q0][n = 16 nt + 4 hi + r], r = 0..3 -- four CONSECUTIVE c2 of one row of P, one 16-byte LDS
+    // write and one 16-byte store to the plan's table per column tile (the plain product leaves four different rows per
+    // lane: 4 x as many of both).
+    f32x4 acc[C::NT1];
+#pragma unroll
+    for (int nt = 0; nt < C::NT1; ++nt) {
+      acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < C::KS1; ++s) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bvp[s][nt], pre_a[s], acc[nt], 0, 0, 0);
+    }
+    const rsrc_t r_p = make_rsrc(plan.ptab + (size_t)gp.first_group * PF, (uint32_t)(GM * PF * 4));
+    const int gi = lo / Q0, a = lo % Q0;
+    const bool on = gi < GM && gp.i0b + (uint32_t)gi < p0;   // (q0 = 5: column 15 is no group's; a batch at the end of an i1 may be short)
+    float* slot = pbuf + (gi < GM ? gi : 0) * PC::SLOT_FLOATS;
+#pragma unroll
+    for (int nt = 0; nt < C::NT1; ++nt) {
+      const int n = 16 * nt + 4 * hi;   // (N1 and r2 are multiples of 4: the four columns stay inside one row of P)
+      const bool col = C::N1 % 16 == 0 || n < C::N1;
+      const int m = a * Q1 + n / R2, c2 = n % R2;
+      if (on && col) *reinterpret_cast<f32x4*>(slot + m * R2 + (c2 ^ PC::swz(m))) = acc[nt];
+      buf_store4(r_p, (on && col) ? (uint32_t)((gi * PF + m * R2 + c2) * 4) : kOobBase, make_float4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]));
+    }
+  };
+  auto fetch_i2 = [&](const uint4& d) {   // lanes past the chunk's length read 0: G2 row 0 stands in, nothing of theirs is stored
+    return buf_load1u(make_rsrc(plan.i2s + uniform(d.x), uniform((d.z & 0xffu) * 4u)), 4u * (uint32_t)b_l);
+  };
+  auto fetch_val = [&](const uint4& d) {
+    return buf_load1u(make_rsrc(plan.vals + uniform(d.x), uniform((d.z & 0xffu) * 4u)), 4u * (uint32_t)b_l);
+  };
+
+  // ---- prologue: chunk 0 (its batch's products formed) in LDS, rows of chunk 1 and the i2 of chunk 2 in flight ----
+  uint4 d_cur = load_desc(ctab, c0, c1);
+  uint4 d_nxt = load_desc(ctab, c0 + 1, c1);   // past c1: an empty chunk
+  uint4 d_nn = load_desc(ctab, c0 + 2, c1);
+  uint4 d_n3 = load_desc(ctab, c0 + 3, c1);
+  Grp g_cur = locate(d_cur), g_nxt = locate(d_nxt);
+  uint32_t i2_nn, val_cur;
+  {
+    const uint32_t i2_a = fetch_i2(d_cur), i2_b = fetch_i2(d_nxt);
+    request(__umul24(i2_a, (uint32_t)(C::ROW2 * 4)), g_cur);   // i2 < p2 <= 4096
+    stage_rows();
+    form_p(g_cur);   // (the share's first chunk always opens a batch)
+    __builtin_amdgcn_sched_barrier(0);
+    request(__umul24(i2_b, (uint32_t)(C::ROW2 * 4)), g_nxt);
+  }
+  i2_nn = fetch_i2(d_nn);
+  val_cur = fetch_val(d_cur);
+  Grp g_nn = locate(d_nn);
+
+  for (uint32_t c = c0;; ++c) {
+    const uint32_t len = d_cur.z & 0xffu;
+    const uint32_t val = val_cur;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_sched_barrier(0);
+
+    TTEMB_PRIO(0);
+    // ---- stage 2: (q0 q1 x r2) . (r2 x 16 q2), P from the group's slot of the batch ----
+    const float* pslot = pbuf + g_cur.slot * PC::SLOT_FLOATS;
+    float av[C::MT2][C::KS2];
+#pragma unroll
+    for (int mt = 0; mt < C::MT2; ++mt)
+#pragma unroll
+      for (int s = 0; s < C::KS2; ++s) av[mt][s] = pslot[(16 * mt + lo) * R2 + ((4 * s) ^ PC::swz(16 * mt + lo)) + hi];
+    float bv[C::NT2][C::KS2];
+#pragma unroll
+    for (int nt = 0; nt < C::NT2; ++nt) {
+      if ((uint32_t)(16 * nt) < len * Q2) {
+        const int n = 16 * nt + lo;
+#pragma unroll
+        for (int s = 0; s < C::KS2; ++s) bv[nt][s] = bbuf[(n / Q2) * C::LDB + (4 * s + hi) * Q2 + n % Q2];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // every staged-G2 read is done: the region becomes the row buffer
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int nt = 0; nt < C::NT2; ++nt) {
+      if ((uint32_t)(16 * nt) < len * Q2) {
+        const int n = 16 * nt + lo;
+        const int b = n / Q2, kk = n % Q2;
+        f32x4 acc[C::MT2];
+#pragma unroll
+        for (int s = 0; s < C::KS2; ++s)
+#pragma unroll
+          for (int mt = 0; mt < C::MT2; ++mt)
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][s], bv[nt][s], s == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < C::MT2; ++mt) {
+          if (16 * mt + 4 * hi + (C::M2 % 4 == 0 ? 3 : 0) < C::M2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (C::M2 % 4 == 0 || 16 * mt + 4 * hi + r < C::M2) obuf[b * C::LDO + (16 * mt + 4 * hi + r) * Q2 + kk] = acc[mt][r];
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    TTEMB_PRIO(2);
+    // ---- this lane's pieces of its output row: LDS -> registers ----
+    float4 x[NLO];
+#pragma unroll
+    for (int k = 0; k < NLO; ++k) {
+      const int idx = 4 * k + j_l < D4 ? 4 * k + j_l : D4 - 1;
+      x[k] = *reinterpret_cast<const float4*>(obuf + b_l * C::LDO + 4 * idx);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // the row buffer has been read: the next chunk's G2 rows may land in it
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- G2 rows of the next chunk: registers -> LDS; the row offset of the chunk after and this chunk's row word are
+    //      consumed HERE, so that no load is outstanding across the branch below (its stores would sit in front of their wait) ----
+    stage_rows();
+    const uint32_t row_nn = __umul24(i2_nn, (uint32_t)(C::ROW2 * 4));
+    asm volatile("" ::"v"(row_nn), "v"(val));
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- 16-byte global stores, four lanes per row ----
+    {
+      const bool row_ok = (uint32_t)b_l < len;
+      const bool multi = (val & kMultiBit) != 0u;
+      const uint32_t row_off = __umul24(val & 0x00ffffffu, (uint32_t)(C::D * 4)) + rowpiece;   // rows < 2^24 (fast3_fits)
+      const uint32_t off = row_ok && !multi ? row_off : kOobBase;   // bags with several ids accumulate below
+#pragma unroll
+      for (int k = 0; k < NLO; ++k) buf_store4(r_out, (k + 1 < NLO || o_has_last) ? off + 64u * k : kOobBase, x[k]);
+      if (__ballot(row_ok && multi) != 0ull) {  // rare: float atomics
+        if (row_ok && multi) {
+          float* dst = out + (size_t)(val & 0x00ffffffu) * (uint32_t)C::D;
+#pragma unroll
+          for (int k = 0; k < NLO; ++k) {
+            const int idx = 4 * k + j_l;
+            if (k + 1 < NLO || o_has_last) {
+              atomicAdd(dst + 4 * idx + 0, x[k].x);
+              atomicAdd(dst + 4 * idx + 1, x[k].y);
+              atomicAdd(dst + 4 * idx + 2, x[k].z);
+              atomicAdd(dst + 4 * idx + 3, x[k].w);
+            }
+          }
+        }
+      }
+    }
+    // ---- the next chunk opens a batch: its prefix products (after the row stores: the rows' registers are free by now) ----
+    __builtin_amdgcn_sched_barrier(0);
+    if (g_nxt.fresh) {   // wave-uniform: the next chunk opens a batch
+      asm volatile("; a batch begins" ::: "memory");
+      form_p(g_nxt);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (c + 1 >= c1) break;
+    // ---- loads of the chunk after next, i2 of the one after that, output rows of the next ----
+    request(row_nn, g_nn);
+    i2_nn = fetch_i2(d_n3);
+    val_cur = fetch_val(d_nxt);
+    d_cur = d_nxt;
+    g_cur = g_nxt;
+    d_nxt = d_nn;
+    g_nxt = g_nn;
+    d_nn = d_n3;
+    g_nn = locate(d_nn);
+    d_n3 = load_desc(ctab, c + 4, c1);
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // backward, atomics-free formulation (four kernels)
 //
 //  A. chunk kernel: per chunk
@@ -1106,9 +1407,12 @@ __global__ __launch_bounds__(kChainWaves * 64) void fast3_forward_kernel(const f
 // the kernel took twice as long -- while the two workgroups drift into complementary phases as independent waves do.
 constexpr int kFuseWaves = TTEMB_FUSE_WAVES;   // a power of two
 constexpr int kFuseQuads = 48 / kFuseWaves;    // register quads of slab rows per wavefront: p2 <= kFuseWaves * GPW * kFuseQuads
-constexpr int kFuseBatch = 6;                  // quads whose list heads / first rows are read together
+#ifndef TTEMB_FUSE_BATCH
+#define TTEMB_FUSE_BATCH 6
+#endif
+constexpr int kFuseBatch = TTEMB_FUSE_BATCH;   // quads whose list heads / first rows are read together
 constexpr int kFuseSub = 2;                    // chunks a wavefront multiplies between two reductions (one more E region each)
-static_assert(kFuseQuads % kFuseBatch == 0, "quads are handled in whole batches");
+static_assert(kFuseQuads % kFuseBatch == 0 && kFuseBatch % 6 == 0, "quads are handled in whole batches");
 // Shapes whose dP is ONE row tile (q0 q1 <= 16) hold half the accumulators and A operands of the others: their wavefronts
 // have registers for half as many slab quads again, which is what a wide row (r2 q2 = 128: two rows per register quad
 // across the lanes) needs to keep 140 slab rows in four wavefronts (q = 4,4,8 at rank 16, the arxiv shape of the scripts).
@@ -1240,6 +1544,7 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
   const int s_kk = s_piece / QK;
   const int rd_off = s_kk * R2 + 4 * ((s_piece % QK) ^ (s_kk & (QK - 1)));   // float offset of this lane's quad inside a row
   constexpr int FQ = fuse_quads(C::M2, C::ROW2);
+  constexpr int FB = FQ % kFuseBatch == 0 ? kFuseBatch : 6;   // quads walked together (fuse_quads() is a multiple of 6)
   f32x4 slab[FQ];
   if constexpr (FUSE) {
 #pragma unroll
@@ -1324,8 +1629,13 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
   uint4 d_nn = load_desc(ctab, c + 2, nchunks);
   if (!more2) d_nn = none;
   uint32_t i2_a, val_a, i2_b, val_b;
+#if defined(TTEMB_ABL) && (TTEMB_ABL & 128)   // (ablation 128: the first two chunks' rows are requested without waiting for their (i2, row) pairs -- wrong rows, timing only)
+  i2_a = i2_b = (uint32_t)b_l;
+  val_a = val_b = (uint32_t)(gw * 16u + (uint32_t)b_l);
+#else
   fetch_meta(d_cur, i2_a, val_a);
   fetch_meta(d_nxt, i2_b, val_b);
+#endif
   request(offsets(d_cur, i2_a, val_a), d_cur);
   stage(true);
   __builtin_amdgcn_sched_barrier(0);
@@ -1604,27 +1914,27 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
         const int qstep = s_grp < GPW ? GPW * kFuseWaves : 0;
         const char* const rows = lds0 + (uint32_t)rd_off * 4u;
 #pragma unroll
-        for (int q0 = 0; q0 < FQ; q0 += kFuseBatch) {
+        for (int q0 = 0; q0 < FQ; q0 += FB) {
           if ((uint32_t)(q0 * GPW * kFuseWaves) >= p2) break;   // wave-uniform: no slab row in the remaining quads
-          uint32_t en[kFuseBatch];   // entry being visited
+          uint32_t en[FB];   // entry being visited
 #pragma unroll
-          for (int u = 0; u < kFuseBatch; ++u) en[u] = my_head[(q0 + u) * qstep];   // heads past p2 hold NIL for ever
+          for (int u = 0; u < FB; ++u) en[u] = my_head[(q0 + u) * qstep];   // heads past p2 hold NIL for ever
 #pragma unroll
-          for (int u = 0; u < kFuseBatch; ++u) my_head[(q0 + u) * qstep] = f_nil;   // (every lane of the group stores the same word)
+          for (int u = 0; u < FB; ++u) my_head[(q0 + u) * qstep] = f_nil;   // (every lane of the group stores the same word)
           // The lists of the batch are walked TOGETHER, one entry of each per step: entries, then rows, in flight together; a
           // list that has ended (or was empty) keeps visiting NIL and adds zeros.  The number of steps is the longest list of
           // the batch (~3: 128 rows over ~140 values of i2) -- walking the tails list by list cost one dependent LDS round
           // trip pair per extra entry of every list: 3 600 of the 9 700 cycles of an iteration.
           for (;;) {
-            uint2 ent[kFuseBatch];
+            uint2 ent[FB];
 #pragma unroll
-            for (int u = 0; u < kFuseBatch; ++u) ent[u] = *reinterpret_cast<const uint2*>(lds0 + en[u]);
-            f32x4 x[kFuseBatch];
+            for (int u = 0; u < FB; ++u) ent[u] = *reinterpret_cast<const uint2*>(lds0 + en[u]);
+            f32x4 x[FB];
 #pragma unroll
-            for (int u = 0; u < kFuseBatch; ++u) x[u] = *reinterpret_cast<const f32x4*>(rows + ent[u].x);
+            for (int u = 0; u < FB; ++u) x[u] = *reinterpret_cast<const f32x4*>(rows + ent[u].x);
             bool left = false;
 #pragma unroll
-            for (int u = 0; u < kFuseBatch; ++u) {
+            for (int u = 0; u < FB; ++u) {
               slab[q0 + u] += x[u];
               en[u] = ent[u].y;
               left = left || en[u] != f_nil;
@@ -1874,7 +2184,7 @@ struct EpiCfg {
 template <int Q0, int Q1, int Q2, int R1, int R2, bool SKIP>
 __device__ __forceinline__ void epilogue_unit(
     const float* __restrict__ G0, const float* __restrict__ G1, uint32_t p0, uint32_t p1, uint32_t gpw, const GroupPlan& plan,
-    float* dpbuf, float* g1buf, uint32_t slice, uint32_t slices) {
+    float* dpbuf, float* g1buf, uint32_t slice, uint32_t slices, uint32_t i1) {
   using C = Cfg<Q0, Q1, Q2, R1, R2>;
   constexpr int GM = 16 / Q0;            // groups per batch: their q0 rows fill one 16-row MFMA tile
   constexpr int LDD = C::N1 + 4;         // row stride of the staged dP rows (16-byte aligned rows)
@@ -1886,7 +2196,6 @@ __device__ __forceinline__ void epilogue_unit(
   constexpr int EW = EpiCfg<Q0, Q1, Q2, R1, R2>::WAVES;
   const int lane = threadIdx.x & 63;
   const int hi = lane >> 4, lo = lane & 15;
-  const uint32_t i1 = blockIdx.y;
   const bool active = slice < slices;   // (a workgroup's last wavefronts may have no slice: they only help with G1)
   const uint32_t i0_begin = active ? slice * gpw : p0;
   const uint32_t i0_end = i0_begin + gpw < p0 ? i0_begin + gpw : p0;
@@ -2055,11 +2364,13 @@ __global__ __launch_bounds__((EpiCfg<Q0, Q1, Q2, R1, R2>::WAVES * 64)) void fast
   __shared__ __attribute__((aligned(16))) float g1buf[R1 * C::LDG];
   const uint32_t wave = threadIdx.x >> 6;
   float* dpbuf = dpbuf_all[wave];
-  const uint32_t slice = blockIdx.x * EW + wave;
+  const uint32_t nsb = (slices + EW - 1u) / EW;   // workgroups per i1 (1-D grid: consecutive workgroups share an i1)
+  const uint32_t i1_blk = blockIdx.x / nsb;
+  const uint32_t slice = (blockIdx.x - i1_blk * nsb) * EW + wave;
   if (sparse_groups(plan, p0 * p1))
-    epilogue_unit<Q0, Q1, Q2, R1, R2, true>(G0, G1, p0, p1, gpw, plan, dpbuf, g1buf, slice, slices);
+    epilogue_unit<Q0, Q1, Q2, R1, R2, true>(G0, G1, p0, p1, gpw, plan, dpbuf, g1buf, slice, slices, i1_blk);
   else
-    epilogue_unit<Q0, Q1, Q2, R1, R2, false>(G0, G1, p0, p1, gpw, plan, dpbuf, g1buf, slice, slices);
+    epilogue_unit<Q0, Q1, Q2, R1, R2, false>(G0, G1, p0, p1, gpw, plan, dpbuf, g1buf, slice, slices, i1_blk);
 }
 
 // D. finalize (and, in the fused modes, the optimiser step: every core element is produced exactly once here, so
@@ -2101,19 +2412,20 @@ __global__ __launch_bounds__(256) void fast3_finalize_kernel(GroupPlan plan, int
     if (o >= g1_floats) return;
     const int i1 = o / (g1_floats / p1);
     float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int t = 0; t < slices; t += 4) {
-      bool on[4];
-      float4 v[4];
+    // (eight slabs in flight per thread: the kernel is a chain of memory round trips -- 16 slices took four of them)
+    for (int t = 0; t < slices; t += 8) {
+      bool on[8];
+      float4 v[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)   // slices without ids wrote nothing (sparse form)
+      for (int u = 0; u < 8; ++u)   // slices without ids wrote nothing (sparse form)
         on[u] = t + u < slices && (!sparse_g1 || plan.epi_live[(size_t)(t + u) * p1 + i1] != 0u);
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < 8; ++u)
         v[u] = on[u] ? *reinterpret_cast<const float4*>(plan.g1part + (size_t)(t + u) * g1_floats + o) : make_float4(0.f, 0.f, 0.f, 0.f);
-      tot.x += (v[0].x + v[1].x) + (v[2].x + v[3].x);
-      tot.y += (v[0].y + v[1].y) + (v[2].y + v[3].y);
-      tot.z += (v[0].z + v[1].z) + (v[2].z + v[3].z);
-      tot.w += (v[0].w + v[1].w) + (v[2].w + v[3].w);
+      tot.x += ((v[0].x + v[1].x) + (v[2].x + v[3].x)) + ((v[4].x + v[5].x) + (v[6].x + v[7].x));
+      tot.y += ((v[0].y + v[1].y) + (v[2].y + v[3].y)) + ((v[4].y + v[5].y) + (v[6].y + v[7].y));
+      tot.z += ((v[0].z + v[1].z) + (v[2].z + v[3].z)) + ((v[4].z + v[5].z) + (v[6].z + v[7].z));
+      tot.w += ((v[0].w + v[1].w) + (v[2].w + v[3].w)) + ((v[4].w + v[5].w) + (v[6].w + v[7].w));
     }
     finalize_emit(upd, 1, dG1, o + 0, tot.x + poison);
     finalize_emit(upd, 1, dG1, o + 1, tot.y + poison);
@@ -2124,7 +2436,7 @@ __global__ __launch_bounds__(256) void fast3_finalize_kernel(GroupPlan plan, int
   const int e = blockIdx.x * 32 + x;
   float s = 0.f;
   // U independent partial sums per thread keep that many loads in flight (a single running sum issues them one by one)
-  constexpr int U = 4;
+  constexpr int U = 8;
   if (e < g2_floats) {
     // the loads of a step go into registers first, then into the sum (accumulating load by load made every one of
     // them wait for the one before: the slabs were written on other XCDs, each dependent step is a trip to memory;
@@ -2153,7 +2465,7 @@ __global__ __launch_bounds__(256) void fast3_finalize_kernel(GroupPlan plan, int
         const int g = (i1 + 8 * u) * p0 + i0;
         v[u] = on[u] ? plan.g0part[(size_t)g * row0 + c] : 0.f;
       }
-      s += (v[0] + v[1]) + (v[2] + v[3]);
+      s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
     }
   }
   part[y][x] = s;
@@ -2542,7 +2854,7 @@ static int group_ids(const DevShape& s, const CorePtrs& cores, const int64_t* in
 static int prepare(const DevShape& s, const CorePtrs& cores, bool bwd, const int64_t* indices, const int64_t* rowidx,
                    const int64_t* offsets, int64_t nnz, const int32_t* nnz_dev, int64_t B, float* zero_out, void* ws,
                    int64_t ws_bytes, void* plan_buf, int64_t plan_bytes, int plan_state, GroupPlan* plan, hipStream_t st,
-                   void* header, const Piece* piece = nullptr) {
+                   void* header, const Piece* piece = nullptr, bool prefix_in_chain = false) {
   memset(plan, 0, sizeof(*plan));
   plan->piece = piece;
   plan->fault_host = fault_word(st);
@@ -2566,7 +2878,8 @@ static int prepare(const DevShape& s, const CorePtrs& cores, bool bwd, const int
   profile_begin(3, st);
   int rc = TTEMB_OK;
   // building the whole plan: the prefix products ride in the last grouping launch
-  if (plan_state <= 1) rc = group_ids(s, cores, indices, rowidx, offsets, nnz, nnz_dev, B, zero_out, plan_state == 0, plan, st);
+  // (prefix_in_chain: the forward chain kernel forms the prefix products itself -- fast3_forward_pfuse_kernel)
+  if (plan_state <= 1) rc = group_ids(s, cores, indices, rowidx, offsets, nnz, nnz_dev, B, zero_out, plan_state == 0 && !prefix_in_chain, plan, st);
   if (rc == TTEMB_OK && plan_state == 2) rc = run_prefix(s, cores, *plan, st);
   profile_end(3, st);
   return rc;
@@ -2686,6 +2999,48 @@ static int run_forward(const DevShape& s, const CorePtrs& cores, const GroupPlan
                      plan, (uint32_t)num_groups(s), (uint32_t)s.p[2], (uint32_t)nnz, output, (uint32_t)(B * s.D * 4));
   profile_end(0, st);
   return check_hip(hipGetLastError(), "fast3_forward_kernel");
+}
+
+// Frontiers with few ids per group form the prefix products inside the chain kernel (fast3_forward_pfuse_kernel).  The rule
+// looks at the call's size only (the occupancy of the groups is known on the device alone): fewer than kPFuseIdsPerGroup ids
+// per group on average.  Measured crossover: see profiles/r04_pfuse_forward.txt.
+#ifndef TTEMB_PFUSE_IDS
+#define TTEMB_PFUSE_IDS 4
+#endif
+constexpr int64_t kPFuseIdsPerGroup = TTEMB_PFUSE_IDS;
+template <int Q0, int Q1, int Q2, int R1, int R2>
+static bool pfuse_shape() { return PFuseCfg<Q0, Q1, Q2, R1, R2>::ok; }
+static bool pfuse_pays(const DevShape& s, int64_t nnz) {
+  if (kPFuseIdsPerGroup <= 0 || !classify(s)) return false;
+  bool ok = false;
+#define TTEMB_X(a, b, c, d, e) if (shape_is(s, a, b, c, d, e)) ok = pfuse_shape<a, b, c, d, e>();
+  TTEMB_FAST3_SHAPES(TTEMB_X)
+#undef TTEMB_X
+  return ok && nnz < kPFuseIdsPerGroup * num_groups(s);
+}
+
+bool fast3_prefix_in_chain(const DevShape& s, int64_t nnz, int64_t B) { return fits_piece(s, nnz, B) && pfuse_pays(s, nnz); }
+
+template <int Q0, int Q1, int Q2, int R1, int R2>
+static int run_forward_pfuse(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int64_t nnz, int64_t B,
+                             float* output, hipStream_t st) {
+  using PC = PFuseCfg<Q0, Q1, Q2, R1, R2>;
+  if constexpr (PC::ok) {
+    const size_t lds = (size_t)kChainWaves * PC::WAVE_FLOATS * sizeof(float);
+    static LdsGate lds_ok;
+    unsigned grid = 0;
+    int rc = chain_grid(reinterpret_cast<const void*>(fast3_forward_pfuse_kernel<Q0, Q1, Q2, R1, R2>), lds, kFwdWgsPerCu, &lds_ok, &grid);
+    if (rc) return rc;
+    const uint64_t magic = (uint64_t(1) << 40) / (uint64_t)s.p[0] + 1ull;   // g / p0 = (g * magic) >> 40 for g p0 < 2^40
+    profile_begin(0, st);
+    hipLaunchKernelGGL((fast3_forward_pfuse_kernel<Q0, Q1, Q2, R1, R2>), dim3(grid), dim3(kChainWaves * 64), lds, st, cores.c[0],
+                       cores.c[1], cores.c[2], plan, (uint32_t)num_groups(s), (uint32_t)s.p[0], magic, (uint32_t)s.p[2], (uint32_t)nnz,
+                       output, (uint32_t)(B * s.D * 4));
+    profile_end(0, st);
+    return check_hip(hipGetLastError(), "fast3_forward_pfuse_kernel");
+  } else {
+    return fail(TTEMB_E_HIP, "internal: pfuse_pays() and PFuseCfg out of step");
+  }
 }
 
 template <int Q0, int Q1, int Q2, int R1, int R2>
@@ -2811,9 +3166,16 @@ int launch_forward_fast3(const DevShape& s, const CorePtrs& cores, const int64_t
     return rc;
   }
   GroupPlan plan;
+  // a whole forward (phase 0) on a frontier with few ids per group: the chain kernel forms the prefix products itself
+  const bool pfuse = phase == 0 && pfuse_pays(s, nnz);
   int rc = prepare(s, cores, false, indices, rowidx, offsets, nnz, nnz_dev, B, zero_rows ? output : nullptr, ws, ws_bytes,
-                   plan_buf, plan_bytes, phase, &plan, st, header);   // phase 0 / 1 / 2 = whole forward / ids only / lookup on a grouped plan
+                   plan_buf, plan_bytes, phase, &plan, st, header, nullptr, pfuse);   // phase 0 / 1 / 2 = whole forward / ids only / lookup on a grouped plan
   if (rc || phase == 1) return rc;
+  if (pfuse) {
+#define TTEMB_X(a, b, c, d, e) if (shape_is(s, a, b, c, d, e)) return run_forward_pfuse<a, b, c, d, e>(s, cores, plan, nnz, B, output, st);
+    TTEMB_FAST3_SHAPES(TTEMB_X)
+#undef TTEMB_X
+  }
   if (wide(s)) {
 #define TTEMB_X(a, b, c, d, e) if (shape_is(s, a, b, c, d, e)) return run_forward_direct<a, b, c, d, e>(s, cores, plan, nnz, B, output, st);
     TTEMB_WIDE3_SHAPES(TTEMB_X)
@@ -2886,8 +3248,9 @@ static int run_backward(const DevShape& s, const CorePtrs& cores, const GroupPla
   if (rc) return rc;
   const int gpw = epi_groups_per_wave(s), slices = epi_slices(s);
   constexpr int EW = EpiCfg<Q0, Q1, Q2, R1, R2>::WAVES;
+  const unsigned epi_blocks = (unsigned)((slices + EW - 1) / EW) * (unsigned)s.p[1];
   profile_begin(8, st);
-  hipLaunchKernelGGL((fast3_group_epilogue_kernel<Q0, Q1, Q2, R1, R2>), dim3((unsigned)((slices + EW - 1) / EW), (unsigned)s.p[1]),
+  hipLaunchKernelGGL((fast3_group_epilogue_kernel<Q0, Q1, Q2, R1, R2>), dim3(epi_blocks),
                      dim3(EW * 64), 0, st, cores.c[0], cores.c[1], (uint32_t)s.p[0], (uint32_t)s.p[1], (uint32_t)gpw, (uint32_t)slices, plan);
   profile_end(8, st);
   rc = check_hip(hipGetLastError(), "fast3_group_epilogue_kernel");

@@ -242,6 +242,7 @@ def plan_bytes(shape: Shape, nnz: int) -> int:
 
 
 FAMILY_SCALAR, FAMILY_PER_BAG, FAMILY_PER_BAG_RT, FAMILY_GROUPED, FAMILY_GROUPED_WIDE, FAMILY_MERGED, FAMILY_PADDED = 0, 1, 2, 3, 4, 16, 32
+FAMILY_PREFIX_IN_CHAIN = 64   # | on FAMILY_GROUPED: a whole forward of this size forms the prefix products in its chain kernel
 
 
 def kernel_family(shape: Shape, nnz: int, B: int, ids_with_offsets: bool = True) -> int:

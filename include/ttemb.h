@@ -136,7 +136,10 @@ int ttemb_set_spin_limit(int64_t tries);
  * | TTEMB_FAMILY_MERGED when a 2- or 4-core table rides on a 3-core view (a virtual core built per call),
  * | TTEMB_FAMILY_PADDED when a 3-core table whose ranks are off the instantiated list rides on the grouped kernels of the
  *   next listed rank through zero-padded copies of its cores (same rows, same gradients: the added rank positions hold
- *   zeros). */
+ *   zeros),
+ * | TTEMB_FAMILY_PREFIX_IN_CHAIN when a whole ttemb_forward of this size forms the prefix products G0[i0].G1[i1] inside
+ *   its chain kernel (fewer than ~4 ids per (i0, i1) group on average: 819 200 ids on the papers100M table) instead of in
+ *   a launch of its own; the plan it leaves and every result are the same. */
 enum {
   TTEMB_FAMILY_SCALAR = 0,
   TTEMB_FAMILY_PER_BAG = 1,
@@ -144,7 +147,8 @@ enum {
   TTEMB_FAMILY_GROUPED = 3,
   TTEMB_FAMILY_GROUPED_WIDE = 4,
   TTEMB_FAMILY_MERGED = 16,
-  TTEMB_FAMILY_PADDED = 32
+  TTEMB_FAMILY_PADDED = 32,
+  TTEMB_FAMILY_PREFIX_IN_CHAIN = 64
 };
 int ttemb_kernel_family(const ttemb_shape_t* shape, int64_t nnz, int64_t B, int32_t ids_with_offsets);
 

@@ -803,7 +803,7 @@ def test_shapes_off_the_instantiated_list(nat, orc, p, q, r, n_ids):
     shape = nat.make_shape(p, q, R)
     rng = np.random.default_rng(sum(p) + sum(q) + sum(r) + n_ids)
     idx, offsets = _random_bags(rng, int(np.prod(p)), n_ids)
-    fam = nat.kernel_family(shape, int(idx.shape[0]), int(offsets.shape[0] - 1), True)
+    fam = nat.kernel_family(shape, int(idx.shape[0]), int(offsets.shape[0] - 1), True) & ~nat.FAMILY_PREFIX_IN_CHAIN
     # past the grouped crossover a 3-core table whose q shape is instantiated at a higher rank rides on the grouped kernels
     # through zero-padded cores (4,5,5 at 12 -> 16, 24 -> 32, (6, 7) -> 8); everything else runs the run-time-shape kernels
     padded = T == 3 and tuple(q) == (4, 5, 5) and max(r) <= 32 and idx.shape[0] >= 4096
@@ -812,7 +812,7 @@ def test_shapes_off_the_instantiated_list(nat, orc, p, q, r, n_ids):
     else:
         assert fam & ~nat.FAMILY_MERGED == nat.FAMILY_PER_BAG_RT, f"kernel family {fam}"
         assert bool(fam & nat.FAMILY_MERGED) == (T != 3)
-    assert nat.kernel_family(shape, int(idx.shape[0]), int(offsets.shape[0] - 1), False) in (
+    assert nat.kernel_family(shape, int(idx.shape[0]), int(offsets.shape[0] - 1), False) & ~nat.FAMILY_PREFIX_IN_CHAIN in (
         nat.FAMILY_SCALAR, nat.FAMILY_GROUPED | nat.FAMILY_PADDED)   # (a row index, no offsets: no per-bag kernels)
     cores = [(rng.standard_normal((p[t], R[t] * q[t] * R[t + 1])) * 0.4).astype(np.float32) for t in range(T)]
     want = orc.tt_forward(idx, offsets, cores, p, q, R)
@@ -1000,7 +1000,7 @@ def test_ranks_off_the_list_ride_on_the_grouped_path(nat, orc, q, r, Rpad):
     rng = np.random.default_rng(sum(r) + Rpad)
     idx, offsets = _random_bags(rng, int(np.prod(p)), 30000)
     nnz, B = int(idx.shape[0]), int(offsets.shape[0] - 1)
-    fam = nat.kernel_family(shape, nnz, B, True)
+    fam = nat.kernel_family(shape, nnz, B, True) & ~nat.FAMILY_PREFIX_IN_CHAIN
     want_fam = (nat.FAMILY_GROUPED_WIDE if Rpad >= 64 else nat.FAMILY_GROUPED) | nat.FAMILY_PADDED
     assert fam == want_fam, f"kernel family {fam}"
     assert nat.plan_bytes(shape, nnz) > 0
@@ -1044,7 +1044,7 @@ def test_an_expired_wait_gives_nan_and_an_error_never_plausible_numbers(nat, orc
     offs = np.arange(n + 1, dtype=np.int64)
     shape = nat.make_shape(p, q, R)
     nat.set_path(nat.PATH_FAST3)
-    assert nat.kernel_family(shape, n, n) in (nat.FAMILY_GROUPED, nat.FAMILY_GROUPED_WIDE)
+    assert nat.kernel_family(shape, n, n) & ~nat.FAMILY_PREFIX_IN_CHAIN in (nat.FAMILY_GROUPED, nat.FAMILY_GROUPED_WIDE)
     ws = nat.Workspace()
     c = [dev(x) for x in cores]
     idx, o = dev(ids), dev(offs)
@@ -1089,3 +1089,52 @@ def test_an_expired_wait_gives_nan_and_an_error_never_plausible_numbers(nat, orc
     tol = 2e-4 if wide else 1e-4   # (split-bf16 GEMMs of the wide chain: fp32-grade, see test_wide_rank_gemms_keep_fp32_accuracy)
     assert_grads_close([g.cpu().numpy() for g in grads], want_g, rel=tol)
     nat.status()
+
+
+# ---------------------------------------------------------------------------------------
+# frontiers with few ids per group: the forward forms the prefix products inside its chain kernel
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("q,r", [([8, 4, 4], [32, 32]), ([4, 4, 8], [16, 16]), ([4, 5, 5], [16, 16]), ([5, 5, 4], [16, 16]),
+                                 ([4, 5, 5], [8, 8]), ([4, 4, 8], [8, 8]), ([5, 4, 5], [16, 16]), ([4, 5, 5], [32, 32])])
+@pytest.mark.parametrize("p0", [40, 41])
+def test_forward_with_the_prefix_products_formed_in_the_chain_kernel(nat, orc, q, r, p0):
+    """~3 ids per (i0, i1) group: ttemb_forward takes fast3_forward_pfuse_kernel (asked from the library).  Batches of 16 / q0
+    groups -- 2 (q0 = 8), 3 with an idle tile row (q0 = 5), 4 (q0 = 4) --, a p0 the batch size does not divide (a short
+    batch at the end of every i1), the masked column tile of q1 r2 = 40 (rank 8), ragged bags with duplicates and empty bags.
+    Rows against the oracle; then the dense backward and the fused SGD step ON THE FORWARD'S PLAN, whose prefix products the
+    forward's chain kernel stored: gradients and cores against the oracle."""
+    p = [p0, 50, 30]
+    R = [1] + r + [1]
+    shape = nat.make_shape(p, q, R)
+    rng = np.random.default_rng(p0 + sum(q) + sum(r))
+    idx, offsets = _random_bags(rng, int(np.prod(p)), 6000)
+    nnz, B = int(idx.shape[0]), int(offsets.shape[0] - 1)
+    nat.set_path(nat.PATH_FAST3)
+    assert nat.kernel_family(shape, nnz, B, True) == nat.FAMILY_GROUPED | nat.FAMILY_PREFIX_IN_CHAIN
+    cores = [(rng.standard_normal((p[t], R[t] * q[t] * R[t + 1])) * 0.4).astype(np.float32) for t in range(3)]
+    want = orc.tt_forward(idx, offsets, cores, p, q, R)
+    c = [dev(x) for x in cores]
+    t_idx, t_offs = dev(idx, torch.int64), dev(offsets, torch.int64)
+    ws = nat.Workspace()
+    plan = nat.new_plan(shape, nnz, t_idx.device)
+    out = torch.full((B, int(np.prod(q))), float("nan"), device="cuda")
+    nat.forward(shape, c, t_idx, None, t_offs, nnz, None, B, out, ws, plan)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-5, atol=1e-4)
+    d_out = ((rng.random(want.shape) - 0.5) * 0.2).astype(np.float32)
+    want_g = orc.tt_dense_backward(idx, offsets, d_out, cores, p, q, R)
+    grads = [torch.full_like(x, float("nan")) for x in c]
+    nat.backward_dense(shape, c, t_idx, None, nnz, None, B, dev(d_out), grads, ws, plan, t_offs)
+    torch.cuda.synchronize()
+    assert_grads_close([g.cpu().numpy() for g in grads], want_g)
+    # the same gradients from a backward that builds its own plan (prefix launch): the two P tables agree
+    grads2 = [torch.full_like(x, float("nan")) for x in c]
+    nat.backward_dense(shape, c, t_idx, None, nnz, None, B, dev(d_out), grads2, ws, None, t_offs)
+    torch.cuda.synchronize()
+    assert_grads_close([g.cpu().numpy() for g in grads2], want_g)
+    lr = 0.05
+    c2 = [x.clone() for x in c]
+    nat.backward_sgd(shape, c2, t_idx, None, nnz, None, B, dev(d_out), lr, ws, plan, t_offs)
+    torch.cuda.synchronize()
+    for got, w0, g in zip(c2, cores, want_g):
+        np.testing.assert_allclose(got.cpu().numpy(), w0 - lr * g, rtol=0, atol=1e-5 + 1e-4 * float(np.abs(lr * g).max()))

@@ -77,7 +77,7 @@ def main():
         out = torch.empty(N, D, device="cuda")
         d_out = (torch.rand(N, D, device="cuda") - 0.5) * 0.1
         grads = [torch.empty_like(c) for c in cores]
-        f, b, c, g = [], [], [], []
+        f, b, c, g, ep, fi = [], [], [], [], [], []
         for i in range(a.iters + 3):
             if a.what in ("both", "fwd"):
                 if a.split:
@@ -97,12 +97,19 @@ def main():
                 if i >= 3:
                     b.append(nat.profile_read(1))
                     c.append(nat.profile_read(2))
+                    try:
+                        ep.append(nat.profile_read(8))
+                        fi.append(nat.profile_read(9))
+                    except RuntimeError:   # (kernel families without these two kernels)
+                        pass
         torch.cuda.synchronize()
         msg = f"{a.cfg} {a.dist} N={N}:"
         if f:
             msg += f" grouping {np.mean(g)*1e3:6.1f} us fwd {np.mean(f)*1e3:8.1f} us ({N/np.mean(f)/1e6:8.2f} G lookups/s)"
         if b:
             msg += f" bwd {np.mean(b)*1e3:8.1f} us ({N/np.mean(b)/1e6:8.2f} G lookups/s) [chunk kernel {np.mean(c)*1e3:7.1f} us]"
+            if ep:
+                msg += f" [epilogue {np.mean(ep)*1e3:5.1f} finalize {np.mean(fi)*1e3:5.1f} us]"
         print(msg, flush=True)
 
 
