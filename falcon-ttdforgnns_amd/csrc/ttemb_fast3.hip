@@ -3117,6 +3117,26 @@ static int run_backward_wide(const DevShape& s, const CorePtrs& cores, const Gro
     g.a_batch = M * N1; g.b_batch = (uint32_t)C::ROW1; g.c_batch = M * R1;
     g.a_bytes = M * N1 * 4; g.b_bytes = (uint32_t)C::ROW1 * 4; g.c_bytes = M * R1 * 4;
     g.tiles_m = (M + 63) / 64; g.tiles_n = R1 / 64;
+#ifndef TTEMB_WIDE_DG0_DIRECT
+    if (R1 % kLdsGemmBlock == 0 && N1 % kLdsGemmK == 0) {   // ranks 128 / 256: through LDS (see wide3_gemm_lds_kernel)
+      static LdsGate lds_ok;
+      rc = allow_big_lds(reinterpret_cast<const void*>(wide3_gemm_lds_kernel), kLdsGemmBytes, &lds_ok, "wide3_gemm_lds_kernel");
+      if (rc) return rc;
+      g.tiles_m = (M + kLdsGemmBlock - 1) / kLdsGemmBlock;   // (128 x 128 blocks)
+      g.tiles_n = R1 / kLdsGemmBlock;
+      g.rows = plan.wrows;
+      g.n_rows = plan.wnrows;
+      g.rows_stride = (uint32_t)wide_rows_stride(s);
+      g.full = M;
+      g.batches = (uint32_t)s.p[1];
+      g.splits = 1;
+      g.k_chunk = N1;
+      g.c_slice = 0;
+      const dim3 grid((g.tiles_m * g.tiles_n * g.batches + 7u) / 8u * 8u);   // 1-D, a multiple of the 8 XCDs
+      hipLaunchKernelGGL(wide3_gemm_lds_kernel, grid, dim3(256), kLdsGemmBytes, st, g);
+      rc = check_hip(hipGetLastError(), "wide3_gemm_lds_kernel (dG0)");
+    } else
+#endif
     rc = run_wide_gemm<true, true, 1>(g, s, plan, st, "wide3_gemm_kernel (dG0)");
     if (rc) return rc;
   }
