@@ -318,8 +318,16 @@ static Merged4 merge_first_two(const DevShape& s, int64_t nnz, int64_t B, bool p
     return m;
   }
   if (per_bag_ok) {   // first pair merged: the per-id operand stays the last core
+    // The virtual core is REBUILT by every forward and split back (over all p0 p1 rows, gradients zero-filled) by every
+    // backward, whatever nnz is: O(p0 p1 row) next to the scalar kernels' O(nnz).  The run scripts' 4-core tables have
+    // 3 000-row virtual cores (0.4-1.5 MB: a few microseconds); a table with a large first pair takes this view only when
+    // the batch amortises the rebuild -- at least one id per 16 rows of V -- or V is small anyway (<= 4 MB).  A conservative
+    // gate, not a measured crossover (no script trains such a table).
     DevShape d;
-    if (view3(s, 0, &d) && small3_supported(d) && (long long)s.p[0] * s.p[1] * d.row_len[0] * 4 <= (256ll << 20)) fill(0, d, true);
+    if (view3(s, 0, &d) && small3_supported(d)) {
+      const long long v_rows = (long long)s.p[0] * s.p[1], v_bytes = v_rows * d.row_len[0] * 4;
+      if (v_bytes <= (256ll << 20) && (v_bytes <= (4ll << 20) || nnz * 16 >= v_rows)) fill(0, d, true);
+    }
   }
   return m;
 }

@@ -69,6 +69,20 @@ def test_workspace_and_plan_sizes_follow_the_kernel_family():
     assert lib.ttemb_set_path(4) == -1
 
 
+def test_a_large_merged_first_pair_needs_a_batch_that_amortises_its_rebuild():
+    """4-core table, per-bag route (below the grouped crossover): the virtual first core G0.G1 is rebuilt per call, so a table
+    whose first pair is large takes the merged per-bag view only for batches of at least one id per 16 rows of it; small
+    virtual cores (the run scripts' 3 000 rows) always do.  Host-side decision only: ttemb_kernel_family launches nothing."""
+    small = nat.make_shape([50, 60, 60, 60], [2, 4, 4, 4], [16, 16, 16])        # V: 3 000 rows x 128 floats = 1.5 MB
+    large = nat.make_shape([700, 800, 60, 60], [2, 4, 4, 4], [16, 16, 16])      # V: 560 000 rows x 128 floats = 287 MB > 256 MB: never
+    medium = nat.make_shape([300, 400, 60, 60], [2, 4, 4, 4], [16, 16, 16])     # V: 120 000 rows = 61 MB
+    merged = lambda shp, n: bool(nat.kernel_family(shp, n, n, True) & nat.FAMILY_MERGED)
+    assert merged(small, 8) and merged(small, 2048)
+    assert not merged(large, 2048)
+    assert not merged(medium, 256)           # 256 ids against 120 000 rows of V: the scalar kernels
+    assert merged(medium, 120000 // 16)      # one id per 16 rows: the merged per-bag view
+
+
 def test_suggested_shapes_match_reference_answers():
     t = load_golden("suggest_kat")["table"]
     for row in t.tolist():
