@@ -233,12 +233,18 @@ struct GroupPlan {           // device pointers into the caller's plan buffer / 
 // kernel that would walk its chunk table leaves instead, the forward fills the output window with NaN, the finalize kernel
 // emits NaN for every gradient element (fused modes: NaN weights) -- and the pinned host word makes the next API call of
 // the process return TTEMB_E_HIP (ttemb_status() asks for it directly).  Tags carry the call's number with the top bit set,
-// like every word of the grouping pass: what a recycled buffer held never reads as a fault.
+// like every word of the grouping pass: what a recycled buffer held never reads as a fault.  The number is SALTED with the
+// address of the workspace header it is counted in: a plan buffer may outlive a workspace, two workspaces count alike (both
+// from whatever their memory held: zeros, often), and a fault word a faulted call left in the buffer must not meet a later
+// call of ANOTHER workspace that happens to carry the same number.
 // ---------------------------------------------------------------------------------
 constexpr uint32_t kFaultTakeOver = 1u, kFaultLookBack = 2u;
-__device__ __forceinline__ uint64_t plan_tag(uint64_t call) { return ((call & ((1ull << 39) - 1ull)) | (1ull << 39)) << 24; }
+__device__ __forceinline__ uint64_t plan_tag(const GroupPlan& plan, uint64_t call) {
+  const uint64_t salt = (reinterpret_cast<uint64_t>(plan.epochs) >> 8) * 0x9e3779b97f4a7c15ull;
+  return (((call + salt) & ((1ull << 39) - 1ull)) | (1ull << 39)) << 24;
+}
 __device__ __forceinline__ void report_fault(const GroupPlan& plan, uint32_t G, uint64_t call, uint32_t code) {
-  __hip_atomic_store(&plan.gpre[G + 2u], plan_tag(call) | code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(&plan.gpre[G + 2u], plan_tag(plan, call) | code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (plan.fault_host != nullptr) __hip_atomic_store(plan.fault_host, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // wave-uniform (scalar loads next to the chunk total every chain kernel reads first)
@@ -619,7 +625,13 @@ __device__ __forceinline__ void place_range(const uint32_t range, const uint32_t
   if (threadIdx.x == 0) {
     if (range == ranges - 1) {
       plan.gpre[G] = (uint64_t)n1 | ((chunk_base + chunks_here) << 32);   // (live ids, chunks)
-      plan.gpre[G + 1u] = epoch << 24;   // the plan's tag (= plan_tag(epochs[1])): a fault word with this tag poisons it
+      const uint64_t ptag = plan_tag(plan, plan.epochs[1]);
+      plan.gpre[G + 1u] = ptag;   // the plan's tag: a fault word with this tag poisons it
+      // a fault word of another call (a buffer that once held a faulted plan; whatever a recycled buffer held) is cleared on
+      // the way.  Compare-and-swap: a report of THIS call that lands in between stays.
+      unsigned long long* fw = reinterpret_cast<unsigned long long*>(&plan.gpre[G + 2u]);
+      const unsigned long long seen = __hip_atomic_load(fw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((seen >> 24) != (ptag >> 24) && seen != 0ull) atomicCAS(fw, seen, 0ull);
       // how many groups hold an id at all: the backward's epilogue / finalize pick their sparse or dense form by it
       plan.counts[G] = (uint32_t)live_all + live_here;
     }

@@ -1089,6 +1089,24 @@ def test_an_expired_wait_gives_nan_and_an_error_never_plausible_numbers(nat, orc
     tol = 2e-4 if wide else 1e-4   # (split-bf16 GEMMs of the wide chain: fp32-grade, see test_wide_rank_gemms_keep_fp32_accuracy)
     assert_grads_close([g.cpu().numpy() for g in grads], want_g, rel=tol)
     nat.status()
+    # A stale fault word must never meet a later call that carries the same call number: call numbers live in the workspace
+    # header and two zero-filled workspaces count alike.  Call no. 1 of workspace A faults into the plan buffer; call no. 1 of
+    # workspace B builds a sound plan in the SAME buffer -- the place step clears the other call's word.
+    big = nat.workspace_bytes(shape, nat.OP_BACKWARD, n, n) * 2
+    ws_a, ws_b = nat.Workspace(), nat.Workspace()
+    ws_a.buf = torch.zeros(big, dtype=torch.uint8, device="cuda")
+    ws_b.buf = torch.zeros(big, dtype=torch.uint8, device="cuda")
+    nat.set_spin_limit(-1)
+    nat.forward(shape, c, idx, None, o, n, None, n, out, ws_a, plan=plan)
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(out).all())
+    with pytest.raises(RuntimeError, match="gave up waiting"):
+        nat.status()
+    nat.set_spin_limit(0)
+    nat.forward(shape, c, idx, None, o, n, None, n, out, ws_b, plan=plan)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-5, atol=1e-4)
+    nat.status()
 
 
 # ---------------------------------------------------------------------------------------
