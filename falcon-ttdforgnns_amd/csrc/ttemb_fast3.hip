@@ -1163,9 +1163,12 @@ __global__ __launch_bounds__(kChainWaves * 64, 2) void fast3_forward_pfuse_kerne
   const uint32_t rowpiece = 16u * (uint32_t)j_l;
   const uint32_t g_last = (F4G % 4 == 0 || j_l + 4 * (NLG - 1) < F4G) ? rowpiece + 64u * (NLG - 1) : kOobBase;
   const bool o_has_last = D4 % 4 == 0 || j_l + 4 * (NLO - 1) < D4;
-  // the P product of a batch: A row lo = (group lo / q0 of the batch, core row lo % q0), k = 4 s + hi
+  // the P product of a batch: row lo = (group lo / q0 of the batch, core row lo % q0).  The K order is permuted: lane group
+  // hi owns k = KPH hi + {0 .. KPH-1} (KPH = r1 / 4 consecutive k), MFMA step s multiplies k = KPH hi + s -- so that a
+  // lane's KS1 values of its G0 row are KPH / 4 16-byte loads instead of KS1 dword loads; the G1 operand is loaded to match
+  constexpr int KPH = R1 / 4;
   const uint32_t a_grp = (uint32_t)lo / Q0;                                   // (q0 = 5: row 15 belongs to no group)
-  const uint32_t a_off = (uint32_t)((lo % Q0) * R1 + hi) * 4u;
+  const uint32_t a_off = (uint32_t)((lo % Q0) * R1 + KPH * hi) * 4u;
 
   // where a chunk's group sits: its i1, the first i0 of its batch, its slot in the batch, and whether the chunk OPENS a batch
   // (the batch differs from the one requested last; chunks are met in group order, so a batch is opened once per wavefront)
@@ -1196,8 +1199,16 @@ __global__ __launch_bounds__(kChainWaves * 64, 2) void fast3_forward_pfuse_kerne
     // the batch's rows of G0 when the chunk opens one (else the loads fall off the buffer: the instruction stream is fixed)
     const uint32_t i0a = gp.i0b + a_grp;
     const uint32_t base = (gp.fresh && a_grp < (uint32_t)GM && i0a < p0) ? i0a * (uint32_t)(C::ROW0 * 4) + a_off : kOobBase;
+    if constexpr (KPH % 4 == 0) {
 #pragma unroll
-    for (int s = 0; s < C::KS1; ++s) pre_a[s] = __uint_as_float(buf_load1u(r_g0, base + 16u * s));
+      for (int v = 0; v < KPH / 4; ++v) {
+        const float4 x = buf_load4(r_g0, base + 16u * v);
+        pre_a[4 * v] = x.x; pre_a[4 * v + 1] = x.y; pre_a[4 * v + 2] = x.z; pre_a[4 * v + 3] = x.w;
+      }
+    } else {   // rank 8: two consecutive k per lane group
+#pragma unroll
+      for (int s = 0; s < C::KS1; ++s) pre_a[s] = __uint_as_float(buf_load1u(r_g0, base + 4u * s));
+    }
   };
   auto stage_rows = [&]() {   // G2 rows: registers -> LDS
 #pragma unroll
@@ -1215,7 +1226,7 @@ __global__ __launch_bounds__(kChainWaves * 64, 2) void fast3_forward_pfuse_kerne
       for (int s = 0; s < C::KS1; ++s)
 #pragma unroll
         for (int nt = 0; nt < C::NT1; ++nt)
-          bvp[s][nt] = (C::N1 % 16 == 0 || 16 * nt + lo < C::N1) ? g1[(4 * s + hi) * C::N1 + 16 * nt + lo] : 0.f;
+          bvp[s][nt] = (C::N1 % 16 == 0 || 16 * nt + lo < C::N1) ? g1[(KPH * hi + s) * C::N1 + 16 * nt + lo] : 0.f;   // k = KPH hi + s
       cur_i1 = gp.i1;
     }
     // The product is formed TRANSPOSED -- G1[i1]^T (rows n = (j, c2)) times the batch's G0 rows (columns (group, a)) -- with
@@ -1279,19 +1290,32 @@ __global__ __launch_bounds__(kChainWaves * 64, 2) void fast3_forward_pfuse_kerne
 
     TTEMB_PRIO(0);
     // ---- stage 2: (q0 q1 x r2) . (r2 x 16 q2), P from the group's slot of the batch ----
+    // (the K order of this product is permuted as well: lane group hi owns c2 = KPH2 hi + {0 .. KPH2-1}, so that a lane's
+    //  KS2 values of its row of P are 16-byte LDS reads -- 4 instead of 16 per chunk at rank 32 -- and the G2 operand follows)
+    constexpr int KPH2 = R2 / 4;
     const float* pslot = pbuf + g_cur.slot * PC::SLOT_FLOATS;
     float av[C::MT2][C::KS2];
 #pragma unroll
-    for (int mt = 0; mt < C::MT2; ++mt)
+    for (int mt = 0; mt < C::MT2; ++mt) {
+      const int m = 16 * mt + lo;
+      if constexpr (KPH2 % 4 == 0) {
 #pragma unroll
-      for (int s = 0; s < C::KS2; ++s) av[mt][s] = pslot[(16 * mt + lo) * R2 + ((4 * s) ^ PC::swz(16 * mt + lo)) + hi];
+        for (int v = 0; v < KPH2 / 4; ++v) {
+          const float4 x = *reinterpret_cast<const float4*>(pslot + m * R2 + ((KPH2 * hi + 4 * v) ^ PC::swz(m)));
+          av[mt][4 * v] = x.x; av[mt][4 * v + 1] = x.y; av[mt][4 * v + 2] = x.z; av[mt][4 * v + 3] = x.w;
+        }
+      } else {   // rank 8: two consecutive c2 per lane group, inside one 16-byte quad
+#pragma unroll
+        for (int s = 0; s < C::KS2; ++s) av[mt][s] = pslot[m * R2 + (((KPH2 * hi + s) & ~3) ^ PC::swz(m)) + ((KPH2 * hi + s) & 3)];
+      }
+    }
     float bv[C::NT2][C::KS2];
 #pragma unroll
     for (int nt = 0; nt < C::NT2; ++nt) {
       if ((uint32_t)(16 * nt) < len * Q2) {
         const int n = 16 * nt + lo;
 #pragma unroll
-        for (int s = 0; s < C::KS2; ++s) bv[nt][s] = bbuf[(n / Q2) * C::LDB + (4 * s + hi) * Q2 + n % Q2];
+        for (int s = 0; s < C::KS2; ++s) bv[nt][s] = bbuf[(n / Q2) * C::LDB + (KPH2 * hi + s) * Q2 + n % Q2];
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
