@@ -3038,21 +3038,25 @@ static int run_forward(const DevShape& s, const CorePtrs& cores, const GroupPlan
 }
 
 // Frontiers with few ids per group form the prefix products inside the chain kernel (fast3_forward_pfuse_kernel).  The rule
-// looks at the call's size only (the occupancy of the groups is known on the device alone): fewer than kPFuseIdsPerGroup ids
-// per group on average.  Measured crossover: see profiles/r04_pfuse_forward.txt.
+// looks at the call's size only (the occupancy of the groups is known on the device alone): fewer than `limit` ids per group
+// on average.  Measured crossovers (profiles/r04_pfuse_forward.txt, grouping + chain kernel, uniform ids): q = 4,4,8 rank 16
+// at 9-10 ids per group; q = 4,5,5 at ranks 16 / 32 and q = 5,5,4 rank 8 at 16-20 (gains of 2-4 % above 8); q0 = 8 (two
+// groups per tile: the prefix launch costs most there) -11 ... -17 % still at 15 ids per group, on the papers100M table
+// -17 % at 8.8.  Hence 8, and 16 for q0 = 8.  (TTEMB_PFUSE_IDS: 0 switches the route off, another value replaces both.)
 #ifndef TTEMB_PFUSE_IDS
-#define TTEMB_PFUSE_IDS 4
+#define TTEMB_PFUSE_IDS -1
 #endif
 constexpr int64_t kPFuseIdsPerGroup = TTEMB_PFUSE_IDS;
+static int64_t pfuse_limit(const DevShape& s) { return kPFuseIdsPerGroup >= 0 ? kPFuseIdsPerGroup : (s.q[0] == 8 ? 16 : 8); }
 template <int Q0, int Q1, int Q2, int R1, int R2>
 static bool pfuse_shape() { return PFuseCfg<Q0, Q1, Q2, R1, R2>::ok; }
 static bool pfuse_pays(const DevShape& s, int64_t nnz) {
-  if (kPFuseIdsPerGroup <= 0 || !classify(s)) return false;
+  if (pfuse_limit(s) <= 0 || !classify(s)) return false;
   bool ok = false;
 #define TTEMB_X(a, b, c, d, e) if (shape_is(s, a, b, c, d, e)) ok = pfuse_shape<a, b, c, d, e>();
   TTEMB_FAST3_SHAPES(TTEMB_X)
 #undef TTEMB_X
-  return ok && nnz < kPFuseIdsPerGroup * num_groups(s);
+  return ok && nnz < pfuse_limit(s) * num_groups(s);
 }
 
 bool fast3_prefix_in_chain(const DevShape& s, int64_t nnz, int64_t B) { return fits_piece(s, nnz, B) && pfuse_pays(s, nnz); }

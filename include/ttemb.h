@@ -138,7 +138,7 @@ int ttemb_set_spin_limit(int64_t tries);
  *   next listed rank through zero-padded copies of its cores (same rows, same gradients: the added rank positions hold
  *   zeros),
  * | TTEMB_FAMILY_PREFIX_IN_CHAIN when a whole ttemb_forward of this size forms the prefix products G0[i0].G1[i1] inside
- *   its chain kernel (fewer than ~4 ids per (i0, i1) group on average: 819 200 ids on the papers100M table) instead of in
+ *   its chain kernel (fewer than 8 ids per (i0, i1) group on average, 16 for q0 = 8: 819 200 ids on the papers100M table) instead of in
  *   a launch of its own; the plan it leaves and every result are the same. */
 enum {
   TTEMB_FAMILY_SCALAR = 0,
