@@ -757,7 +757,9 @@ def test_fast_path_with_a_device_side_live_count(nat, orc, live, wide):
         torch.cuda.synchronize()
         ref = orc.tt_dense_backward(idx[:live], np.arange(live + 1), d_out[:live], cores, p, q, R)
         assert_grads_close([g.cpu().numpy() for g in grads], ref, rel=2e-4)
-    assert np.array_equal(outs[0], outs[1])
+    # the whole forward of a sparse-group frontier forms its prefix products inside the chain kernel (with a permuted K order),
+    # the two-phase forward in a launch of their own: the same rows up to the order of the fp32 sums
+    np.testing.assert_allclose(outs[0], outs[1], rtol=2e-6, atol=2e-6)
 
 
 # ---------------------------------------------------------------------------------------
