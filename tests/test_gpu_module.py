@@ -723,6 +723,47 @@ def test_captured_lookup_on_the_wide_rank_chain(ops):
             torch.testing.assert_close(cb.data, ca.data, rtol=1e-4, atol=1e-5 * float(ca.data.abs().max()))
 
 
+@pytest.mark.parametrize("n", [20000, 200000])
+def test_captured_lookup_on_the_grouped_chain(ops, orc, n):
+    """emb.capture() on the narrow grouped chain (products shape): 20 000 ids take the forward that forms its prefix products
+    in the chain kernel (1.1 ids per group), 200 000 the prefix launch (11 per group); grouping pass with its call counter on
+    the device, chain kernels and the fused backward replay from HIP graphs -- three steps with different ids through the same
+    graphs -- give the oracle's rows and train like the eager module; nothing is pending on the fault word afterwards."""
+    import ttemb_native as nat
+    torch.manual_seed(13)
+    p, q, r = [125, 140, 140], [4, 5, 5], [16, 16]
+    n_emb = 2449029
+    mk = lambda: ops.TTEmbeddingBag(n_emb, 100, r, p, q, optimizer=ops.OptimType.SGD, sparse=True, use_cache=False,
+                                    weight_dist="normal", learning_rate=0.05)
+    a, b = mk(), mk()
+    for ca, cb in zip(a.tt_cores, b.tt_cores):
+        ca.data.mul_(300.0)
+        cb.data.copy_(ca.data)
+    fam = nat.kernel_family(nat.make_shape(p, q, [1] + r + [1]), n, n, True)
+    assert fam == nat.FAMILY_GROUPED | (nat.FAMILY_PREFIX_IN_CHAIN if n < 8 * p[0] * p[1] else 0)
+    cap = b.capture(n, n)
+    rng = np.random.default_rng(14)
+    offs = torch.arange(n + 1).cuda()
+    for step in range(3):
+        ids_np = rng.choice(n_emb, size=n, replace=False).astype(np.int64)
+        ids = torch.tensor(ids_np).cuda()
+        d = torch.tensor(((rng.random((n, 100)) - 0.5) * 0.05).astype(np.float32)).cuda()
+        if step == 0:
+            cores_np = [c.detach()[0].cpu().numpy() for c in b.tt_cores]
+            want = orc.tt_rows(ids_np[:2000], cores_np, p, q, [1] + r + [1])
+        out_a = a(ids, offs)
+        out_b = cap(ids)
+        if step == 0:
+            np.testing.assert_allclose(out_b.detach()[:2000].cpu().numpy(), want, rtol=1e-5, atol=1e-4)
+        torch.testing.assert_close(out_b, out_a, rtol=1e-5, atol=2e-6)
+        out_a.backward(d)
+        out_b.backward(d)
+        torch.cuda.synchronize()
+        for ca, cb in zip(a.tt_cores, b.tt_cores):   # (summation order inside a group comes from LDS atomics: rounding only)
+            torch.testing.assert_close(cb.data, ca.data, rtol=1e-4, atol=1e-6)
+    nat.status()
+
+
 @pytest.mark.parametrize("one_sweep", [False, True])
 def test_lfu_update_on_a_colliding_stream(orc, one_sweep):
     """cache_update on a table that is far too small for its stream (H = 96, hundreds of distinct ids): whatever the

@@ -83,6 +83,16 @@ def test_a_large_merged_first_pair_needs_a_batch_that_amortises_its_rebuild():
     assert merged(medium, 120000 // 16)      # one id per 16 rows: the merged per-bag view
 
 
+def test_status_and_spin_limit_are_host_side_calls():
+    """ttemb_status() reads a pinned host word that exists only after a grouped lookup has run: without one (and without a
+    GPU) it reports nothing; the spin limit is a process-wide diagnostic value."""
+    nat.status()
+    nat.set_spin_limit(-1)
+    nat.set_spin_limit(123)
+    nat.set_spin_limit(0)
+    nat.status()
+
+
 def test_suggested_shapes_match_reference_answers():
     t = load_golden("suggest_kat")["table"]
     for row in t.tolist():
