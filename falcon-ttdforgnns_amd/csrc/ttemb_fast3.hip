@@ -965,7 +965,11 @@ __global__ __launch_bounds__(kChainWaves * 64) void fast3_forward_kernel(const f
   uint4 d_n3 = load_desc(ctab, c0 + 3, c1);
   uint32_t i2_nn, val_cur;
   {
+#if defined(TTEMB_ABL) && (TTEMB_ABL & 256)   // (ablation 256: the first two chunks' rows are requested without waiting for their i2 -- wrong rows, timing only)
+    const uint32_t i2_a = (uint32_t)b_l, i2_b = (uint32_t)b_l + 16u;
+#else
     const uint32_t i2_a = fetch_i2(d_cur), i2_b = fetch_i2(d_nxt);
+#endif
     uint4 d0 = d_cur;   // a share may begin inside a group: its first chunk needs P whatever its flags say
     d0.z |= kFirstBit;
     request(__umul24(i2_a, (uint32_t)(C::ROW2 * 4)), d0);   // i2 < p2 <= 4096
