@@ -2631,7 +2631,9 @@ static std::atomic<int64_t> g_spin_limit{0};
 void fast3_set_spin_limit(int64_t tries) { g_spin_limit.store(tries); }
 static uint32_t spin_limit() {
   const int64_t t = g_spin_limit.load();
-  return t == 0 ? (1u << 16) : (t < 0 ? 0u : (t > 0x7fffffffll ? 0x7fffffffu : (uint32_t)t));
+  // default 2^20 tries (~1.5 s of s_sleep + load per waiter): an expiry is an ERROR now (NaN results), so the bound is generous --
+  // it only has to end a wait that will never be answered
+  return t == 0 ? (1u << 20) : (t < 0 ? 0u : (t > 0x7fffffffll ? 0x7fffffffu : (uint32_t)t));
 }
 // DIAGNOSTIC (ttemb_set_piece_limits): tests cut small calls into pieces with it; 0 = the hardware's limits
 static std::atomic<int64_t> g_piece_rows{0}, g_piece_ids{0};

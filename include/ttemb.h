@@ -120,7 +120,7 @@ int ttemb_set_piece_limits(int64_t rows, int64_t ids);
  *   - the reason is stored to a pinned host word, and the next ttemb_forward* / ttemb_backward* call of the process that
  *     sees it returns TTEMB_E_HIP with a message (once per fault; no synchronisation is added for this).
  * ttemb_status() is that check as a call of its own, for callers that synchronise: 0, or TTEMB_E_HIP (and the fault is
- * consumed).  ttemb_set_spin_limit is a DIAGNOSTIC, process-wide: tries of those waits (0 = the default of 65 536;
+ * consumed).  ttemb_set_spin_limit is a DIAGNOSTIC, process-wide: tries of those waits (0 = the default of 2^20, about 1.5 s;
  * negative = none at all, every wait expires -- how tests reach the fault path). */
 int ttemb_status(void);
 int ttemb_set_spin_limit(int64_t tries);
