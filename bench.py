@@ -53,6 +53,34 @@ def _launch_ranks(n):
     return subprocess.run(cmd, env=env).returncode
 
 
+def spread(ms):
+    """min / median / max (+ the two largest) of per-step times in ms: what tells a slow box from a few slow steps."""
+    a = np.sort(np.asarray(ms, dtype=np.float64))
+    return {"min": round(float(a[0]), 4), "median": round(float(np.median(a)), 4), "max": round(float(a[-1]), 4),
+            "p90": round(float(a[int(0.9 * (len(a) - 1))]), 4), "n": int(len(a))}
+
+
+def timed_steps(fn, n, before=None, after=None):
+    """n steps between two host fences: wall clock per step, and the GPU's own clock -- one HIP event on the compute stream
+    at every step boundary (torch's current stream is the stream the library launches on), so the line can tell host from
+    GPU and a slow step from a slow box.  `before` / `after`: fences (after() runs before the last event is read)."""
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+    if before is not None:
+        before()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    evs[0].record()
+    for i in range(n):
+        fn(i)
+        evs[i + 1].record()
+    if after is not None:
+        after()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    per = [evs[i].elapsed_time(evs[i + 1]) for i in range(n)]
+    return wall, per, evs[0].elapsed_time(evs[n])
+
+
 SHAPES = {   # SURVEY.md §8d: name -> (p, q, ranks, num_embeddings)
     "products_r16": ([125, 140, 140], [4, 5, 5], [16, 16], 2449029),
     "papers100M_r32": ([500, 560, 400], [8, 4, 4], [32, 32], 111059956),
@@ -289,14 +317,43 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # untimed pre-warm: the driver's --warmup 5 is ~1 ms of GPU work straight after minutes of host-side set-up (id generation,
+    # the first import of torch) -- clocks, the allocator's block lists and the workspace are cold.  At least 0.3 s of the
+    # headline step, untimed, before the warm-up steps the driver asked for (which stay the driver's)
+    t_pw = time.perf_counter()
+    n_pw = 0
+    while True:
+        for i in range(20):
+            step(n_pw + i)
+        n_pw += 20
+        if dp is not None:
+            dp.flush()
+        torch.cuda.synchronize()
+        more = time.perf_counter() - t_pw < 0.3
+        if world > 1:   # every rank leaves the loop after the same round: the ranks that want more are counted
+            go = torch.tensor([1.0 if more else 0.0], device="cpu" if rehearsal else "cuda")
+            dist.all_reduce(go)
+            more = float(go.item()) > 0.0
+        if not more:
+            break
+    prewarm_s = time.perf_counter() - t_pw
     for i in range(args.warmup):
         step(i)
     fence()
+    ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    step_evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     t0 = time.perf_counter()
+    ev_a.record()
     for i in range(args.steps):
         step(i)
+        step_evs[i].record()
+    if dp is not None:
+        dp.flush()              # the last step's update belongs to the timed region
+    ev_b.record()
     fence()
     elapsed = time.perf_counter() - t0
+    gpu_ms = ev_a.elapsed_time(ev_b)   # the same region on the GPU's clock (first launch .. last kernel's end)
+    step_gpu_ms = [(ev_a if i == 0 else step_evs[i - 1]).elapsed_time(step_evs[i]) for i in range(args.steps)]
     dist_info = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
@@ -318,14 +375,20 @@ def main():
     # Every rank runs these steps (they contain the collective); rank 0 reports its own kernel times.
     nat.profile_enable(True)
     fwd_ms, bwd_ms, chunk_ms, group_ms, epi_ms, fin_ms = [], [], [], [], [], []
+    def read_slot(slot):   # (kernel families without that kernel record no bracket: not a failure of the bench)
+        try:
+            return nat.profile_read(slot)
+        except RuntimeError:
+            return float("nan")
+
     for i in range(10):
         step(i)
         fwd_ms.append(nat.profile_read(0))
         bwd_ms.append(nat.profile_read(1))
         chunk_ms.append(nat.profile_read(2))
         group_ms.append(nat.profile_read(3))
-        epi_ms.append(nat.profile_read(8))
-        fin_ms.append(nat.profile_read(9))
+        epi_ms.append(read_slot(8))
+        fin_ms.append(read_slot(9))
     nat.profile_enable(False)
     fence()
 
@@ -371,7 +434,8 @@ def main():
                     "traffic_gbs": None if traffic is None else round(traffic / (dom_ms * 1e-3) / 1e9, 1),
                     "fwd_kernel_ms": round(fwd, 4), "bwd_chunk_kernel_ms": round(chunk, 4),
                     "bwd_chain_ms": round(bwd, 4), "grouping_ms": round(group, 4),
-                    "bwd_epilogue_kernel_ms": round(float(np.mean(epi_ms)), 4), "bwd_finalize_kernel_ms": round(float(np.mean(fin_ms)), 4),
+                    "bwd_epilogue_kernel_ms": None if np.isnan(epi_ms).any() else round(float(np.mean(epi_ms)), 4),
+                    "bwd_finalize_kernel_ms": None if np.isnan(fin_ms).any() else round(float(np.mean(fin_ms)), 4),
                     # chain level, nominal flops (executed flops are lower: P is formed once per group)
                     "fwd_chain_nominal_tflops": round(tf(FWD_FLOPS, fwd + group), 3),
                     "fwd_chain_mfma_frac": round(tf(FWD_FLOPS, fwd + group) / PEAK_F32_MFMA_TFLOPS, 4),
@@ -435,13 +499,10 @@ def main():
             ids_l = torch.from_numpy((starts[:, None] + np.arange(200)[None, :]).reshape(-1)[:N].astype(np.int64)).cuda()
             for _ in range(5):
                 emb(ids_l, offsets).backward(d_out)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(20):
-                emb(ids_l, offsets).backward(d_out)
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t1) / 20
-            local = {"ids": N, "ms_per_step": round(dt * 1e3, 4), "lookups_per_s": round(N / dt, 1)}
+            wall, per, gpu = timed_steps(lambda i: emb(ids_l, offsets).backward(d_out), 20)
+            dt = wall / 20
+            local = {"ids": N, "ms_per_step": round(dt * 1e3, 4), "lookups_per_s": round(N / dt, 1),
+                     "ms_per_step_gpu_events": round(gpu / 20, 4), "step_gpu_ms": spread(per)}
         # The step N > 1 runs, on ONE GPU: dense gradients straight into the flat bucket, TTDataParallel.step (no collective at
         # world 1), one fused SGD launch over the flat weights -- so that a multi-GPU value divides by a like-for-like
         # single-GPU one (the headline N = 1 line is the fused in-backward update: a different step)
@@ -457,15 +518,10 @@ def main():
 
             for i in range(10):
                 dstep(i)
-            dp_d.flush()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for i in range(100):
-                dstep(i)
-            dp_d.flush()
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t1) / 100
+            wall, per, gpu = timed_steps(dstep, 100, before=dp_d.flush, after=dp_d.flush)
+            dt = wall / 100
             dp1 = {"ids": N, "ms_per_step": round(dt * 1e3, 4), "lookups_per_s": round(N / dt, 1),
+                   "ms_per_step_gpu_events": round(gpu / 100, 4), "step_gpu_ms": spread(per),
                    "what": "the data-parallel step at world size 1: sparse=False, gradients into the bucket, "
                            "TTDataParallel.step(overlap=True), fused SGD over the flat weights, no collective; "
                            "the like-for-like N = 1 for `--gpus N` values (which run this step plus one all-reduce)"}
@@ -494,24 +550,36 @@ def main():
             hit = float(np.mean([float(torch.isin(b, keys).float().mean()) for b in test[:4]]))
             for b in test[:4]:
                 cemb(b, offsets).backward(d_out)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for b in test:
-                cemb(b, offsets).backward(d_out)
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t1) / len(test)
+            wall, per, gpu = timed_steps(lambda i: cemb(test[i], offsets).backward(d_out), len(test))
+            dt = wall / len(test)
             cached = {"ids": N, "ms_per_step": round(dt * 1e3, 4), "lookups_per_s": round(N / dt, 1),
+                      "ms_per_step_gpu_events": round(gpu / len(test), 4), "step_gpu_ms": spread(per),
                       "cache_rows": int(cemb.cache_weight.shape[0]), "hit_rate": round(hit, 3)}
-            # the same frontiers through the cache-less module: what the cache is up against
+            # the same frontiers through the cache-less module: what the cache is up against.  Per-step GPU times and the
+            # per-step wall clock of the host side of every step (a step the host took long to enqueue shows in both)
             for b in test[:4]:
                 emb(b, offsets).backward(d_out)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
+            host_us = []
+
+            def off_step(i):
+                th = time.perf_counter()
+                emb(test[i], offsets).backward(d_out)
+                host_us.append((time.perf_counter() - th) * 1e6)
+
+            wall, per, gpu = timed_steps(off_step, len(test))
+            dt_off = wall / len(test)
+            cached["cache_off_same_frontiers_ms"] = round(dt_off * 1e3, 4)
+            cached["cache_off_gpu_events_ms"] = round(gpu / len(test), 4)
+            cached["cache_off_step_gpu_ms"] = spread(per)
+            cached["cache_off_host_enqueue_us"] = spread(host_us)
+            # ... and once more with the library's own brackets: the grouping pass of every step (profile slot 3)
+            nat.profile_enable(True)
+            grp = []
             for b in test:
                 emb(b, offsets).backward(d_out)
-            torch.cuda.synchronize()
-            dt_off = (time.perf_counter() - t1) / len(test)
-            cached["cache_off_same_frontiers_ms"] = round(dt_off * 1e3, 4)
+                grp.append(nat.profile_read(3))
+            nat.profile_enable(False)
+            cached["cache_off_grouping_ms"] = spread(grp)
             # HBM-bound gather / update kernels of the cached rows and the two kernels every id pays, timed LIVE (HIP-event
             # brackets inside the library, profile slots 4-7) over the same frontiers.  Algorithmic bytes per cached row:
             # forward 8 + 4 + 4 D read + 4 D written = 812 B, backward 8 + 4 + 4 D gradient + 4 D row read + 4 D written = 1 212 B
@@ -617,7 +685,9 @@ def main():
         result = {
             "metric": "tt_embedding_lookups_per_sec", "value": round(value, 1), "unit": "lookups/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "ms_per_step_gpu_events": round(gpu_ms / args.steps, 4), "step_gpu_ms": spread(step_gpu_ms),
+            "prewarm_s": round(prewarm_s, 3), "prewarm_steps": n_pw, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "ogbn-products TTEmbeddingBag fwd+bwd+SGD per step, frontier of a "
                                    "2048-seed batch = 409600 unique uniform ids per GPU, bag length 1",

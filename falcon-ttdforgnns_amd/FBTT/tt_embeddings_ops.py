@@ -259,6 +259,10 @@ class TTLookupFunction(torch.autograd.Function):
         # a data-parallel wrapper may have provided one flat bucket for the gradients (ttemb_dist): they are then
         # produced straight into it and nothing is handed back to autograd (no AccumulateGrad, no views)
         bucket = getattr(m, "_dense_grad_out", None)
+        # (for ttemb_dist: did this gradient come from a grouped backward -- the family with bounded device-side waits,
+        #  whose last kernel leaves its verdict in the workspace header?  Host-side rule, launches nothing.)
+        m._last_bwd_grouped = nnz > 0 and (_nat.kernel_family(m._shape, nnz, B, rowidx is None) & 7) in (
+            _nat.FAMILY_GROUPED, _nat.FAMILY_GROUPED_WIDE)
         if bucket is not None and not ctx.live_cache:
             if m._bucket_filled:
                 # a second backward before dp.step() (micro-batches, two lookups through one module): the kernels
@@ -362,6 +366,7 @@ class CapturedLookup:
             plan = self._lean.forward(cores, self.indices, self.offsets, self.nnz, self.B, self.output)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
+        _nat.init()   # the pinned fault word exists before anything is captured (a capture must not allocate it)
         self.fwd_graph, self.bwd_graph = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.fwd_graph):
             self.plan = self._lean.forward(cores, self.indices, self.offsets, self.nnz, self.B, self.output)

@@ -59,50 +59,55 @@ int device_cus() {
 int current_path() { return g_path.load(); }
 
 // ---- device-side faults (a bounded wait of the grouping pass that ran out: report_fault in ttemb_fast3.hip) ----
-// One pinned, device-visible host word per process, allocated at the first grouped lookup that is not being captured and
-// never freed (its address is baked into captured graphs).  The kernel that gives up stores its reason there; every lookup
-// entry point looks at it first (a plain host read, no synchronisation), so the fault surfaces as TTEMB_E_HIP on the next
-// call the host makes after the store has landed -- at the latest on the one after a synchronisation -- and is then
-// cleared.  The results of the faulted call itself are NaN (poisoned plan), whether or not anyone asks.
+// One pinned, device-visible host word per process, allocated by ttemb_init() (or the first ttemb_status()) -- an explicit
+// call the host makes outside any stream capture, never by a lookup (the lookups allocate nothing) -- and never freed (its
+// address is baked into captured graphs).  The kernel that gives up stores its reason there; every lookup entry point looks
+// at it first (one atomic exchange on a host word, no synchronisation), so the fault surfaces as TTEMB_E_HIP on the next
+// call the host makes after the store has landed -- at the latest on the one after a synchronisation -- and is consumed by
+// exactly one caller.  The error therefore names an EARLIER call: the call that reports it has not been started.  The
+// results of the faulted call itself are NaN (poisoned plan), whether or not anyone asks.
 static std::atomic<uint32_t*> g_fault_host{nullptr};
 static std::atomic<uint32_t*> g_fault_dev{nullptr};
 static std::atomic<int> g_fault_state{0};   // 0 = not tried, 1 = being set up, 2 = ready, 3 = not available
 
-uint32_t* fault_word(hipStream_t st) {
+// the lookups' view: the word's device address when it exists, else null (that call reports through its NaN results only)
+uint32_t* fault_word(hipStream_t) {
+  return g_fault_state.load(std::memory_order_acquire) == 2 ? g_fault_dev.load(std::memory_order_relaxed) : nullptr;
+}
+
+// ttemb_init / ttemb_status: create the word (once per process; a call that loses the race goes without)
+int fault_word_init() {
   int state = g_fault_state.load(std::memory_order_acquire);
-  if (state == 2) return g_fault_dev.load(std::memory_order_relaxed);
-  if (state == 3) return nullptr;
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
-    (void)hipGetLastError();
-    return nullptr;   // no allocation during a capture; this graph reports through its NaN results only
-  }
+  if (state == 2) return TTEMB_OK;
+  if (state == 3) return fail(TTEMB_E_HIP, "no pinned host memory for the device-fault word: expired device-side waits are reported through NaN results only");
   int expect = 0;
-  if (!g_fault_state.compare_exchange_strong(expect, 1)) return nullptr;   // another thread is setting it up: this call goes without
+  if (!g_fault_state.compare_exchange_strong(expect, 1)) return TTEMB_OK;   // another thread is setting it up
   void* host = nullptr;
   void* dev = nullptr;
   if (hipHostMalloc(&host, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess || host == nullptr ||
       hipHostGetDevicePointer(&dev, host, 0) != hipSuccess || dev == nullptr) {
     (void)hipGetLastError();
     g_fault_state.store(3, std::memory_order_release);
-    return nullptr;
+    return fail(TTEMB_E_HIP, "no pinned host memory for the device-fault word: expired device-side waits are reported through NaN results only");
   }
   memset(host, 0, 64);
   g_fault_host.store(reinterpret_cast<uint32_t*>(host), std::memory_order_relaxed);
   g_fault_dev.store(reinterpret_cast<uint32_t*>(dev), std::memory_order_relaxed);
   g_fault_state.store(2, std::memory_order_release);
-  return reinterpret_cast<uint32_t*>(dev);
+  return TTEMB_OK;
 }
 
 int pending_device_fault() {
   if (g_fault_state.load(std::memory_order_acquire) != 2) return TTEMB_OK;
-  volatile uint32_t* w = g_fault_host.load(std::memory_order_relaxed);
-  const uint32_t code = *w;
+  uint32_t* w = g_fault_host.load(std::memory_order_relaxed);
+  if (__atomic_load_n(w, __ATOMIC_RELAXED) == 0u) return TTEMB_OK;   // (the usual case: one plain read)
+  const uint32_t code = __atomic_exchange_n(w, 0u, __ATOMIC_ACQ_REL);   // consumed by exactly one caller; a report landing now stays for the next
   if (code == 0u) return TTEMB_OK;
-  *w = 0u;
   return fail(TTEMB_E_HIP,
-              "an earlier grouped lookup gave up waiting on the device (%s): the rows / gradients of that call are NaN, "
-              "not wrong numbers.  The GPU is shared or throttled beyond what the grouping pass tolerates; rerun the step",
+              "an EARLIER grouped lookup of this process gave up waiting on the device (%s): the rows / gradients of that call are "
+              "NaN, not wrong numbers; a fused SGD / Adagrad backward on such a plan left the parameters and the optimizer state "
+              "untouched (dense gradients are NaN).  The GPU is shared or throttled beyond what the grouping pass tolerates.  The "
+              "call that returns this error was not started; discard the faulted step's outputs and run it again",
               code == 1u ? "range counter take-over in the decode step" : "look-back of the place step");
 }
 
@@ -602,7 +607,8 @@ __global__ void zero_rows_kernel(const int64_t* __restrict__ offsets, int64_t B,
   for (int c = 0; c * 4 < D; ++c) o[c] = z;
 }
 
-__global__ void sgd_step_kernel(float* __restrict__ w, const float* __restrict__ g, int64_t n, float lr) {
+__global__ void sgd_step_kernel(float* __restrict__ w, const float* __restrict__ g, int64_t n, float lr, const float* __restrict__ skip) {
+  if (skip != nullptr && *skip != 0.f) return;   // (ttemb_sgd_step_guarded: some rank's gradient came from a poisoned plan)
   int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i + 3 < n) {
     float4 wv = *reinterpret_cast<float4*>(w + i);
@@ -632,7 +638,9 @@ struct Seg3 {
 };
 
 // one launch for every core: blockIdx.y selects the core
-__global__ void fused_step_kernel(Seg3 seg, float lr, float eps, int adagrad) {
+// `skip`: the poison word a grouped backward of this call left in the workspace header (FusedUpdate::poison_out), or null
+__global__ void fused_step_kernel(Seg3 seg, float lr, float eps, int adagrad, const uint32_t* __restrict__ skip) {
+  if (skip != nullptr && *skip != 0u) return;   // the gradients are NaN and the host hears of it: parameters stay as they are
   const int t = blockIdx.y;
   float* __restrict__ w = seg.w[t];
   const float* __restrict__ g = seg.g[t];
@@ -666,13 +674,13 @@ __global__ void fused_step_kernel(Seg3 seg, float lr, float eps, int adagrad) {
   }
 }
 
-static int run_sgd(float* w, const float* g, int64_t n, float lr, hipStream_t st) {
+static int run_sgd(float* w, const float* g, int64_t n, float lr, hipStream_t st, const float* skip = nullptr) {
   if (n <= 0) return TTEMB_OK;
   if ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(g)) & 15)
     return fail(TTEMB_E_BADARG, "sgd_step: buffers must be 16-byte aligned");
   const int threads = 256;
   const int64_t blocks = ((n + 3) / 4 + threads - 1) / threads;
-  hipLaunchKernelGGL(sgd_step_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, w, g, n, lr);
+  hipLaunchKernelGGL(sgd_step_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, w, g, n, lr, skip);
   return check_hip(hipGetLastError(), "sgd_step_kernel");
 }
 
@@ -713,12 +721,18 @@ static int resolve_rowidx(const int64_t** rowidx, const int64_t* offsets, int64_
 static int backward_into(const DevShape& ds, const CorePtrs& cp, const int64_t* indices,
                          const int64_t* rowidx, const int64_t* offsets, int64_t nnz, const int32_t* nnz_dev, int64_t B,
                          const float* d_output, const CorePtrsMut& dst, void* ws, int64_t ws_bytes,
-                         const void* plan, int64_t plan_bytes, hipStream_t st, void* header, const FusedUpdate* update = nullptr) {
-  if (use_fast3(ds, nnz, B, offsets != nullptr))
+                         const void* plan, int64_t plan_bytes, hipStream_t st, void* header, const FusedUpdate* update = nullptr,
+                         bool* grouped = nullptr) {
+  // *grouped: the gradients come from a grouped backward, whose finalize kernel left its verdict in the header's poison word
+  if (grouped != nullptr) *grouped = false;
+  if (use_fast3(ds, nnz, B, offsets != nullptr)) {
+    if (grouped != nullptr) *grouped = true;
     return launch_backward_fast3(ds, cp, indices, rowidx, offsets, nnz, nnz_dev, B, d_output, dst, ws, ws_bytes, plan,
                                  plan_bytes, st, update, header);
+  }
   const Merged4 m4 = merge_first_two(ds, nnz, B, rowidx == nullptr && offsets != nullptr, offsets != nullptr);
   if (m4.on) {   // 4 cores: the 3-core backward on (V, G2, G3), then dV back onto G0 and G1
+    if (grouped != nullptr) *grouped = !m4.per_bag;
     if (ws == nullptr || ws_bytes < 2 * m4.v_bytes) return fail(TTEMB_E_WORKSPACE, "backward needs room for the merged core");
     float* V = reinterpret_cast<float*>(ws);
     float* dV = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + m4.v_bytes);
@@ -747,6 +761,7 @@ static int backward_into(const DevShape& ds, const CorePtrs& cp, const int64_t* 
   const Padded3 pd = pad_ranks(ds, nnz, B, offsets != nullptr);
   if (pd.on) {   // ranks off the list: grouped backward on the padded cores, then the original sub-block of its gradient
     if (update != nullptr) return fail(TTEMB_E_BADARG, "internal: a padded table writes gradients, the step follows");
+    if (grouped != nullptr) *grouped = true;
     if (ws == nullptr || ws_bytes < 2 * pd.cores_total) return fail(TTEMB_E_WORKSPACE, "backward needs room for the padded cores");
     char* wp = reinterpret_cast<char*>(ws);
     CorePtrs cp3;
@@ -838,9 +853,16 @@ int ttemb_set_spin_limit(int64_t tries) {
   return TTEMB_OK;
 }
 
-int ttemb_status(void) { return pending_device_fault(); }
+int ttemb_init(void) { return fault_word_init(); }
+
+int ttemb_status(void) {
+  if (g_fault_state.load(std::memory_order_acquire) == 0) (void)fault_word_init();   // (a caller that asks wants the word to exist)
+  return pending_device_fault();
+}
 
 int ttemb_profile_enable(int32_t on) {
+  if (on != 0)   // a read must never return a bracket recorded before this enable (by another leg, another kernel family)
+    for (int i = 0; i < kProfSlots; ++i) g_prof_valid[i] = false;
   g_prof_on.store(on != 0);
   return TTEMB_OK;
 }
@@ -892,7 +914,8 @@ int ttemb_kernel_family(const ttemb_shape_t* shape, int64_t nnz, int64_t B, int3
   if (rc) return rc;
   if (nnz < 0 || B < 0) return fail(TTEMB_E_BADARG, "negative size");
   auto family3 = [nnz, B](const DevShape& s, bool grouped) {
-    if (grouped) return fast3_wide(s) ? (int)TTEMB_FAMILY_GROUPED_WIDE : (TTEMB_FAMILY_GROUPED | (fast3_prefix_in_chain(s, nnz, B) ? TTEMB_FAMILY_PREFIX_IN_CHAIN : 0));
+    if (grouped) return fast3_wide(s) ? (int)TTEMB_FAMILY_GROUPED_WIDE : (TTEMB_FAMILY_GROUPED | (fast3_prefix_in_chain(s, nnz, B) ? TTEMB_FAMILY_PREFIX_IN_CHAIN : 0) |
+                                                                          (fast3_group_products_in_chain(s, nnz, B) ? TTEMB_FAMILY_GROUP_PRODUCTS_IN_CHAIN : 0));
     return small3_templated_shape(s) ? (int)TTEMB_FAMILY_PER_BAG : (int)TTEMB_FAMILY_PER_BAG_RT;
   };
   // (without the bag boundaries a call past one row window cannot be cut into pieces)
@@ -1138,8 +1161,9 @@ static int fused_backward(const ttemb_shape_t* shape, float* const* cores, float
   upd.lr = lr;
   upd.eps = eps;
   // the grouped path applies the step inside its last kernel; the generic path writes gradients, then steps
+  bool grouped = false;
   rc = backward_into(ds, cp, indices, rowidx, offsets, nnz, nnz_dev, B, d_output, gp, rest_ws, rest, plan, plan_bytes, st,
-                     header, f3 ? &upd : nullptr);
+                     header, f3 ? &upd : nullptr, &grouped);
   if (rc || f3) return rc;
   Seg3 seg;
   memset(&seg, 0, sizeof(seg));
@@ -1157,7 +1181,8 @@ static int fused_backward(const ttemb_shape_t* shape, float* const* cores, float
   int64_t blocks = (nmax / 4 + 255) / 256;
   blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
   hipLaunchKernelGGL(fused_step_kernel, dim3((unsigned)blocks, (unsigned)ds.T), dim3(256), 0, st, seg, lr, eps,
-                     opt_state ? 1 : 0);
+                     opt_state ? 1 : 0,
+                     grouped ? reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(header) + kHeaderPoisonOffset) : nullptr);
   return check_hip(hipGetLastError(), "fused_step_kernel");
 }
 
@@ -1185,6 +1210,12 @@ int ttemb_sgd_step(float* weights, const float* grads, int64_t n, float lr, void
   ApiRange api_range("ttemb_sgd_step");
   if (n > 0 && (weights == nullptr || grads == nullptr)) return fail(TTEMB_E_BADARG, "null buffer");
   return run_sgd(weights, grads, n, lr, reinterpret_cast<hipStream_t>(stream));
+}
+
+int ttemb_sgd_step_guarded(float* weights, const float* grads, int64_t n, float lr, const float* skip, void* stream) {
+  ApiRange api_range("ttemb_sgd_step_guarded");
+  if (n > 0 && (weights == nullptr || grads == nullptr)) return fail(TTEMB_E_BADARG, "null buffer");
+  return run_sgd(weights, grads, n, lr, reinterpret_cast<hipStream_t>(stream), skip);
 }
 
 int ttemb_adagrad_step(float* weights, float* state, const float* grads, int64_t n, float lr,

@@ -69,14 +69,16 @@ int launch_zero_cores(const DevShape& s, const CorePtrsMut& d_cores, hipStream_t
 bool fast3_supported(const DevShape& s);
 bool fast3_pays(const DevShape& s, int64_t nnz);
 bool fast3_prefix_in_chain(const DevShape& s, int64_t nnz, int64_t B);   // a whole forward of this size forms P inside its chain kernel
+bool fast3_group_products_in_chain(const DevShape& s, int64_t nnz, int64_t B);   // a backward of this size forms the per-group products inside its chunk kernel
 bool fast3_fits(const DevShape& s, int64_t nnz, int64_t B);   // the call fits one 32-bit row window / one grouping pass
 bool fast3_fits_in_pieces(const DevShape& s, int64_t nnz, int64_t B);   // ... or runs as several pieces (needs `offsets`)
 void fast3_set_piece_limits(int64_t rows, int64_t ids);                  // diagnostic: smaller pieces than the hardware's
 void fast3_set_spin_limit(int64_t tries);                                // diagnostic: tries of the grouping pass's bounded waits
 // The pinned host word a device-side wait that ran out reports to (ttemb_api.hip): its device address for the kernels
-// (null when it cannot be had: no such memory, or a stream that is being captured before the first eager call), and the
-// host-side check every lookup entry point starts with -- TTEMB_E_HIP once per reported fault.
+// (null until ttemb_init() / ttemb_status() has created it -- the lookups allocate nothing), and the host-side check every
+// lookup entry point starts with -- TTEMB_E_HIP once per reported fault.
 uint32_t* fault_word(hipStream_t st);
+int fault_word_init();
 int pending_device_fault();
 int64_t fast3_workspace_bytes(const DevShape& s, int32_t op, int64_t nnz, int64_t B);
 int64_t fast3_plan_bytes(const DevShape& s, int64_t nnz);
@@ -95,7 +97,17 @@ struct FusedUpdate {
   float* w[TTEMB_MAX_CORES];
   float* st[TTEMB_MAX_CORES];   // Adagrad state, or null for SGD
   float lr, eps;
+  // A word of the workspace header the finalize kernel sets to 1 when the plan it ran on is POISONED and the host hears of
+  // it (fault word present), else to 0 (sticky = 1: a later piece of the same call only ever sets it): the optimiser step
+  // that follows a gradient-writing route (padded ranks, merged pairs, calls in pieces) reads it and leaves the parameters
+  // alone -- what the fused finalize kernel does by itself.  Written by every grouped backward, so any content is valid.
+  uint32_t* poison_out;
+  int32_t sticky;
 };
+// where that word sits in the header: behind the epoch words and the banks of range counters (16 + 8 * 512 * 8 bytes)
+constexpr int64_t kHeaderPoisonOffset = 16 + 8 * 512 * 8;
+static_assert(kHeaderPoisonOffset + 8 <= kFast3HeaderBytes, "the poison word lies inside the header");
+static_assert(kHeaderPoisonOffset == TTEMB_HEADER_POISON_OFFSET, "include/ttemb.h names the same offset");
 int launch_backward_fast3(const DevShape& s, const CorePtrs& cores, const int64_t* indices,
                           const int64_t* rowidx, const int64_t* offsets, int64_t nnz, const int32_t* nnz_dev,
                           int64_t B, const float* d_output, const CorePtrsMut& d_cores, void* ws,

@@ -221,6 +221,7 @@ struct GroupPlan {           // device pointers into the caller's plan buffer / 
   uint32_t* epi_live;        // [slices][p1] sparse form only: 1 when the slice of that i1 holds an id (its slab exists)
   uint32_t* wrows;           // wide-rank chain: [p1][stride] the rows (i0, a) of every i1 whose group holds an id (wide3_rows_kernel)
   uint32_t* wnrows;          // [p1] their number
+  uint32_t* ticket;          // header word: the place step's range tickets (zeroed by the spread step of the same call)
   uint32_t* fault_host;      // pinned host word (device address) a bounded wait that ran out reports to, or null
   uint32_t spin_limit;       // tries of the bounded waits of the grouping pass (ttemb_set_spin_limit; 0 = none: every wait expires)
 };
@@ -451,6 +452,7 @@ __device__ __forceinline__ void spread_slice(uint32_t s, uint32_t slices, uint32
   if (s == 0 && threadIdx.x == 0) {
     plan.rstart[ranges] = all;
     plan.epochs[1] = plan.epochs[0] + 1ull;   // the running call's number, for the place step
+    *plan.ticket = 0u;                        // the place step's workgroups draw their ranges from it (nobody reads it during this launch)
   }
   __syncthreads();
   const uint32_t s0 = s * per_slice;
@@ -498,15 +500,27 @@ __global__ __launch_bounds__(kSortThreads) void fast3_spread_kernel(uint32_t nnz
 //      of step 2 sits between a workgroup's own publication and its first look (a separate count launch in front of the
 //      place launch cost ~5 us + the launch gap; a look-back BEFORE the scatter waited for the slowest histogram);
 //   4. chunk descriptors and group starts, one thread per group (a chunk's descriptor depends on its group's numbers only).
-// Workgroups are dispatched in index order and wait only for lower indices, so the wait cannot starve what it waits for;
-// it is bounded all the same: a wait that runs out poisons the plan and reports (report_fault) -- never a hung device, never
-// a plausible wrong table.
+// A workgroup's range is a TICKET it draws when it starts (one atomic on a header word the spread step zeroed), not its
+// blockIdx: it then waits only for ranges whose workgroups have already started, whatever order the dispatcher chose and
+// whatever else occupies the CUs -- the data-parallel step runs this launch next to an RCCL all-reduce kernel
+// (TTDataParallel.step(overlap=True)), where "every workgroup of the launch is resident" is no longer a given (rocPRIM's
+// look-back scan draws its tile ids the same way).  The wait is bounded all the same: one that runs out poisons the plan and
+// reports (report_fault) -- never a hung device, never a plausible wrong table.
 constexpr uint64_t kEpochMask = (1ull << 40) - 1ull;
 static_assert(kMaxRanges <= kRangeThreads, "the look-back reads one published word per thread");
-__device__ __forceinline__ void place_range(const uint32_t range, const uint32_t ranges, uint32_t G, uint32_t shift,
+__device__ __forceinline__ void place_range(const uint32_t ranges, uint32_t G, uint32_t shift,
                                             uint32_t nnz, uint32_t max_chunks, const GroupPlan& plan, uint32_t* lds_s,
                                             uint64_t* red) {
   // lds_s: [span] cursor | [span] first position | [span] count | [span] first chunk (inside the range)
+#ifdef TTEMB_PLACE_BY_BLOCK   // (A/B: the range is the workgroup's index, as until round 4)
+  const uint32_t range = blockIdx.x;
+#else
+  if (threadIdx.x == 0) reinterpret_cast<uint32_t*>(red)[0] = atomicAdd(plan.ticket, 1u);
+  __syncthreads();
+  const uint32_t range = reinterpret_cast<uint32_t*>(red)[0];
+  __syncthreads();   // (red is the scan's scratch next)
+  if (range >= ranges) return;   // (cannot happen: `ranges` workgroups draw from a counter that started at 0)
+#endif
   const uint32_t span = 1u << shift;
   const uint32_t g0 = range << shift;
   uint32_t* cursor = lds_s;
@@ -646,7 +660,7 @@ __global__ __launch_bounds__(kRangeThreads) void fast3_place_kernel(uint32_t nnz
                                                                     GroupPlan plan) {
   extern __shared__ uint32_t lds_s[];
   __shared__ uint64_t red[2 * (kRangeThreads / kWave + 1)];
-  place_range(blockIdx.x, gridDim.x, G, shift, nnz, max_chunks, plan, lds_s, red);
+  place_range(gridDim.x, G, shift, nnz, max_chunks, plan, lds_s, red);
 }
 
 // The piece table of a call past one 32-bit row window (struct Piece): a greedy walk over the id list on the device.  A
@@ -826,7 +840,7 @@ __global__ __launch_bounds__(kRangeThreads) void fast3_place_prefix_kernel(uint3
   extern __shared__ uint32_t lds_s[];
   __shared__ uint64_t red[2 * (kRangeThreads / kWave + 1)];
   if (blockIdx.x < ranges) {
-    place_range(blockIdx.x, ranges, G, shift, nnz, max_chunks, plan, lds_s, red);
+    place_range(ranges, G, shift, nnz, max_chunks, plan, lds_s, red);
     return;
   }
   const uint32_t blocks0 = (p0 + kPrefixGroups - 1) / kPrefixGroups;
@@ -1109,9 +1123,14 @@ template <int Q0, int Q1, int Q2, int R1, int R2>
 struct PFuseCfg {
   using C = Cfg<Q0, Q1, Q2, R1, R2>;
   static constexpr int GM = 16 / Q0;          // groups per batch
-  // q0 > 8: one group per tile -- nothing to batch; q = 4,4,8 / 5,5,4 at rank 32 spill 64-76 bytes per lane under the
-  // two-wavefront bound (G1[i1] alone is 64 registers there).  Those shapes keep the prefix launch.
+  // q0 > 8: one group per tile -- nothing to batch; at rank 32 only q0 = 8 (the papers100M shape: G1[i1] is 64 registers) fits
+  // the two-wavefront bound: q = 4,4,8 / 5,5,4 spill 64-76 bytes per lane there, q = 4,5,5 (80 registers of G1 row) 20 bytes.
+  // Those shapes keep the prefix launch (no shipped kernel has scratch: tools/kres.py --fail-on-scratch, run by the CPU tests).
+#ifdef TTEMB_PFUSE_455_R32   // (A/B: the spilling q = 4,5,5 rank-32 instance, shipped in round 4)
   static constexpr bool ok = GM >= 2 && !(R1 == 32 && ((Q0 == 4 && Q1 == 4 && Q2 == 8) || (Q0 == 5 && Q1 == 5 && Q2 == 4)));
+#else
+  static constexpr bool ok = GM >= 2 && !(R1 == 32 && Q0 != 8);
+#endif
   // A staged P is M2 rows of r2 floats, UNPADDED (a padded row cost the q = 4,4,8 rank-16 shape its third workgroup per CU):
   // the 16-byte quads of row m are XOR-swizzled by swz(m) instead, so that the A-operand reads (lane lo = row, 4 s + hi =
   // column) of eight consecutive rows fall on eight different bank groups.  Rows past M2 of the last row tile are read
@@ -1464,12 +1483,37 @@ constexpr int fuse_quads(int m2, int row2) { return (m2 <= 16 && row2 >= 128) ? 
 // FUSE = true is instantiated for these shapes only.
 constexpr bool fuse_shape(int r2, int row2) { return r2 <= 16 && row2 % 4 == 0 && row2 / 4 <= kWave / 2; }
 
-template <int Q0, int Q1, int Q2, int R1, int R2, bool FUSE>
+// GF ("group products fused", frontiers with few ids per group): the two per-group products of fast3_group_epilogue_kernel
+//        dG0 part[g] = dP[g] (q0 x q1 r2) . G1[i1]^T,      dG1[i1] += G0[i0]^T (r1 x q0) . dP[g]
+// are formed HERE, at the moment a group's last chunk has been multiplied and its dP is still in this wavefront's
+// accumulators -- the dP table (q0 q1 r2 floats per group: 1.08 GB written and read back around 0.43 GB of algorithmic bytes
+// on the papers100M frontier of 819 200 ids, where three ids share a group) never exists, and the epilogue launch is gone.
+// What leaves the kernel per group is its dG0 part (q0 r1 floats instead of q0 q1 r2); dG1[i1] accumulates in MFMA registers
+// for as long as the wavefront stays inside one i1 (its share of the chunk table covers a fraction of one: the fact
+// fast3_forward_pfuse_kernel uses to keep G1[i1] in registers) and is added to ONE zero-filled slab with float atomics when
+// the i1 changes -- a few thousand flushes per launch.  Groups are batched 16 / q0 at a time (consecutive i0 of one i1: one
+// full 16-row MFMA tile), their dP rows meet in an LDS slot; a batch is multiplied when the wavefront's next chunk belongs to
+// another batch.  G1[i1] as the B operand of the dG0 product stays in registers, K-permuted so that it is loaded with
+// 16-byte pieces (lane group hi owns n = (N1/4) hi + s); the batch's G0 rows are requested at the top of the iteration
+// that multiplies the batch's last chunk (an instruction of every iteration: off the buffer when no batch ends).
+struct GroupFuse {
+  const float* G0;
+  const float* G1;
+  float* dg1;          // [p1][ROW1], zero-filled by the host: dG1 (added with float atomics, one flush per (wavefront, i1))
+  uint32_t p0;
+  uint64_t p0_magic;   // g / p0 = (g * magic) >> 40
+};
+
+template <int Q0, int Q1, int Q2, int R1, int R2, bool FUSE, bool GF = false>
 __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / kFuseWaves : 1) void fast3_bwd_chunk_kernel(
     const float* __restrict__ G2, uint32_t G, uint32_t p2, uint32_t nnz, const float* __restrict__ d_out, uint32_t dout_bytes,
-    GroupPlan plan) {
+    GroupPlan plan, GroupFuse gf) {
   using C = Cfg<Q0, Q1, Q2, R1, R2>;
+  static_assert(!(FUSE && GF), "the in-kernel dG2 reduction and the in-kernel group products are separate forms");
   constexpr int NW = FUSE ? kFuseWaves : kChainWaves;
+  constexpr int GM = 16 / Q0;             // GF: groups per batch
+  constexpr int LDD = C::N1 + 4;          // GF: row stride of the batch's stacked dP rows [rho][n] (16-byte aligned rows)
+  constexpr int GF_FLOATS = GF ? 16 * LDD : 0;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63;
   const uint32_t wave = uniform(threadIdx.x >> 6);
@@ -1478,7 +1522,7 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
   // FUSE: a second region for E rows behind the staging regions -- a wavefront multiplies kFuseSub = 2 chunks between two
   // reductions (the barriers and the fixed part of the list walk are paid once per two chunks); the first chunk's rows
   // wait there, the second's take the place of its staged G2 rows
-  constexpr int WF = C::PB_FLOATS + C::BB2_FLOATS + C::OB_FLOATS + (FUSE ? kChunk * C::ROW2 : 0);
+  constexpr int WF = C::PB_FLOATS + C::BB2_FLOATS + C::OB_FLOATS + (FUSE ? kChunk * C::ROW2 : 0) + GF_FLOATS;
   float* pbuf = smem + wave * WF;
   // FUSE: [kFuseWaves] "has a chunk after this one" | [kFuseWaves * 16] list entry of every row of the round: {byte offset
   // of the row in LDS, byte offset of the next entry of its list} | [heads] byte offset of the first entry of every i2's
@@ -1499,6 +1543,7 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
   const uint32_t my_row0 = (uint32_t)((wave * WF + C::PB_FLOATS + C::BB2_FLOATS + C::OB_FLOATS + b_l * C::ROW2) * sizeof(float));
   const uint32_t my_row1 = (uint32_t)((wave * WF + C::PB_FLOATS + b_l * C::ROW2) * sizeof(float));
   float* ebuf = pbuf + C::PB_FLOATS + C::BB2_FLOATS + C::OB_FLOATS;
+  float* const gslot = ebuf;   // GF: the batch's dP rows (FUSE and GF exclude each other: the region behind the staging regions)
   uint32_t sub = 0;   // which chunk of the round is being multiplied
   float* bbuf = pbuf + C::PB_FLOATS;   // staged G2 rows
   float* dbuf = bbuf + C::BB2_FLOATS;  // staged d_output rows
@@ -1629,7 +1674,11 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
     for (int k = 0; k < NLD; ++k)
       pre_d[k] = buf_load4(r_do, (k + 1 < NLD || d_has_last) ? o.grow + rowpiece + 64u * k : kOobBase);   // o.grow may be kOobBase itself
     // P of a new group: the descriptor is re-based on the group's slot, empty when the chunk continues a group
+#if defined(TTEMB_ABL) && (TTEMB_ABL & 1024)   // (ablation 1024: P is not read -- zeros; timing only)
+    const rsrc_t r_p = make_rsrc(plan.ptab + (size_t)uniform(d.y) * PF, 0u);
+#else
     const rsrc_t r_p = make_rsrc(plan.ptab + (size_t)uniform(d.y) * PF, uniform((d.z & kFirstBit) ? (uint32_t)(PF * 4) : 0u));
+#endif
 #pragma unroll
     for (int it = 0; it < NLP; ++it) pre_p[it] = buf_load4(r_p, 16u * (uint32_t)lane + 1024u * it);
   };
@@ -1655,6 +1704,47 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
   };
 
   f32x4 dp[C::MT2][C::RT2];
+  // ---- GF: state of the group products ----
+  constexpr int KS3 = C::N1 / 4, KPH3 = C::N1 / 4;          // k-steps of the dG0 product; lane group hi owns n = KPH3 hi + s
+  f32x4 g1acc[GF ? C::RT1 : 1][GF ? C::NT1 : 1];            // dG1[cur_i1] of this wavefront's groups so far
+  float gf_g1[GF ? KS3 : 1][GF ? C::RT1 : 1];               // G1[cur_i1] as the B operand of the dG0 product
+  float gf_g0[4][GF ? C::RT1 : 1];                          // the G0 rows of the batch that ends in this iteration (A of the dG1 product)
+  uint32_t gf_i1 = 0xffffffffu, gf_batch = 0xffffffffu, gf_mask = 0u;   // i1 of g1acc / gf_g1; first group of the open batch; its staged groups
+  const rsrc_t r_g0 = make_rsrc(gf.G0, GF ? gf.p0 * (uint32_t)C::ROW0 * 4u : 0u);
+  const rsrc_t r_part = make_rsrc(plan.g0part, GF ? G * (uint32_t)C::ROW0 * 4u : 0u);
+  struct Batch {
+    uint32_t i1, i0b, first_group;
+  };
+  auto batch_of = [&](uint32_t g) {   // (scalar arithmetic: g is wave-uniform)
+    Batch b;
+    b.i1 = (uint32_t)(((uint64_t)g * gf.p0_magic) >> 40);   // g / p0: exact for g p0 < 2^40
+    const uint32_t i0 = g - b.i1 * gf.p0;
+    b.i0b = i0 / GM * GM;
+    b.first_group = g - (i0 - b.i0b);
+    return b;
+  };
+  auto flush_g1 = [&]() {   // dG1[gf_i1] += this wavefront's sums (row c1 = 16 t + 4 hi + r, column n = 16 nt + lo), then zeros
+    if constexpr (GF) {
+      float* dst = gf.dg1 + (size_t)gf_i1 * C::ROW1;
+#pragma unroll
+      for (int t = 0; t < C::RT1; ++t)
+#pragma unroll
+        for (int nt = 0; nt < C::NT1; ++nt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int c1 = 16 * t + 4 * hi + r;
+            if (c1 < R1 && (C::N1 % 16 == 0 || 16 * nt + lo < C::N1)) atomicAdd(dst + c1 * C::N1 + 16 * nt + lo, g1acc[t][nt][r]);
+          }
+          g1acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+  };
+  if constexpr (GF) {
+#pragma unroll
+    for (int t = 0; t < C::RT1; ++t)
+#pragma unroll
+      for (int nt = 0; nt < C::NT1; ++nt) g1acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
   // which chunk follows `cc` for this wavefront: the next one, unless `cc` closed a group at or past the range end
   auto has_next = [&](uint32_t cc, const uint4& d) { return cc + 1 < nchunks && !((d.z & kLastBit) && cc + 1 >= c1); };
   const uint4 none = make_uint4(0u, 0u, 0u, 0u);
@@ -1707,6 +1797,24 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
       d_n4 = load_desc(ctab, c + 4, nchunks);
     }
     const uint32_t len = d_cur.z & 0xffu;
+    // GF: does the batch of this chunk's group end here?  (the group ends, and the wavefront's next chunk -- if it has one --
+    // belongs to another batch.)  Its G0 rows are requested now and used after this chunk's products.
+    Batch b_cur = {0u, 0u, 0u};
+    bool batch_ends = false;
+    if constexpr (GF) {
+      b_cur = batch_of(uniform(d_cur.y));
+      batch_ends = (d_cur.z & kLastBit) != 0u && (!more1 || batch_of(uniform(d_nxt.y)).first_group != b_cur.first_group);
+      // A operand of the dG1 product: row c1 = 16 t + lo of G0^T, column rho = 4 s + hi = (group rho / q0, core row rho % q0)
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int rho = 4 * s4 + hi;
+        const uint32_t i0a = b_cur.i0b + (uint32_t)(rho / Q0);
+        const bool on = batch_ends && rho / Q0 < GM && i0a < gf.p0;
+#pragma unroll
+        for (int t = 0; t < C::RT1; ++t)
+          gf_g0[s4][t] = __uint_as_float(buf_load1u(r_g0, (on && 16 * t + lo < R1) ? i0a * (uint32_t)(C::ROW0 * 4) + 4u * ((rho % Q0) * R1 + 16 * t + lo) : kOob));
+      }
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1909,7 +2017,114 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
       }
     }
 #endif
-    if (d_cur.z & kLastBit) {  // dP of a finished group, into its own slot
+    if constexpr (GF) {
+      if (d_cur.z & kLastBit) {   // a group is complete: its dP joins the batch's slot; a complete batch is multiplied
+        asm volatile("; a group ends" ::: "memory");
+        if (b_cur.first_group != gf_batch) {   // the batch's first group (of this wavefront): the rows of the others read zero
+          constexpr int Z4 = 16 * LDD / 4;
+#pragma unroll
+          for (int it = 0; it < (Z4 + kWave - 1) / kWave; ++it)
+            if (Z4 % kWave == 0 || it * kWave + lane < Z4) *reinterpret_cast<float4*>(gslot + 4 * (it * kWave + lane)) = make_float4(0.f, 0.f, 0.f, 0.f);
+          gf_batch = b_cur.first_group;
+          gf_mask = 0u;
+        }
+        const uint32_t sl = uniform(d_cur.y) - b_cur.first_group;   // the group's place in its batch (< GM)
+        gf_mask |= 1u << sl;
+        float* const rows = gslot + sl * (uint32_t)(Q0 * LDD);
+        // dP[m = (a, j)][c2] -> slot row (sl q0 + a), column n = j r2 + c2
+#pragma unroll
+        for (int mt = 0; mt < C::MT2; ++mt)
+#pragma unroll
+          for (int t = 0; t < C::RT2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              if (kNarrowTail && mt == C::MT2 - 1) {   // narrow tile: register r of lane (hi, lo) is lane group hi's share of dP[16 mt + r][16 t + lo]
+                float v = dp[mt][t][r];
+                v += __shfl_xor(v, 16, kWave);
+                v += __shfl_xor(v, 32, kWave);
+                const int m = 16 * mt + r;
+                if (hi == 0 && 16 * t + lo < R2 && r < kTailRows) rows[(m / Q1) * LDD + (m % Q1) * R2 + 16 * t + lo] = v;
+              } else {
+                const int m = 16 * mt + 4 * hi + r;
+                if (m < C::M2 && 16 * t + lo < R2) rows[(m / Q1) * LDD + (m % Q1) * R2 + 16 * t + lo] = dp[mt][t][r];
+              }
+            }
+        if (batch_ends) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          if (b_cur.i1 != gf_i1) {   // rare (a share covers a fraction of one i1): the sums of the i1 before leave, G1[i1] is loaded
+            asm volatile("; another i1" ::: "memory");
+            if (gf_i1 != 0xffffffffu) flush_g1();
+            const float* g1 = gf.G1 + (size_t)b_cur.i1 * C::ROW1;
+#pragma unroll
+            for (int t = 0; t < C::RT1; ++t)
+#pragma unroll
+              for (int v = 0; v < KPH3 / 4; ++v) {   // B[k = n = KPH3 hi + s][c1 = 16 t + lo] = G1[i1][c1][n]
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (16 * t + lo < R1) x = *reinterpret_cast<const float4*>(g1 + (16 * t + lo) * C::N1 + KPH3 * hi + 4 * v);
+                gf_g1[4 * v][t] = x.x; gf_g1[4 * v + 1][t] = x.y; gf_g1[4 * v + 2][t] = x.z; gf_g1[4 * v + 3][t] = x.w;
+              }
+            gf_i1 = b_cur.i1;
+          }
+          // operands of both products out of the slot, then the MFMAs back to back
+          float b1[4][C::NT1];   // dG1: B[k = rho = 4 s + hi][n = 16 nt + lo]
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int nt = 0; nt < C::NT1; ++nt) b1[s4][nt] = gslot[(4 * s4 + hi) * LDD + 16 * nt + lo];
+          float a3[KS3];         // dG0: A[rho = lo][k = n = KPH3 hi + s]
+#pragma unroll
+          for (int v = 0; v < KPH3 / 4; ++v) {
+            const float4 x = *reinterpret_cast<const float4*>(gslot + lo * LDD + KPH3 * hi + 4 * v);
+            a3[4 * v] = x.x; a3[4 * v + 1] = x.y; a3[4 * v + 2] = x.z; a3[4 * v + 3] = x.w;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();   // every read of the slot is done before the next batch's rows land
+          TTEMB_PRIO(0);
+          // dG1[i1] += [G0 rows]^T (r1 x 16) . [dP] (16 x q1 r2)
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int nt = 0; nt < C::NT1; ++nt)
+#pragma unroll
+              for (int t = 0; t < C::RT1; ++t)
+                g1acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gf_g0[s4][t], b1[s4][nt], g1acc[t][nt], 0, 0, 0);
+          // dG0 parts = [dP] (16 x q1 r2) . G1[i1]^T (q1 r2 x r1); four interleaved accumulation chains
+          f32x4 g0p[4][C::RT1];
+#pragma unroll
+          for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+            for (int t = 0; t < C::RT1; ++t) g0p[c4][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s3 = 0; s3 < KS3; ++s3)
+#pragma unroll
+            for (int t = 0; t < C::RT1; ++t)
+              g0p[s3 & 3][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[s3], gf_g1[s3][t], g0p[s3 & 3][t], 0, 0, 0);
+          TTEMB_PRIO(2);
+          // accumulator row 4 hi + r = rho = (group rho / q0 of the batch, core row rho % q0), column c1 = 16 t + lo: the part of
+          // every group this wavefront staged (the finalize kernel sums the parts of the non-empty groups over i1)
+#pragma unroll
+          for (int t = 0; t < C::RT1; ++t) {
+            const f32x4 sum = (g0p[0][t] + g0p[1][t]) + (g0p[2][t] + g0p[3][t]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int rho = 4 * hi + r;
+              const bool on = rho / Q0 < GM && ((gf_mask >> (rho / Q0)) & 1u) != 0u && 16 * t + lo < R1;
+              buf_store1(r_part, on ? (b_cur.first_group + (uint32_t)(rho / Q0)) * (uint32_t)(C::ROW0 * 4) + 4u * ((rho % Q0) * R1 + 16 * t + lo) : kOob, sum[r]);
+            }
+          }
+          gf_batch = 0xffffffffu;
+          gf_mask = 0u;
+        }
+      }
+    } else
+#if defined(TTEMB_ABL) && (TTEMB_ABL & 512)   // (ablation 512: the dP table is not written -- with the epilogue launch skipped: what folding the epilogue into this kernel can save at most; timing only)
+    if (!FUSE && nnz == 0xffffffffu)
+#else
+    if (d_cur.z & kLastBit)
+#endif
+    {  // dP of a finished group, into its own slot
       const rsrc_t r_dp = make_rsrc(plan.dptab + (size_t)uniform(d_cur.y) * PF, (uint32_t)(PF * 4));
 #pragma unroll
       for (int mt = 0; mt < C::MT2; ++mt)
@@ -2027,6 +2242,9 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
     for (int i = 0; i < (FUSE ? 9 : 5); ++i) st_acc[i] += st_t[i + 1] - st_t[i];
     ++st_n;
 #endif
+  }
+  if constexpr (GF) {
+    if (gf_i1 != 0xffffffffu) flush_g1();   // what this wavefront still holds of dG1
   }
   if constexpr (FUSE) {
     // this wavefront's rows of the workgroup's slab: i2 = 8 (q GPW + lane group) + wave, every row of the slab is written by
@@ -2439,8 +2657,16 @@ __global__ __launch_bounds__(256) void fast3_finalize_kernel(GroupPlan plan, int
   const int n0 = p0 * row0;
   // the form the epilogue kernel took; the wide-rank chain (all_parts) writes every dG1 slab and the dG0 parts of the non-empty groups
   const bool sparse_any = sparse_groups(plan, (uint32_t)(p0 * p1));
-  // a poisoned plan (a bounded wait of the grouping pass ran out): every element this kernel produces is NaN
-  const float poison = plan_poisoned(plan, (uint32_t)(p0 * p1)) ? __uint_as_float(0x7fc00000u) : 0.f;
+  // a poisoned plan (a bounded wait of the grouping pass ran out): every gradient element this kernel produces is NaN.  In
+  // the fused modes NaN would go into the parameters and the Adagrad state, with nothing left to rerun: when the host hears
+  // of the fault anyway (the pinned word exists: ttemb_status / the next call return TTEMB_E_HIP) the update is SKIPPED and
+  // parameters and state stay as they were -- the NaN forward rows and the error are loud enough.  Without the host word (a
+  // graph captured before ttemb_init) NaN parameters remain the only signal.
+  const bool poisoned = plan_poisoned(plan, (uint32_t)(p0 * p1));
+  const bool loud = poisoned && plan.fault_host != nullptr;
+  if (upd.poison_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && (loud || !upd.sticky)) *upd.poison_out = loud ? 1u : 0u;
+  if (loud && upd.w[0] != nullptr) return;   // (wave- and grid-uniform)
+  const float poison = poisoned ? __uint_as_float(0x7fc00000u) : 0.f;
   const bool sparse = all_parts ? true : sparse_any;          // dG0 parts: skip the groups without ids by their counts
   const bool sparse_g1 = all_parts ? false : sparse_any;      // dG1 slabs: skip the slices without ids by their flags
   // dG1 has few terms per output (one per slice): one thread per FOUR consecutive outputs (16-byte loads; a row of G1 is a
@@ -2907,7 +3133,8 @@ static int prepare(const DevShape& s, const CorePtrs& cores, bool bwd, const int
   if (plan_state <= 1 && header == nullptr) return fail(TTEMB_E_WORKSPACE, "fast path needs the workspace header");
   plan->epochs = reinterpret_cast<uint64_t*>(header);
   plan->rcount = plan->epochs ? plan->epochs + 2 : nullptr;
-  static_assert(16 + (int64_t)kCountBanks * kMaxRanges * 8 <= kFast3HeaderBytes, "the header holds the epoch words and every bank of range counters");
+  plan->ticket = header ? reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(header) + kHeaderPoisonOffset + 8) : nullptr;
+  static_assert(kHeaderPoisonOffset + 16 <= kFast3HeaderBytes, "the header holds the epoch words, every bank of range counters, the poison word and the ticket");
   const bool external = plan_buf != nullptr && plan_bytes >= fast3_plan_bytes(s, nnz);
   if (plan_state != 0 && !external) return fail(TTEMB_E_BADARG, "this call needs a plan buffer of ttemb_plan_bytes() bytes");
   const bool reuse = plan_state >= 2;
@@ -3131,12 +3358,19 @@ static int run_backward_wide(const DevShape& s, const CorePtrs& cores, const Gro
   static_assert(C::ROW2 % 256 == 0, "the E reduce takes 256 columns per launch row");
   const int tiles = (int)reduce_tiles(nnz);
   const size_t reduce_lds = (size_t)(2 * s.p[2] + 1) * 4 + kRowsB * 2;
+#if defined(TTEMB_ABL) && (TTEMB_ABL & 2048)   // (ablation 2048: no E stores in the wide chunk kernel, no reduce launch: what the E round trip costs; timing only)
+  if (nnz < 0) {
+#else
   if (shared_slab(s)) {
+#endif
     rc = launch_zero(plan.g2part, (size_t)s.p[2] * C::ROW2 * 4, st, "zero the shared dG2 slab");
     if (rc) return rc;
     hipLaunchKernelGGL((fast3_dg2_reduce_kernel<256, kRowsB, NWB, true>), dim3((unsigned)tiles, C::ROW2 / 256), dim3(NWB * 64), reduce_lds,
                        st, plan, (int)G, (uint32_t)s.p[2], (uint32_t)reduce_rows(nnz), (uint32_t)C::ROW2);
   } else {
+#if defined(TTEMB_ABL) && (TTEMB_ABL & 2048)
+    if (nnz < 0)
+#endif
     hipLaunchKernelGGL((fast3_dg2_reduce_kernel<256, kRowsB, NWB, false>), dim3((unsigned)tiles, C::ROW2 / 256), dim3(NWB * 64), reduce_lds,
                        st, plan, (int)G, (uint32_t)s.p[2], (uint32_t)reduce_rows(nnz), (uint32_t)C::ROW2);
   }
@@ -3255,6 +3489,31 @@ int launch_forward_fast3(const DevShape& s, const CorePtrs& cores, const int64_t
   return fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
 }
 
+// The backward chunk kernel that also forms the per-group products (GF): shapes with at least two groups per MFMA tile and
+// q1 r2 a multiple of 16 (the K permutation of its dG0 product moves 16-byte pieces).  Taken by frontiers with few ids per
+// group (the rule of the forward that forms its own prefix products) whose dG2 reduction is not fused into the chunk kernel.
+#ifndef TTEMB_GFUSE_IDS
+#define TTEMB_GFUSE_IDS -1
+#endif
+constexpr int64_t kGFuseIdsPerGroup = TTEMB_GFUSE_IDS;   // (0 switches the route off, another value replaces the rule)
+template <int Q0, int Q1, int Q2, int R1, int R2>
+struct GFuseCfg {
+  using C = Cfg<Q0, Q1, Q2, R1, R2>;
+  static constexpr bool ok = 16 / Q0 >= 2 && C::N1 % 16 == 0 && Q1 > 1;
+};
+static int64_t gfuse_limit(const DevShape& s) { return kGFuseIdsPerGroup >= 0 ? kGFuseIdsPerGroup : (s.q[0] == 8 ? 16 : 8); }
+
+static bool gfuse_pays(const DevShape& s, int64_t nnz) {   // (the rule run_backward applies, for ttemb_kernel_family)
+  if (gfuse_limit(s) <= 0 || !classify(s) || fused_dg2(s)) return false;
+  bool ok = false;
+#define TTEMB_X(a, b, c, d, e) if (shape_is(s, a, b, c, d, e)) ok = GFuseCfg<a, b, c, d, e>::ok;
+  TTEMB_FAST3_SHAPES(TTEMB_X)
+#undef TTEMB_X
+  const int64_t G = num_groups(s);
+  return ok && nnz < gfuse_limit(s) * G && (uint64_t)G * (uint64_t)s.p[0] < (uint64_t(1) << 40);
+}
+bool fast3_group_products_in_chain(const DevShape& s, int64_t nnz, int64_t B) { return fits_piece(s, nnz, B) && gfuse_pays(s, nnz); }
+
 template <int Q0, int Q1, int Q2, int R1, int R2>
 static int run_backward(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int64_t nnz, int64_t B,
                         const float* d_output, const CorePtrsMut& d_cores, const FusedUpdate& upd, hipStream_t st) {
@@ -3265,6 +3524,8 @@ static int run_backward(const DevShape& s, const CorePtrs& cores, const GroupPla
   constexpr size_t wave_lds = (size_t)(C::PB_FLOATS + C::BB2_FLOATS + C::OB_FLOATS) * sizeof(float);
   constexpr bool kCanFuse = fuse_shape(R2, C::ROW2);
   const bool fused = kCanFuse && fused_dg2(s);
+  constexpr bool kCanGFuse = GFuseCfg<Q0, Q1, Q2, R1, R2>::ok;
+  const bool gfuse = kCanGFuse && !fused && gfuse_pays(s, nnz);
   if constexpr (!kCanFuse) {
     if (fused_dg2(s)) return fail(TTEMB_E_HIP, "internal: fused_dg2() and fuse_shape() out of step");
   }
@@ -3278,9 +3539,31 @@ static int run_backward(const DevShape& s, const CorePtrs& cores, const GroupPla
       if (rc) return rc;
       profile_begin(2, st);
       hipLaunchKernelGGL((fast3_bwd_chunk_kernel<Q0, Q1, Q2, R1, R2, true>), dim3((unsigned)fused_tiles(s, nnz)), dim3(kFuseWaves * 64),
-                         lds, st, cores.c[2], (uint32_t)G, (uint32_t)s.p[2], (uint32_t)nnz, d_output, (uint32_t)(B * s.D * 4), plan);
+                         lds, st, cores.c[2], (uint32_t)G, (uint32_t)s.p[2], (uint32_t)nnz, d_output, (uint32_t)(B * s.D * 4), plan, GroupFuse{});
       profile_end(2, st);
       rc = check_hip(hipGetLastError(), "fast3_bwd_chunk_kernel (fused)");
+      if (rc) return rc;
+    }
+  } else if (gfuse) {
+    if constexpr (kCanGFuse) {   // chunk products AND the per-group products in one launch: no dP table, no epilogue launch
+      const size_t lds = kChainWaves * (wave_lds + 16 * (C::N1 + 4) * sizeof(float));
+      static LdsGate lds_ok;
+      unsigned grid = 0;
+      rc = chain_grid(reinterpret_cast<const void*>(fast3_bwd_chunk_kernel<Q0, Q1, Q2, R1, R2, false, true>), lds, kBwdWgsPerCu, &lds_ok, &grid);
+      if (rc) return rc;
+      rc = launch_zero(plan.g1part, (size_t)s.p[1] * C::ROW1 * 4, st, "zero the dG1 slab");   // (the kernel adds with float atomics)
+      if (rc) return rc;
+      GroupFuse gf;
+      gf.G0 = cores.c[0];
+      gf.G1 = cores.c[1];
+      gf.dg1 = plan.g1part;
+      gf.p0 = (uint32_t)s.p[0];
+      gf.p0_magic = (uint64_t(1) << 40) / (uint64_t)s.p[0] + 1ull;
+      profile_begin(2, st);
+      hipLaunchKernelGGL((fast3_bwd_chunk_kernel<Q0, Q1, Q2, R1, R2, false, true>), dim3(grid), dim3(kChainWaves * 64), lds, st, cores.c[2],
+                         (uint32_t)G, (uint32_t)s.p[2], (uint32_t)nnz, d_output, (uint32_t)(B * s.D * 4), plan, gf);
+      profile_end(2, st);
+      rc = check_hip(hipGetLastError(), "fast3_bwd_chunk_kernel (group products fused)");
       if (rc) return rc;
     }
   } else {
@@ -3291,7 +3574,7 @@ static int run_backward(const DevShape& s, const CorePtrs& cores, const GroupPla
     if (rc) return rc;
     profile_begin(2, st);
     hipLaunchKernelGGL((fast3_bwd_chunk_kernel<Q0, Q1, Q2, R1, R2, false>), dim3(grid), dim3(kChainWaves * 64), lds, st, cores.c[2],
-                       (uint32_t)G, (uint32_t)s.p[2], (uint32_t)nnz, d_output, (uint32_t)(B * s.D * 4), plan);
+                       (uint32_t)G, (uint32_t)s.p[2], (uint32_t)nnz, d_output, (uint32_t)(B * s.D * 4), plan, GroupFuse{});
     profile_end(2, st);
     rc = check_hip(hipGetLastError(), "fast3_bwd_chunk_kernel");
     if (rc) return rc;
@@ -3312,21 +3595,27 @@ static int run_backward(const DevShape& s, const CorePtrs& cores, const GroupPla
   }
   rc = check_hip(hipGetLastError(), "fast3_dg2_reduce_kernel");
   if (rc) return rc;
-  const int gpw = epi_groups_per_wave(s), slices = epi_slices(s);
-  constexpr int EW = EpiCfg<Q0, Q1, Q2, R1, R2>::WAVES;
-  const unsigned epi_blocks = (unsigned)((slices + EW - 1) / EW) * (unsigned)s.p[1];
-  profile_begin(8, st);
-  hipLaunchKernelGGL((fast3_group_epilogue_kernel<Q0, Q1, Q2, R1, R2>), dim3(epi_blocks),
-                     dim3(EW * 64), 0, st, cores.c[0], cores.c[1], (uint32_t)s.p[0], (uint32_t)s.p[1], (uint32_t)gpw, (uint32_t)slices, plan);
-  profile_end(8, st);
-  rc = check_hip(hipGetLastError(), "fast3_group_epilogue_kernel");
-  if (rc) return rc;
+  const int gpw = epi_groups_per_wave(s), slices = gfuse ? 1 : epi_slices(s);
+  if (!gfuse) {
+    constexpr int EW = EpiCfg<Q0, Q1, Q2, R1, R2>::WAVES;
+    const unsigned epi_blocks = (unsigned)((slices + EW - 1) / EW) * (unsigned)s.p[1];
+    profile_begin(8, st);
+#if defined(TTEMB_ABL) && (TTEMB_ABL & 512)
+    if (fused)
+#endif
+    hipLaunchKernelGGL((fast3_group_epilogue_kernel<Q0, Q1, Q2, R1, R2>), dim3(epi_blocks),
+                       dim3(EW * 64), 0, st, cores.c[0], cores.c[1], (uint32_t)s.p[0], (uint32_t)s.p[1], (uint32_t)gpw, (uint32_t)slices, plan);
+    profile_end(8, st);
+    rc = check_hip(hipGetLastError(), "fast3_group_epilogue_kernel");
+    if (rc) return rc;
+  }
   {
+    // (group products fused: ONE dG1 slab, whole; dG0 parts of the non-empty groups only -- the form the wide chain leaves)
     const int g2_floats = s.p[2] * C::ROW2, g1_floats = s.p[1] * C::ROW1;
     const int wgs = (g2_floats + s.p[0] * C::ROW0 + 31) / 32 + (g1_floats + 1023) / 1024;   // dG2 | dG0, then dG1
     profile_begin(9, st);
     hipLaunchKernelGGL(fast3_finalize_kernel, dim3((unsigned)wgs), dim3(256), 0, st, plan, (int)slab_count(s, nnz), slices,
-                       s.p[0], s.p[1], g2_floats, (int)C::ROW0, g1_floats, Q2, R2, d_cores.c[0], d_cores.c[1], d_cores.c[2], upd, 0);
+                       s.p[0], s.p[1], g2_floats, (int)C::ROW0, g1_floats, Q2, R2, d_cores.c[0], d_cores.c[1], d_cores.c[2], upd, gfuse ? 1 : 0);
     profile_end(9, st);
   }
   profile_end(1, st);
@@ -3340,6 +3629,9 @@ int launch_backward_fast3(const DevShape& s, const CorePtrs& cores, const int64_
   FusedUpdate upd;
   memset(&upd, 0, sizeof(upd));
   if (update != nullptr) upd = *update;
+  upd.poison_out = header != nullptr ? reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(header) + kHeaderPoisonOffset) : nullptr;
+  upd.sticky = 0;
+  static_assert(kHeaderPoisonOffset == 16 + (int64_t)kCountBanks * kMaxRanges * 8, "the poison word sits behind the range counters");
   // every core gradient is written whole by the finalize kernel (an empty call in a fused mode is a no-op)
   for (int t = 0; t < s.T; ++t) {
     if (nnz > 0 || update != nullptr) continue;
@@ -3366,6 +3658,7 @@ int launch_backward_fast3(const DevShape& s, const CorePtrs& cores, const int64_
                    nullptr, 0, 0, &plan, st, header, tab + k);
       if (rc) break;
       upd.eps = k > 0 ? 1.f : 0.f;   // (dense mode: finalize adds to the gradient instead of writing it)
+      upd.sticky = k > 0 ? 1 : 0;    // (a poisoned piece marks the whole call)
       rc = fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
       if (wide(s)) {
 #define TTEMB_X(a, b, c, d, e) if (shape_is(s, a, b, c, d, e)) rc = run_backward_wide<a, b, c, d, e>(s, cores, plan, np, piece_rows(s), d_output, d_cores, upd, st);

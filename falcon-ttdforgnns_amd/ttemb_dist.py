@@ -28,7 +28,13 @@ class FlatGradBucket:
             self.offsets.append(off)
             off += (n + 3) & ~3
         dev = self.params[0].device
-        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        # behind the gradients: four floats of which the first is the FAULT COUNT of the step -- 1 on a rank whose gradient
+        # came from a poisoned plan (a device-side wait of the grouping pass ran out: that gradient is NaN), else 0.  It is
+        # summed by the same all-reduce, so every rank learns whether ANY rank faulted and all of them skip the update
+        # together (TTDataParallel.flush): replicas stay identical, nobody trains on NaN.
+        self.n_grad = off
+        self.flat = torch.zeros(off + 4, dtype=torch.float32, device=dev)
+        self.fault = self.flat[off:off + 1]
         self.views = [self.flat[o:o + n].view_as(p) for o, n, p in zip(self.offsets, self.sizes, self.params)]
 
     def pack(self) -> None:
@@ -39,10 +45,14 @@ class FlatGradBucket:
                 v.copy_(p.grad)
 
 
-def default_apply(weight: torch.Tensor, grad: torch.Tensor, lr: float) -> None:
-    """Fused SGD epilogue on the device (libttemb_hip.so); no CPU fallback."""
+def default_apply(weight: torch.Tensor, grad: torch.Tensor, lr: float, skip: Optional[torch.Tensor] = None) -> None:
+    """Fused SGD epilogue on the device (libttemb_hip.so); no CPU fallback.  ``skip``: a device float -- non-zero leaves the
+    weights as they are (some rank's gradient of this step came from a poisoned plan)."""
     import ttemb_native as nat
-    nat.sgd_step(weight.view(-1), grad.reshape(-1), lr)
+    if skip is None:
+        nat.sgd_step(weight.view(-1), grad.reshape(-1), lr)
+    else:
+        nat.sgd_step_guarded(weight.view(-1), grad.reshape(-1), lr, skip)
 
 
 class TTDataParallel:
@@ -78,7 +88,7 @@ class TTDataParallel:
     def adopt_parameters(self) -> None:
         """Move the parameters into one flat buffer (same layout as the gradient bucket)."""
         b = self.bucket
-        self.flat_weights = torch.zeros_like(b.flat)
+        self.flat_weights = torch.zeros(b.n_grad, dtype=torch.float32, device=b.flat.device)
         self.weight_views = [self.flat_weights[o:o + n].view_as(p) for o, n, p in zip(b.offsets, b.sizes, b.params)]
         with torch.no_grad():
             for v, p in zip(self.weight_views, b.params):
@@ -118,6 +128,15 @@ class TTDataParallel:
                     v.copy_(p.grad)
             for p in b.params:
                 p.grad = None
+        # this rank's fault count rides in the bucket: the word the grouped backward's last kernel left in the workspace
+        # header (1 = poisoned plan; nothing is synchronised here).  Backwards of the other kernel families have no
+        # bounded waits and do not write the word.  A fault some EARLIER call reported raises here, before NaN gradients
+        # are summed into every rank.
+        word = self._poison_word()
+        if word is None:
+            b.fault.zero_()
+        else:
+            b.fault.copy_(word)
         work = None
         if self.world > 1:
             work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=overlap)
@@ -137,8 +156,18 @@ class TTDataParallel:
         if work is not None:
             work.wait()
         b = self.bucket
+        guard = (b.fault,) if self.apply_fn is default_apply else ()   # (an injected epilogue -- the CPU tests' -- takes no guard)
         if self._flat_ok():
-            self.apply_fn(self.flat_weights, b.flat, lr / self.world)
+            self.apply_fn(self.flat_weights, b.flat[:b.n_grad], lr / self.world, *guard)
         else:
             for p, g in zip(b.params, b.views):
-                self.apply_fn(p.data, g, lr / self.world)
+                self.apply_fn(p.data, g, lr / self.world, *guard)
+
+    def _poison_word(self) -> Optional[torch.Tensor]:
+        m = self.module
+        if not self.bucket.flat.is_cuda or not getattr(m, "_last_bwd_grouped", False):
+            return None
+        import ttemb_native as nat
+        nat.status()   # an expired wait an earlier call reported: RuntimeError on this rank, before the collective
+        return nat.poison_word(m._ws)
+

@@ -21,16 +21,16 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TTEMB_LIB") or os.path.join(_HERE, "lib", "libttemb_hip.so")
 
 MAX_CORES = 4
-ABI_VERSION = 2
+ABI_VERSION = 3
 OP_FORWARD, OP_BACKWARD, OP_PREPROCESS, OP_CACHE_POPULATE = 0, 1, 2, 3
 PATH_AUTO, PATH_GENERIC, PATH_FAST3, PATH_PER_BAG = 0, 1, 2, 3
 
 # every symbol include/ttemb.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = (
     "ttemb_abi_version", "ttemb_last_error", "ttemb_workspace_bytes", "ttemb_plan_bytes", "ttemb_set_path",
-    "ttemb_profile_enable", "ttemb_profile_read", "ttemb_kernel_family", "ttemb_set_piece_limits", "ttemb_status", "ttemb_set_spin_limit",
+    "ttemb_profile_enable", "ttemb_profile_read", "ttemb_kernel_family", "ttemb_set_piece_limits", "ttemb_init", "ttemb_status", "ttemb_set_spin_limit",
     "ttemb_forward", "ttemb_forward_group", "ttemb_forward_lookup", "ttemb_backward_dense", "ttemb_backward_sgd", "ttemb_backward_adagrad",
-    "ttemb_sgd_step", "ttemb_adagrad_step", "ttemb_cache_update", "ttemb_cache_update_one_sweep", "ttemb_cache_populate",
+    "ttemb_sgd_step", "ttemb_sgd_step_guarded", "ttemb_adagrad_step", "ttemb_cache_update", "ttemb_cache_update_one_sweep", "ttemb_cache_populate",
     "ttemb_preprocess", "ttemb_preprocess_update", "ttemb_cache_forward", "ttemb_cache_backward_sgd",
     "ttemb_cache_backward_dense", "ttemb_cache_backward_rowwise_adagrad",
 )
@@ -68,6 +68,9 @@ def _load() -> ctypes.CDLL:
     vp, i64, i32, f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_float
     shp = ctypes.POINTER(Shape)
     lib.ttemb_abi_version.restype = ctypes.c_int
+    if lib.ttemb_abi_version() != ABI_VERSION:   # (before any other symbol is bound: a stale library fails HERE, with this message)
+        raise ImportError(f"{LIB_PATH}: ABI version {lib.ttemb_abi_version()}, this binding needs {ABI_VERSION} -- rebuild the library "
+                          "(`make -C falcon-ttdforgnns_amd/csrc`)")
     lib.ttemb_last_error.restype = ctypes.c_char_p
     lib.ttemb_workspace_bytes.restype = i64
     lib.ttemb_workspace_bytes.argtypes = [shp, i32, i64, i64]
@@ -78,6 +81,7 @@ def _load() -> ctypes.CDLL:
     lib.ttemb_set_piece_limits.argtypes = [i64, i64]
     lib.ttemb_set_spin_limit.argtypes = [i64]
     lib.ttemb_status.argtypes = []
+    lib.ttemb_init.argtypes = []
     lib.ttemb_plan_bytes.restype = i64
     lib.ttemb_plan_bytes.argtypes = [shp, i64]
     lib.ttemb_forward.argtypes = [shp, vp, vp, vp, vp, i64, vp, i64, vp, vp, i64, vp, i64, vp]
@@ -87,6 +91,7 @@ def _load() -> ctypes.CDLL:
     lib.ttemb_backward_sgd.argtypes = [shp, vp, vp, vp, vp, i64, vp, i64, vp, f32, vp, i64, vp, i64, vp]
     lib.ttemb_backward_adagrad.argtypes = [shp, vp, vp, vp, vp, vp, i64, vp, i64, vp, f32, f32, vp, i64, vp, i64, vp]
     lib.ttemb_sgd_step.argtypes = [vp, vp, i64, f32, vp]
+    lib.ttemb_sgd_step_guarded.argtypes = [vp, vp, i64, f32, vp, vp]
     lib.ttemb_adagrad_step.argtypes = [vp, vp, vp, i64, f32, f32, vp]
     lib.ttemb_cache_update.argtypes = [vp, i64, vp, vp, i64, vp]
     lib.ttemb_cache_update_one_sweep.argtypes = [vp, i64, vp, vp, i64, vp]
@@ -101,8 +106,6 @@ def _load() -> ctypes.CDLL:
         fn = getattr(lib, name)
         if name not in ("ttemb_last_error", "ttemb_workspace_bytes", "ttemb_plan_bytes"):
             fn.restype = ctypes.c_int
-    if lib.ttemb_abi_version() != ABI_VERSION:
-        raise ImportError("libttemb_hip.so ABI version mismatch")
     return lib
 
 
@@ -173,6 +176,8 @@ class Workspace:
         self._retired: List[torch.Tensor] = []
 
     def get(self, nbytes: int, device: torch.device) -> torch.Tensor:
+        if not _initialised:
+            init()
         nbytes = max(int(nbytes), 256)
         if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
             if self.buf is not None and self._in_a_graph:
@@ -182,6 +187,21 @@ class Workspace:
         if not self._in_a_graph and torch.cuda.is_current_stream_capturing():
             self._in_a_graph = True
         return self.buf
+
+
+_initialised = False
+
+
+def init() -> None:
+    """``ttemb_init()``: the pinned host word an expired device-side wait reports to -- the library's one allocation, made
+    here and never inside a lookup.  Called by the first ``Workspace.get`` of the process that is not under a stream capture
+    (every lookup through this module asks its workspace first) and by ``TTEmbeddingBag.capture`` before it captures; a
+    failure is not an error of the caller's (such a process reports expired waits through NaN results only)."""
+    global _initialised
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        return   # not now: no allocation during a capture; the next eager call tries again
+    _initialised = True
+    LIB.ttemb_init()
 
 
 _size_cache: dict = {}   # (kind, shape bytes, op, nnz, B) -> bytes; emptied when the kernel family changes
@@ -243,6 +263,8 @@ def plan_bytes(shape: Shape, nnz: int) -> int:
 
 FAMILY_SCALAR, FAMILY_PER_BAG, FAMILY_PER_BAG_RT, FAMILY_GROUPED, FAMILY_GROUPED_WIDE, FAMILY_MERGED, FAMILY_PADDED = 0, 1, 2, 3, 4, 16, 32
 FAMILY_PREFIX_IN_CHAIN = 64   # | on FAMILY_GROUPED: a whole forward of this size forms the prefix products in its chain kernel
+FAMILY_GROUP_PRODUCTS_IN_CHAIN = 128   # | on FAMILY_GROUPED: a backward of this size forms the per-group products in its chunk kernel
+FAMILY_ROUTE_FLAGS = FAMILY_PREFIX_IN_CHAIN | FAMILY_GROUP_PRODUCTS_IN_CHAIN   # which kernels of the grouped family a call of this size takes
 
 
 def kernel_family(shape: Shape, nnz: int, B: int, ids_with_offsets: bool = True) -> int:
@@ -333,6 +355,23 @@ def backward_adagrad(shape: Shape, cores, opt_state, indices, rowidx, nnz: int, 
 def sgd_step(weights: torch.Tensor, grads: torch.Tensor, lr: float) -> None:
     with _on_device(weights.device):
         _check(LIB.ttemb_sgd_step(_ptr(weights), _ptr(grads), weights.numel(), lr, _stream(weights)))
+
+
+HEADER_POISON_OFFSET = 32784   # TTEMB_HEADER_POISON_OFFSET
+
+
+def sgd_step_guarded(weights: torch.Tensor, grads: torch.Tensor, lr: float, skip: torch.Tensor) -> None:
+    """``weights -= lr * grads`` unless the device float ``skip[0]`` is non-zero (then nothing is written)."""
+    with _on_device(weights.device):
+        _check(LIB.ttemb_sgd_step_guarded(_ptr(weights), _ptr(grads), weights.numel(), lr, _ptr(skip), _stream(weights)))
+
+
+def poison_word(ws: "Workspace") -> Optional[torch.Tensor]:
+    """int32[1] view of the word the last GROUPED backward on this workspace left in its header (1 = poisoned plan and the
+    host hears of it); None before the workspace exists.  Meaningful only right after a grouped backward."""
+    if ws.buf is None or ws.buf.numel() < HEADER_POISON_OFFSET + 4:
+        return None
+    return ws.buf[HEADER_POISON_OFFSET:HEADER_POISON_OFFSET + 4].view(torch.int32)
 
 
 def adagrad_step(weights, state, grads, lr: float, eps: float) -> None:

@@ -10,7 +10,7 @@
  * calls except process-wide DIAGNOSTIC switches that never change a result: the kernel-family
  * override (ttemb_set_path), the piece limits (ttemb_set_piece_limits), the spin limit (ttemb_set_spin_limit) and the
  * event profiler (ttemb_profile_enable) -- and one pinned host word through which a device-side wait that ran out is
- * reported (ttemb_status).  A caller that never touches them has none.
+ * reported (ttemb_init / ttemb_status).  A caller that never touches them has none.
  *
  * Tracing: with TTEMB_ROCTX=1 in the environment every lookup / cache entry point is bracketed by a roctx range
  * (roctxRangePush / Pop from librocprofiler-sdk-roctx.so or libroctx64.so, looked up at run time), so a
@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TTEMB_ABI_VERSION 2
+#define TTEMB_ABI_VERSION 3   /* 3: + ttemb_init / ttemb_status / ttemb_set_spin_limit, TTEMB_FAMILY_PREFIX_IN_CHAIN, plan of G + 3 group words */
 #define TTEMB_MAX_CORES 4
 
 enum {
@@ -116,12 +116,28 @@ int ttemb_set_piece_limits(int64_t rows, int64_t ids);
  * numbers (the reference's kernels cannot time out; it checks its launches with AT_CUDA_CHECK,
  * FBTT/tt_embeddings_cuda.cu:1666,1742,1845):
  *   - the call's plan is POISONED on the device: the forward writes NaN into its whole output window, a backward on that
- *     plan writes NaN gradients (fused modes: NaN weights); no kernel walks the chunk table;
+ *     plan writes NaN gradients; no kernel walks the chunk table.  A FUSED backward (ttemb_backward_sgd / _adagrad) on a
+ *     poisoned plan leaves the parameters and the optimizer state UNTOUCHED when the host word below exists (the step can
+ *     be repeated); without the word -- a graph captured before ttemb_init() -- it writes NaN parameters, the only signal
+ *     such a graph has;
  *   - the reason is stored to a pinned host word, and the next ttemb_forward* / ttemb_backward* call of the process that
- *     sees it returns TTEMB_E_HIP with a message (once per fault; no synchronisation is added for this).
- * ttemb_status() is that check as a call of its own, for callers that synchronise: 0, or TTEMB_E_HIP (and the fault is
- * consumed).  ttemb_set_spin_limit is a DIAGNOSTIC, process-wide: tries of those waits (0 = the default of 2^20, about 1.5 s;
- * negative = none at all, every wait expires -- how tests reach the fault path). */
+ *     sees it returns TTEMB_E_HIP with a message (once per fault, consumed by exactly one caller through an atomic
+ *     exchange; no synchronisation is added for this).  The error refers to an EARLIER call; the call that returns it has
+ *     not been started.
+ * ttemb_init() creates that word (64 bytes of pinned, device-mapped host memory -- the ONE allocation this library ever
+ * makes, which is why it is a call of its own and no lookup does it): call it once per process, from the host, OUTSIDE any
+ * stream capture and before capturing a graph that contains grouped lookups.  Lookups made before it report an expired wait
+ * through their NaN results only.  Idempotent; TTEMB_E_HIP when the memory cannot be had.
+ * ttemb_status() is the check as a call of its own, for callers that synchronise: 0, or TTEMB_E_HIP (and the fault is
+ * consumed); it creates the word when ttemb_init() has not.  ttemb_set_spin_limit is a DIAGNOSTIC, process-wide: tries of
+ * those waits (0 = the default of 2^20, about 1.5 s; negative = none at all, every wait expires -- how tests reach the
+ * fault path). */
+int ttemb_init(void);
+/* Byte offset, inside the header every lookup workspace begins with, of the uint32 the LAST grouped backward on that
+ * workspace left: 1 = its plan was poisoned and the host word exists (gradients NaN, a fused update skipped), 0 = healthy.
+ * Written by every backward of the grouped families (ttemb_kernel_family & 7 in {GROUPED, GROUPED_WIDE}); not written by the
+ * others, which have no bounded waits. */
+#define TTEMB_HEADER_POISON_OFFSET 32784
 int ttemb_status(void);
 int ttemb_set_spin_limit(int64_t tries);
 
@@ -139,7 +155,11 @@ int ttemb_set_spin_limit(int64_t tries);
  *   zeros),
  * | TTEMB_FAMILY_PREFIX_IN_CHAIN when a whole ttemb_forward of this size forms the prefix products G0[i0].G1[i1] inside
  *   its chain kernel (fewer than 8 ids per (i0, i1) group on average, 16 for q0 = 8: 819 200 ids on the papers100M table) instead of in
- *   a launch of its own; the plan it leaves and every result are the same. */
+ *   a launch of its own; the plan it leaves and every result are the same,
+ * | TTEMB_FAMILY_GROUP_PRODUCTS_IN_CHAIN when a backward of this size forms the two per-group products (the dG0 parts and
+ *   dG1: FBTT/tt_embeddings_cuda.cu:531-609 runs them as the t = 0 GEMM pair over a partial-product table) inside its chunk
+ *   kernel, while a group's dP is still in registers: no dP table, no epilogue launch.  Same rule on the ids per group,
+ *   for shapes whose dG2 reduction is not already fused into the chunk kernel (rank 32; large p2). */
 enum {
   TTEMB_FAMILY_SCALAR = 0,
   TTEMB_FAMILY_PER_BAG = 1,
@@ -148,7 +168,8 @@ enum {
   TTEMB_FAMILY_GROUPED_WIDE = 4,
   TTEMB_FAMILY_MERGED = 16,
   TTEMB_FAMILY_PADDED = 32,
-  TTEMB_FAMILY_PREFIX_IN_CHAIN = 64
+  TTEMB_FAMILY_PREFIX_IN_CHAIN = 64,
+  TTEMB_FAMILY_GROUP_PRODUCTS_IN_CHAIN = 128
 };
 int ttemb_kernel_family(const ttemb_shape_t* shape, int64_t nnz, int64_t B, int32_t ids_with_offsets);
 
@@ -159,7 +180,8 @@ int ttemb_kernel_family(const ttemb_shape_t* shape, int64_t nnz, int64_t B, int3
  * kernel alone, 3 = the id-grouping pass including the prefix-product kernel, 4 = the cache probe pass of
  * ttemb_preprocess / ttemb_preprocess_update, 5 = its partition scatter, 6 = the cached-row gather of ttemb_cache_forward,
  * 7 = the cached-row update of ttemb_cache_backward_*, 8 = the group epilogue kernel of the backward, 9 = its finalize
- * kernel) and returns its duration in milliseconds.  Off by default; costs two event records per bracket when on. */
+ * kernel) and returns its duration in milliseconds; a slot no launch has bracketed since the last ttemb_profile_enable(1)
+ * is TTEMB_E_BADARG (enabling forgets every earlier bracket).  Off by default; costs two event records per bracket when on. */
 int ttemb_profile_enable(int32_t on);
 int ttemb_profile_read(int32_t which, float* ms_host);
 
@@ -236,6 +258,12 @@ int ttemb_backward_adagrad(const ttemb_shape_t* shape, float* const* cores,
 /* Flat optimiser epilogues over n floats (used after the data-parallel all-reduce of
  * the flattened core gradients; same arithmetic as tt_embeddings_cuda.cu:381-419). */
 int ttemb_sgd_step(float* weights, const float* grads, int64_t n, float lr, void* stream);
+/* The same step, skipped as a whole when the device float *skip is non-zero.  The data-parallel step (no counterpart in the
+ * reference: its DDP path is a stub, sage_dgl_partition.py:198-255) all-reduces, next to the gradients, the number of ranks
+ * whose gradient came from a POISONED plan (the word at TTEMB_HEADER_POISON_OFFSET of the workspace the backward ran on,
+ * see "Device-side faults"): when any did, the summed gradient is NaN and every rank skips the update together -- replicas
+ * stay identical and untouched, the faulted rank's next call returns TTEMB_E_HIP. */
+int ttemb_sgd_step_guarded(float* weights, const float* grads, int64_t n, float lr, const float* skip, void* stream);
 int ttemb_adagrad_step(float* weights, float* state, const float* grads, int64_t n,
                        float lr, float eps, void* stream);
 

@@ -86,7 +86,8 @@ def test_flat_bucket_layout():
     from ttemb_dist import FlatGradBucket
     ps = [torch.nn.Parameter(torch.zeros(1, 5, 7)), torch.nn.Parameter(torch.zeros(1, 3, 2))]
     b = FlatGradBucket(ps)
-    assert b.offsets == [0, 36] and b.flat.numel() == 36 + 8
+    assert b.offsets == [0, 36] and b.n_grad == 36 + 8 and b.flat.numel() == 36 + 8 + 4   # gradients, then the fault count
+    assert b.fault.data_ptr() == b.flat[44:].data_ptr() and float(b.fault) == 0.0
     ps[0].grad = torch.ones_like(ps[0])
     b.pack()
     assert b.flat[:35].eq(1).all() and b.flat[35:].eq(0).all()

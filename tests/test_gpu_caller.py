@@ -279,3 +279,24 @@ def test_module_call_in_pieces_matches_the_uncut_call(sparse):
             torch.testing.assert_close(cb.data, ca.data, rtol=1e-4, atol=1e-6)
         else:
             torch.testing.assert_close(cb.grad, ca.grad, rtol=1e-4, atol=1e-4 * float(ca.grad.abs().max()))
+
+
+def test_bench_two_ranks_as_a_fresh_child_process():
+    """`python bench.py --gpus 2` the way the driver's scaling run starts it -- a fresh process that launches its own ranks
+    through torch.distributed.run, rendezvous on 127.0.0.1, TTDataParallel.step(overlap=True) every step -- rehearsed on the
+    one GPU of this box (TTEMB_BENCH_REHEARSAL=1: both ranks on GPU 0, gloo carries the all-reduce; RCCL needs a GPU per
+    rank).  Asserts the JSON line: two ranks, a per-rank time each, the weak-scaling value."""
+    import json
+    import subprocess
+    env = dict(os.environ, TTEMB_BENCH_REHEARSAL="1", OMP_NUM_THREADS="4")
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["dist"]["world_size"] == 2 and res["dist"]["backend"] == "gloo"
+    assert res["dist"]["rehearsal_on_one_gpu"] is True and len(res["dist"]["ms_per_step_by_rank"]) == 2
+    assert res["scaling"] == "weak" and res["config"]["parallelism"] == "dp2" and res["steps"] == 3
+    assert res["value"] > 0 and res["ms_per_step_gpu_events"] > 0 and res["roofline"]["kernel"].startswith("fast3_")

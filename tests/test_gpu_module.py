@@ -567,7 +567,7 @@ def test_cache_live_on_the_fast_path(ops, orc):
                                    atol=1e-5 + 2e-4 * float(np.abs(lr * gr).max()))
 
 
-def _dp_gpu_worker(rank, world, port, out_dir, overlap=False):
+def _dp_gpu_worker(rank, world, port, out_dir, overlap=False, poison_rank=-1):
     import os
     import sys
     from conftest import PKG, ROOT
@@ -592,8 +592,28 @@ def _dp_gpu_worker(rank, world, port, out_dir, overlap=False):
     g = torch.Generator().manual_seed(7 + rank)
     ids = torch.randperm(2449029, generator=g)[:60000]
     d_out = (torch.rand(60000, 100, generator=g) - 0.5) * 0.02
+    if rank == poison_rank:   # every bounded wait of this rank's grouping pass expires: NaN rows, NaN gradients
+        import ttemb_native as nat
+        nat.set_spin_limit(-1)
     out = emb(ids.cuda(), torch.arange(60001).cuda())
     out.backward(d_out.cuda())
+    if poison_rank >= 0:
+        import ttemb_native as nat
+        torch.cuda.synchronize()
+        nat.set_spin_limit(0)
+        if rank == poison_rank:
+            assert bool(torch.isnan(out).all())
+            with pytest.raises(RuntimeError, match="gave up waiting"):   # consumed here, so that step() below reaches the collective
+                nat.status()
+        dp.step(overlap=overlap)
+        dp.flush()
+        torch.cuda.synchronize()
+        # the fault count travelled with the gradients: BOTH ranks skipped the update
+        assert float(dp.bucket.fault.item()) == 1.0
+        torch.save({"start": start, "end": [c.detach().cpu().clone() for c in emb.tt_cores]}, os.path.join(out_dir, f"rank{rank}.pt"))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     dp.step(overlap=overlap)
     if overlap:  # the update is still pending; the next forward groups its ids, finishes the update, then looks up
         assert emb._before_weights is not None
@@ -636,6 +656,22 @@ def test_data_parallel_step_two_ranks_on_gpu(orc, tmp_path, overlap):
         ids2 = r[k]["ids"][:50000].numpy()
         want_rows = orc.tt_rows(ids2, new_cores, p, q, R)
         np.testing.assert_allclose(r[k]["out2"].numpy(), want_rows, rtol=1e-4, atol=1e-4 * float(np.abs(want_rows).max()))
+
+
+def test_a_poisoned_rank_makes_every_rank_skip_the_data_parallel_update(tmp_path):
+    """One rank's grouping pass gives up (ttemb_set_spin_limit(-1)): its gradient is NaN.  The count of such ranks rides in the
+    all-reduced bucket and the guarded SGD step (ttemb_sgd_step_guarded) skips the update on EVERY rank: replicas stay
+    identical and untouched instead of all-NaN."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_dp_gpu_worker, args=(2, port, str(tmp_path), False, 1), nprocs=2, join=True)
+    r = [torch.load(tmp_path / f"rank{k}.pt") for k in range(2)]
+    for t in range(3):
+        for k in range(2):
+            assert torch.equal(r[k]["end"][t], r[0]["start"][t]) and bool(torch.isfinite(r[k]["end"][t]).all())
 
 
 def test_bucket_accumulates_over_two_backwards_before_the_step(ops, orc):
@@ -740,7 +776,7 @@ def test_captured_lookup_on_the_grouped_chain(ops, orc, n):
         ca.data.mul_(300.0)
         cb.data.copy_(ca.data)
     fam = nat.kernel_family(nat.make_shape(p, q, [1] + r + [1]), n, n, True)
-    assert fam == nat.FAMILY_GROUPED | (nat.FAMILY_PREFIX_IN_CHAIN if n < 8 * p[0] * p[1] else 0)
+    assert fam & ~nat.FAMILY_GROUP_PRODUCTS_IN_CHAIN == nat.FAMILY_GROUPED | (nat.FAMILY_PREFIX_IN_CHAIN if n < 8 * p[0] * p[1] else 0)
     cap = b.capture(n, n)
     rng = np.random.default_rng(14)
     offs = torch.arange(n + 1).cuda()
@@ -1140,7 +1176,8 @@ def test_the_reference_papers100M_invocation_with_its_five_percent_cache(ops, or
     assert torch.equal(got[1][:ntt], torch.arange(N, device="cuda")[~hit])
     shape = nat.make_shape(p, q, R)
     # the TT share rides on the grouped chain (unfused E table: p2 = 600); ~2 ids per group: the forward forms P in its chain kernel
-    assert nat.kernel_family(shape, ntt, N) == nat.FAMILY_GROUPED | nat.FAMILY_PREFIX_IN_CHAIN
+    # (p2 = 600: the dG2 reduction is not fused into the chunk kernel, and at ~4 ids per group the backward forms its group products there)
+    assert nat.kernel_family(shape, ntt, N) == nat.FAMILY_GROUPED | nat.FAMILY_PREFIX_IN_CHAIN | nat.FAMILY_GROUP_PRODUCTS_IN_CHAIN
     plain = ops.TTEmbeddingBag(n, D, r, p, q, sparse=False, use_cache=False, weight_dist="normal")
     for a, b in zip(plain.tt_cores, emb.tt_cores):
         a.data.copy_(b.data)

@@ -805,7 +805,7 @@ def test_shapes_off_the_instantiated_list(nat, orc, p, q, r, n_ids):
     shape = nat.make_shape(p, q, R)
     rng = np.random.default_rng(sum(p) + sum(q) + sum(r) + n_ids)
     idx, offsets = _random_bags(rng, int(np.prod(p)), n_ids)
-    fam = nat.kernel_family(shape, int(idx.shape[0]), int(offsets.shape[0] - 1), True) & ~nat.FAMILY_PREFIX_IN_CHAIN
+    fam = nat.kernel_family(shape, int(idx.shape[0]), int(offsets.shape[0] - 1), True) & ~nat.FAMILY_ROUTE_FLAGS
     # past the grouped crossover a 3-core table whose q shape is instantiated at a higher rank rides on the grouped kernels
     # through zero-padded cores (4,5,5 at 12 -> 16, 24 -> 32, (6, 7) -> 8); everything else runs the run-time-shape kernels
     padded = T == 3 and tuple(q) == (4, 5, 5) and max(r) <= 32 and idx.shape[0] >= 4096
@@ -814,7 +814,7 @@ def test_shapes_off_the_instantiated_list(nat, orc, p, q, r, n_ids):
     else:
         assert fam & ~nat.FAMILY_MERGED == nat.FAMILY_PER_BAG_RT, f"kernel family {fam}"
         assert bool(fam & nat.FAMILY_MERGED) == (T != 3)
-    assert nat.kernel_family(shape, int(idx.shape[0]), int(offsets.shape[0] - 1), False) & ~nat.FAMILY_PREFIX_IN_CHAIN in (
+    assert nat.kernel_family(shape, int(idx.shape[0]), int(offsets.shape[0] - 1), False) & ~nat.FAMILY_ROUTE_FLAGS in (
         nat.FAMILY_SCALAR, nat.FAMILY_GROUPED | nat.FAMILY_PADDED)   # (a row index, no offsets: no per-bag kernels)
     cores = [(rng.standard_normal((p[t], R[t] * q[t] * R[t + 1])) * 0.4).astype(np.float32) for t in range(T)]
     want = orc.tt_forward(idx, offsets, cores, p, q, R)
@@ -911,7 +911,7 @@ def test_call_past_2_24_rows_stays_on_the_grouped_path(nat, orc):
     R, D = [1] + r + [1], 128
     B = (1 << 24) + 4096
     shape = nat.make_shape(p, q, R)
-    assert nat.kernel_family(shape, B, B, True) == nat.FAMILY_GROUPED
+    assert nat.kernel_family(shape, B, B, True) & ~nat.FAMILY_ROUTE_FLAGS == nat.FAMILY_GROUPED
     assert nat.kernel_family(shape, B, B, False) != nat.FAMILY_GROUPED   # (no bag boundaries: no pieces)
     assert nat.plan_bytes(shape, B) == 0
     rng = np.random.default_rng(24)
@@ -971,7 +971,7 @@ def test_fused_backward_at_the_full_409600_ids_against_the_oracle(nat, orc):
     offsets = np.arange(n + 1, dtype=np.int64)
     d_out = ((rng.random((n, int(np.prod(q)))) - 0.5) * 0.1).astype(np.float32)
     shape = nat.make_shape(p, q, R)
-    assert nat.kernel_family(shape, n, n, True) == nat.FAMILY_GROUPED
+    assert nat.kernel_family(shape, n, n, True) & ~nat.FAMILY_ROUTE_FLAGS == nat.FAMILY_GROUPED
     want = [np.zeros_like(c, dtype=np.float64) for c in cores]
     for k in range(8):
         sl = slice(k * n // 8, (k + 1) * n // 8)
@@ -1002,7 +1002,7 @@ def test_ranks_off_the_list_ride_on_the_grouped_path(nat, orc, q, r, Rpad):
     rng = np.random.default_rng(sum(r) + Rpad)
     idx, offsets = _random_bags(rng, int(np.prod(p)), 30000)
     nnz, B = int(idx.shape[0]), int(offsets.shape[0] - 1)
-    fam = nat.kernel_family(shape, nnz, B, True) & ~nat.FAMILY_PREFIX_IN_CHAIN
+    fam = nat.kernel_family(shape, nnz, B, True) & ~nat.FAMILY_ROUTE_FLAGS
     want_fam = (nat.FAMILY_GROUPED_WIDE if Rpad >= 64 else nat.FAMILY_GROUPED) | nat.FAMILY_PADDED
     assert fam == want_fam, f"kernel family {fam}"
     assert nat.plan_bytes(shape, nnz) > 0
@@ -1034,9 +1034,10 @@ def test_ranks_off_the_list_ride_on_the_grouped_path(nat, orc, q, r, Rpad):
 @pytest.mark.parametrize("wide", [False, True])
 def test_an_expired_wait_gives_nan_and_an_error_never_plausible_numbers(nat, orc, wide):
     """ttemb_set_spin_limit(-1): every bounded wait of the grouping pass expires (the look-back of every range but the first;
-    on a fresh workspace the counter take-over too).  The forward must give NaN rows, a backward on that plan NaN gradients
-    (fused SGD: NaN weights), the next call TTEMB_E_HIP -- and the call after that, with the default limit, the oracle's
-    numbers again on the same workspace."""
+    on a fresh workspace the counter take-over too).  The forward must give NaN rows, a backward on that plan NaN gradients,
+    a FUSED backward must leave parameters and optimizer state untouched (the host hears of the fault: nothing is lost, the
+    step can be repeated) -- also on the routes that write gradients and step afterwards (ranks off the list) --, the next
+    call TTEMB_E_HIP -- and the call after that, with the default limit, the oracle's numbers again on the same workspace."""
     p, q = [125, 140, 140], ([5, 5, 4] if wide else [4, 5, 5])
     R = [1, 64, 64, 1] if wide else [1, 16, 16, 1]
     rng = np.random.default_rng(11)
@@ -1046,7 +1047,7 @@ def test_an_expired_wait_gives_nan_and_an_error_never_plausible_numbers(nat, orc
     offs = np.arange(n + 1, dtype=np.int64)
     shape = nat.make_shape(p, q, R)
     nat.set_path(nat.PATH_FAST3)
-    assert nat.kernel_family(shape, n, n) & ~nat.FAMILY_PREFIX_IN_CHAIN in (nat.FAMILY_GROUPED, nat.FAMILY_GROUPED_WIDE)
+    assert nat.kernel_family(shape, n, n) & ~nat.FAMILY_ROUTE_FLAGS in (nat.FAMILY_GROUPED, nat.FAMILY_GROUPED_WIDE)
     ws = nat.Workspace()
     c = [dev(x) for x in cores]
     idx, o = dev(ids), dev(offs)
@@ -1067,11 +1068,17 @@ def test_an_expired_wait_gives_nan_and_an_error_never_plausible_numbers(nat, orc
     torch.cuda.synchronize()
     for g in grads:
         assert bool(torch.isnan(g).all()), "gradients of a poisoned plan must be NaN"
-    # ... and NaN weights in the fused mode (on a copy)
+    word = nat.poison_word(ws)
+    assert int(word.item()) == 1, "the finalize kernel of a poisoned backward marks the workspace header"
+    # ... and in the fused modes NOTHING: parameters and the Adagrad state stay as they were (the pinned host word exists --
+    # ttemb_init ran with the first Workspace.get -- so the fault is loud without NaN weights, and the step can be repeated)
     c2 = [x.clone() for x in c]
     nat.backward_sgd(shape, c2, idx, None, n, None, n, d_out, 0.1, ws, plan=plan, offsets=o)
+    st2 = [torch.full_like(x, 0.25) for x in c]
+    nat.backward_adagrad(shape, c2, st2, idx, None, n, None, n, d_out, 0.1, 1e-8, ws, plan=plan, offsets=o)
     torch.cuda.synchronize()
-    assert all(bool(torch.isnan(x).all()) for x in c2)
+    assert all(torch.equal(x, y) for x, y in zip(c2, c)), "a fused step on a poisoned plan must not touch the parameters"
+    assert all(bool((x == 0.25).all()) for x in st2), "... nor the optimizer state"
     nat.status()   # the backwards walked no wait: nothing new
     # a backward that regroups under the limit reports again
     nat.backward_dense(shape, c, idx, None, n, None, n, d_out, grads, ws, offsets=o)
@@ -1080,6 +1087,19 @@ def test_an_expired_wait_gives_nan_and_an_error_never_plausible_numbers(nat, orc
     with pytest.raises(RuntimeError, match="gave up waiting"):
         nat.status()
     nat.status()   # consumed
+    if not wide:
+        # ranks off the list ride on padded cores: the grouped backward writes (NaN) gradients and a separate kernel steps --
+        # it reads the header's poison word and leaves the parameters alone as well
+        R12 = [1, 12, 12, 1]
+        shape12 = nat.make_shape(p, q, R12)
+        assert nat.kernel_family(shape12, n, n) & nat.FAMILY_PADDED
+        c12 = [dev(x) for x in seeded_cores(p, q, R12, 6, 0.3)]
+        keep = [x.clone() for x in c12]
+        nat.backward_sgd(shape12, c12, idx, None, n, None, n, d_out, 0.1, ws, offsets=o)
+        torch.cuda.synchronize()
+        assert all(torch.equal(x, y) for x, y in zip(c12, keep)), "padded route: the step after a poisoned backward must be skipped"
+        with pytest.raises(RuntimeError, match="gave up waiting"):
+            nat.status()
     # default limit, same workspace and plan buffer: the oracle's rows and gradients
     nat.set_spin_limit(0)
     nat.forward(shape, c, idx, None, o, n, None, n, out, ws, plan=plan)
@@ -1091,6 +1111,11 @@ def test_an_expired_wait_gives_nan_and_an_error_never_plausible_numbers(nat, orc
     tol = 2e-4 if wide else 1e-4   # (split-bf16 GEMMs of the wide chain: fp32-grade, see test_wide_rank_gemms_keep_fp32_accuracy)
     assert_grads_close([g.cpu().numpy() for g in grads], want_g, rel=tol)
     nat.status()
+    assert int(nat.poison_word(ws).item()) == 0, "a healthy backward clears the header's poison word"
+    if not wide:   # ... and the padded route steps again
+        nat.backward_sgd(shape12, c12, idx, None, n, None, n, d_out, 0.1, ws, offsets=o)
+        torch.cuda.synchronize()
+        assert not any(torch.equal(x, y) for x, y in zip(c12, keep)) and all(bool(torch.isfinite(x).all()) for x in c12)
     # A stale fault word must never meet a later call that carries the same call number: call numbers live in the workspace
     # header and two zero-filled workspaces count alike.  Call no. 1 of workspace A faults into the plan buffer; call no. 1 of
     # workspace B builds a sound plan in the SAME buffer -- the place step clears the other call's word.
@@ -1115,7 +1140,7 @@ def test_an_expired_wait_gives_nan_and_an_error_never_plausible_numbers(nat, orc
 # frontiers with few ids per group: the forward forms the prefix products inside its chain kernel
 # ---------------------------------------------------------------------------------------
 @pytest.mark.parametrize("q,r", [([8, 4, 4], [32, 32]), ([4, 4, 8], [16, 16]), ([4, 5, 5], [16, 16]), ([5, 5, 4], [16, 16]),
-                                 ([4, 5, 5], [8, 8]), ([4, 4, 8], [8, 8]), ([5, 4, 5], [16, 16]), ([4, 5, 5], [32, 32])])
+                                 ([4, 5, 5], [8, 8]), ([4, 4, 8], [8, 8]), ([5, 4, 5], [16, 16]), ([8, 4, 4], [16, 16])])
 @pytest.mark.parametrize("p0", [40, 41])
 def test_forward_with_the_prefix_products_formed_in_the_chain_kernel(nat, orc, q, r, p0):
     """~3 ids per (i0, i1) group: ttemb_forward takes fast3_forward_pfuse_kernel (asked from the library).  Batches of 16 / q0
@@ -1130,7 +1155,7 @@ def test_forward_with_the_prefix_products_formed_in_the_chain_kernel(nat, orc, q
     idx, offsets = _random_bags(rng, int(np.prod(p)), 6000)
     nnz, B = int(idx.shape[0]), int(offsets.shape[0] - 1)
     nat.set_path(nat.PATH_FAST3)
-    assert nat.kernel_family(shape, nnz, B, True) == nat.FAMILY_GROUPED | nat.FAMILY_PREFIX_IN_CHAIN
+    assert nat.kernel_family(shape, nnz, B, True) & ~nat.FAMILY_GROUP_PRODUCTS_IN_CHAIN == nat.FAMILY_GROUPED | nat.FAMILY_PREFIX_IN_CHAIN
     cores = [(rng.standard_normal((p[t], R[t] * q[t] * R[t + 1])) * 0.4).astype(np.float32) for t in range(3)]
     want = orc.tt_forward(idx, offsets, cores, p, q, R)
     c = [dev(x) for x in cores]
@@ -1158,3 +1183,62 @@ def test_forward_with_the_prefix_products_formed_in_the_chain_kernel(nat, orc, q
     torch.cuda.synchronize()
     for got, w0, g in zip(c2, cores, want_g):
         np.testing.assert_allclose(got.cpu().numpy(), w0 - lr * g, rtol=0, atol=1e-5 + 1e-4 * float(np.abs(lr * g).max()))
+
+
+# ---------------------------------------------------------------------------------------
+# frontiers with few ids per group: the backward forms the per-group products (dG0 parts, dG1) inside its chunk kernel
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("q,r,p2", [([8, 4, 4], [32, 32], 30), ([4, 4, 8], [32, 32], 30), ([4, 5, 5], [32, 32], 35), ([5, 5, 4], [32, 32], 30),
+                                   ([4, 4, 8], [16, 16], 600), ([4, 5, 5], [16, 16], 700), ([5, 5, 4], [16, 16], 700),
+                                   ([8, 4, 4], [16, 16], 700), ([5, 4, 5], [16, 16], 700), ([4, 4, 8], [8, 8], 900)])
+@pytest.mark.parametrize("p0", [40, 41])
+def test_backward_with_the_group_products_formed_in_the_chunk_kernel(nat, orc, q, r, p2, p0):
+    """~3 ids per (i0, i1) group on shapes whose dG2 reduction is not fused into the chunk kernel (rank 32; p2 past the
+    register slab): ttemb_backward_* takes fast3_bwd_chunk_kernel<..., GF> -- asked from the library -- which multiplies a
+    batch of 16 / q0 groups' dP with G1[i1]^T and G0^T while dP is in registers (no dP table, no epilogue launch).  Batches of
+    2 / 3 (idle tile row) / 4 groups, a p0 the batch size does not divide (a short batch at the end of every i1), the narrow
+    last row tile of q0 q1 = 20, groups that span several chunks (a hot group of 50 ids, another of 17), duplicate ids,
+    ragged bags with empty ones.  Dense gradients, then the fused SGD step, on the forward's plan and on a plan the backward
+    builds itself, against the oracle; Adagrad once."""
+    p = [p0, 50, p2]
+    R = [1] + r + [1]
+    shape = nat.make_shape(p, q, R)
+    rng = np.random.default_rng(p0 + sum(q) + sum(r) + p2)
+    idx, offsets = _random_bags(rng, int(np.prod(p)), 6000)
+    # two hot groups: 50 ids of group (i0 = 3, i1 = 7) -- four chunks --, 17 of the LAST group of an i1 (i0 = p0 - 1: the short batch)
+    hot = lambda i0, i1, k: (i0 * p[1] + i1) * p[2] + rng.integers(0, p[2], size=k)
+    idx[100:150] = hot(3, 7, 50)
+    idx[300:317] = hot(p0 - 1, 11, 17)
+    nnz, B = int(idx.shape[0]), int(offsets.shape[0] - 1)
+    nat.set_path(nat.PATH_FAST3)
+    fam = nat.kernel_family(shape, nnz, B, True)
+    assert fam & nat.FAMILY_GROUP_PRODUCTS_IN_CHAIN and fam & 7 == nat.FAMILY_GROUPED, f"kernel family {fam}"
+    cores = [(rng.standard_normal((p[t], R[t] * q[t] * R[t + 1])) * 0.4).astype(np.float32) for t in range(3)]
+    c = [dev(x) for x in cores]
+    t_idx, t_offs = dev(idx, torch.int64), dev(offsets, torch.int64)
+    ws = nat.Workspace()
+    plan = nat.new_plan(shape, nnz, t_idx.device)
+    D = int(np.prod(q))
+    out = torch.empty((B, D), device="cuda")
+    nat.forward(shape, c, t_idx, None, t_offs, nnz, None, B, out, ws, plan)
+    d_out = ((rng.random((B, D)) - 0.5) * 0.2).astype(np.float32)
+    want_g = orc.tt_dense_backward(idx, offsets, d_out, cores, p, q, R)
+    for use_plan in (plan, None):
+        grads = [torch.full_like(x, float("nan")) for x in c]
+        nat.backward_dense(shape, c, t_idx, None, nnz, None, B, dev(d_out), grads, ws, use_plan, t_offs)
+        torch.cuda.synchronize()
+        assert_grads_close([g.cpu().numpy() for g in grads], want_g)
+    lr = 0.05
+    c2 = [x.clone() for x in c]
+    nat.backward_sgd(shape, c2, t_idx, None, nnz, None, B, dev(d_out), lr, ws, plan, t_offs)
+    torch.cuda.synchronize()
+    for got, w0, g in zip(c2, cores, want_g):
+        np.testing.assert_allclose(got.cpu().numpy(), w0 - lr * g, rtol=0, atol=1e-5 + 1e-4 * float(np.abs(lr * g).max()))
+    c3, st3 = [x.clone() for x in c], [torch.zeros_like(x) for x in c]
+    nat.backward_adagrad(shape, c3, st3, t_idx, None, nnz, None, B, dev(d_out), lr, 1e-6, ws, plan, t_offs)
+    torch.cuda.synchronize()
+    for got, st, w0, g in zip(c3, st3, cores, want_g):
+        np.testing.assert_allclose(st.cpu().numpy(), g * g, rtol=2e-4, atol=1e-6 * float((g * g).max()) + 1e-12)
+        ref = w0 - lr * g / (np.sqrt(g * g) + 1e-6)
+        big = np.abs(g) > 1e-3 * float(np.abs(g).max())   # (where g ~ 0 the step is lr * g / (|g| + eps): any rounding of g flips it)
+        np.testing.assert_allclose(got.cpu().numpy()[big], ref[big], rtol=0, atol=2e-3 * lr)
