@@ -167,7 +167,10 @@ def papers_roofline_leg(nat, n_ids=819200, iters=20):
         nat.backward_sgd(shape, cores, idx, None, n_ids, None, n_ids, d_out, 1e-12, ws, plan, offs)
         if it >= 3:
             for k, slot in (("group", 3), ("fwd", 0), ("bwd", 1), ("chunk", 2), ("epi", 8), ("fin", 9)):
-                t[k].append(nat.profile_read(slot))
+                try:
+                    t[k].append(nat.profile_read(slot))
+                except RuntimeError:   # no epilogue launch: the chunk kernel formed the group products itself (GROUP_PRODUCTS_IN_CHAIN)
+                    t[k].append(0.0)
     nat.profile_enable(False)
     torch.cuda.synchronize()
     m = {k: float(np.median(v)) for k, v in t.items()}   # ms
@@ -176,7 +179,9 @@ def papers_roofline_leg(nat, n_ids=819200, iters=20):
     executed_f = groups * f0 + n_ids * f1                 # P once per group
     executed_b = groups * 2 * f0 + n_ids * 2 * f1         # dG0 / dG1 products per group, dP / E per id (P is the forward's)
     tfl = lambda fl, ms: fl / (ms * 1e-3) / 1e12
-    r = {"bound": "mfma", "workload": "papers100M r32 (p = 500,560,400 q = 8,4,4), %d unique uniform ids on one GPU, fwd + fused-SGD bwd at the C ABI" % n_ids,
+    fam = nat.kernel_family(shape, n_ids, n_ids)
+    r = {"bound": "mfma", "kernel_family": int(fam), "group_products_in_chunk_kernel": bool(fam & nat.FAMILY_GROUP_PRODUCTS_IN_CHAIN),
+         "workload": "papers100M r32 (p = 500,560,400 q = 8,4,4), %d unique uniform ids on one GPU, fwd + fused-SGD bwd at the C ABI" % n_ids,
          "groups_touched": groups, "ids_per_group": round(n_ids / groups, 2),
          "kernel_ms": {k: round(v, 4) for k, v in m.items()},
          "fwd_ms_incl_grouping": round(fwd_ms, 4), "bwd_ms": round(bwd_ms, 4),
@@ -187,7 +192,7 @@ def papers_roofline_leg(nat, n_ids=819200, iters=20):
          "frac": round(tfl(executed_f + executed_b, fwd_ms + bwd_ms) / PEAK_F32_MFMA_TFLOPS, 4),
          "frac_nominal": round(tfl(nominal_f + nominal_b, fwd_ms + bwd_ms) / PEAK_F32_MFMA_TFLOPS, 4),
          "algorithmic_hbm_bytes": n_ids * 2 * (8 + 4 * Dp)}
-    for key, src in (("traffic", "profiles/r04_papers_traffic.json"), ("mfma_busy", "profiles/r04_papers_mfma_util.json")):
+    for key, src in (("traffic", "profiles/r05_papers_traffic.json"), ("mfma_busy", "profiles/r05_papers_mfma_util.json")):
         try:
             with open(os.path.join(ROOT, src)) as fh:
                 kern = json.load(fh)["kernels"]
@@ -404,7 +409,7 @@ def main():
         achieved = N * row_bytes / (dom_ms * 1e-3) / 1e9
         # HBM bytes per launch of that kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read from
         # inside the process): NOT measured by this run -- the files are named in the line -- valid for the default workload
-        traffic_src, busy_src = "profiles/r04_traffic.json", "profiles/r04_mfma_util.json"
+        traffic_src, busy_src = "profiles/r05_traffic.json", "profiles/r05_mfma_util.json"
         traffic = None
         try:
             if N == 409600 and args.path == "auto":

@@ -512,26 +512,27 @@ __device__ __forceinline__ void place_range(const uint32_t ranges, uint32_t G, u
                                             uint32_t nnz, uint32_t max_chunks, const GroupPlan& plan, uint32_t* lds_s,
                                             uint64_t* red) {
   // lds_s: [span] cursor | [span] first position | [span] count | [span] first chunk (inside the range)
-#ifdef TTEMB_PLACE_BY_BLOCK   // (A/B: the range is the workgroup's index, as until round 4)
-  const uint32_t range = blockIdx.x;
-#else
-  if (threadIdx.x == 0) reinterpret_cast<uint32_t*>(red)[0] = atomicAdd(plan.ticket, 1u);
-  __syncthreads();
-  const uint32_t range = reinterpret_cast<uint32_t*>(red)[0];
-  __syncthreads();   // (red is the scan's scratch next)
-  if (range >= ranges) return;   // (cannot happen: `ranges` workgroups draw from a counter that started at 0)
-#endif
   const uint32_t span = 1u << shift;
-  const uint32_t g0 = range << shift;
   uint32_t* cursor = lds_s;
   uint32_t* gfirst = cursor + span;
   uint32_t* gcount = gfirst + span;
   uint32_t* gchunk = gcount + span;
   constexpr int NWV = kRangeThreads / kWave;
+  // (the ticket's round trip runs next to the epoch load and the clearing of the counters: neither needs the range)
   const uint64_t epoch = (plan.epochs[1] & (kEpochMask >> 1)) | (1ull << 39);   // (top bit set: zeros / all-ones never match)
-  const uint32_t n0 = plan.rstart[range], n1 = plan.rstart[range + 1];
+#ifdef TTEMB_PLACE_BY_BLOCK   // (A/B: the range is the workgroup's index, as until round 4)
+  const uint32_t range = blockIdx.x;
   for (uint32_t i = threadIdx.x; i < span; i += kRangeThreads) gcount[i] = 0u;
   __syncthreads();
+#else
+  if (threadIdx.x == 0) reinterpret_cast<uint32_t*>(red)[0] = atomicAdd(plan.ticket, 1u);
+  for (uint32_t i = threadIdx.x; i < span; i += kRangeThreads) gcount[i] = 0u;
+  __syncthreads();
+  const uint32_t range = reinterpret_cast<uint32_t*>(red)[0];   // (red is the scan's scratch next: two barriers further down)
+  if (range >= ranges) return;   // (cannot happen: `ranges` workgroups draw from a counter that started at 0)
+#endif
+  const uint32_t g0 = range << shift;
+  const uint32_t n0 = plan.rstart[range], n1 = plan.rstart[range + 1];
   // ---- 1. histogram, scan, publication ----
   for (uint32_t b0 = n0 + threadIdx.x; b0 < n1; b0 += kRangeThreads * kSortBatch) {
     uint32_t g[kSortBatch];
@@ -1971,53 +1972,13 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
     TTEMB_PRIO(2);
     TTEMB_STAMP(2);
 
-    // ---- rows of the next chunk: registers -> LDS; then the offsets of the chunk after (consumes its pairs) ----
-    Offs o_nn;
-    if constexpr (!FUSE) {
-      stage((d_nxt.z & kFirstBit) != 0u);
-      o_nn = offsets(d_nn, i2_nn, val_nn);
-      // the offsets are needed only after the stores; computed there, their wait for the (i2, row) pairs would become a
-      // wait for every store in front of it as well (vmcnt counts in order): ~3 000 cycles per chunk.  Pin them here.
-      asm volatile("" ::"v"(o_nn.row), "v"(o_nn.grow));
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    TTEMB_STAMP(3);
-
-    // ---- this chunk's results leave now: no load is waited for behind these stores ----
-    // Lane (hi, lo) holds E[c2 = 16 t + 4 hi + r][col = 16 nt + lo] with col = id * q2 + kk, and the E table keeps
-    // an id's row as [kk][c2] (the reduce kernel sums rows element by element, the finalize kernel puts dG2 back
-    // into [c2][kk]): the chunk's rows are one contiguous block indexed col * r2 + c2, written in 16-byte pieces
-    // through a descriptor that covers exactly this chunk's rows.
-    if constexpr (FUSE) {
-      // (the wave barrier above: every staged-G2 read of this chunk is done; the second chunk's E rows take that region)
-      float* const eb = sub == 0 ? ebuf : bbuf;
-#pragma unroll
-      for (int nt = 0; nt < C::NT2; ++nt) {
-        if ((uint32_t)(16 * nt) < len * Q2) {
-#pragma unroll
-          for (int t = 0; t < C::RT2; ++t)
-            if (ewr[nt][t] >= 0) *reinterpret_cast<f32x4*>(eb + ewr[nt][t]) = e[t][nt];
-        }
-      }
-      if (j_l == 0 && (uint32_t)b_l < len)   // the row joins the list of its i2
-        f_tab[(wave * kFuseSub + sub) * 16 + b_l] =
-            make_uint2(sub == 0 ? my_row0 : my_row1, atomicExch(&f_head[i2_cur], sub == 0 ? my_entry0 : my_entry1));
-      if (lane == 0) f_more[wave] = more1 ? 1u : 0u;
-    }
-#if !(defined(TTEMB_ABL) && (TTEMB_ABL & 1))
-    if constexpr (!FUSE) {
-      const rsrc_t r_e = make_rsrc(plan.etab + (size_t)uniform(d_cur.x) * C::ROW2, uniform(len) * (uint32_t)(C::ROW2 * 4));
-#pragma unroll
-      for (int nt = 0; nt < C::NT2; ++nt) {
-        if ((uint32_t)(16 * nt) < len * Q2) {
-#pragma unroll
-          for (int t = 0; t < C::RT2; ++t)
-            buf_store4(r_e, eoff[t] + (uint32_t)(16 * nt * R2 * 4), make_float4(e[t][nt][0], e[t][nt][1], e[t][nt][2], e[t][nt][3]));
-        }
-      }
-    }
-#endif
+    // ---- GF: a finished group's dP joins its batch; a finished batch is multiplied HERE, in front of the wait for the next
+    //      chunk's rows (requested an iteration ago: they arrive under these MFMAs) ----
+    f32x4 gf_out[GF ? C::RT1 : 1];
+    bool gf_store = false;
+    uint32_t gf_store_mask = 0u, gf_store_group = 0u;
     if constexpr (GF) {
+      gf_store = false;
       if (d_cur.z & kLastBit) {   // a group is complete: its dP joins the batch's slot; a complete batch is multiplied
         asm volatile("; a group ends" ::: "memory");
         if (b_cur.first_group != gf_batch) {   // the batch's first group (of this wavefront): the rows of the others read zero
@@ -2103,20 +2064,91 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
               g0p[s3 & 3][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[s3], gf_g1[s3][t], g0p[s3 & 3][t], 0, 0, 0);
           TTEMB_PRIO(2);
           // accumulator row 4 hi + r = rho = (group rho / q0 of the batch, core row rho % q0), column c1 = 16 t + lo: the part of
-          // every group this wavefront staged (the finalize kernel sums the parts of the non-empty groups over i1)
+          // every group this wavefront staged (the finalize kernel sums the parts of the non-empty groups over i1).  Stored
+          // further down, behind this chunk's E rows: no wait of the pipeline sits behind a store
 #pragma unroll
-          for (int t = 0; t < C::RT1; ++t) {
-            const f32x4 sum = (g0p[0][t] + g0p[1][t]) + (g0p[2][t] + g0p[3][t]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int rho = 4 * hi + r;
-              const bool on = rho / Q0 < GM && ((gf_mask >> (rho / Q0)) & 1u) != 0u && 16 * t + lo < R1;
-              buf_store1(r_part, on ? (b_cur.first_group + (uint32_t)(rho / Q0)) * (uint32_t)(C::ROW0 * 4) + 4u * ((rho % Q0) * R1 + 16 * t + lo) : kOob, sum[r]);
-            }
-          }
+          for (int t = 0; t < C::RT1; ++t) gf_out[t] = (g0p[0][t] + g0p[1][t]) + (g0p[2][t] + g0p[3][t]);
+          gf_store = true;
+          gf_store_mask = gf_mask;
+          gf_store_group = b_cur.first_group;
           gf_batch = 0xffffffffu;
           gf_mask = 0u;
         }
+      }
+    }
+#ifdef TTEMB_STAMPS
+    if constexpr (GF) {   // (the group products' share of the "stage" interval, and how many iterations multiplied a batch)
+      __builtin_amdgcn_sched_barrier(0);
+      const long long now = clock64();
+      st_acc[9] += now - st_t[2];
+      st_acc[8] += gf_store ? 1 : 0;
+      st_t[2] = now;
+    }
+#endif
+    // ---- rows of the next chunk: registers -> LDS; then the offsets of the chunk after (consumes its pairs) ----
+    Offs o_nn;
+    uint4 d_n3x = none;
+    if constexpr (!FUSE) {
+      stage((d_nxt.z & kFirstBit) != 0u);
+#ifndef TTEMB_DESC_LATE
+      // the descriptor of chunk c + 3 is requested HERE and used at the end of the iteration (loaded there, its scalar round
+      // trip -- a wait of its own, ~600 cycles -- closed every iteration).  From here to the end of the iteration no LDS
+      // operation is waited for, so the outstanding scalar load turns no partial LDS wait into a full one.
+      d_n3x = load_desc(ctab, c + 3, nchunks);
+#endif
+      o_nn = offsets(d_nn, i2_nn, val_nn);
+      // the offsets are needed only after the stores; computed there, their wait for the (i2, row) pairs would become a
+      // wait for every store in front of it as well (vmcnt counts in order): ~3 000 cycles per chunk.  Pin them here.
+      asm volatile("" ::"v"(o_nn.row), "v"(o_nn.grow));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    TTEMB_STAMP(3);
+
+    // ---- this chunk's results leave now: no load is waited for behind these stores ----
+    // Lane (hi, lo) holds E[c2 = 16 t + 4 hi + r][col = 16 nt + lo] with col = id * q2 + kk, and the E table keeps
+    // an id's row as [kk][c2] (the reduce kernel sums rows element by element, the finalize kernel puts dG2 back
+    // into [c2][kk]): the chunk's rows are one contiguous block indexed col * r2 + c2, written in 16-byte pieces
+    // through a descriptor that covers exactly this chunk's rows.
+    if constexpr (FUSE) {
+      // (the wave barrier above: every staged-G2 read of this chunk is done; the second chunk's E rows take that region)
+      float* const eb = sub == 0 ? ebuf : bbuf;
+#pragma unroll
+      for (int nt = 0; nt < C::NT2; ++nt) {
+        if ((uint32_t)(16 * nt) < len * Q2) {
+#pragma unroll
+          for (int t = 0; t < C::RT2; ++t)
+            if (ewr[nt][t] >= 0) *reinterpret_cast<f32x4*>(eb + ewr[nt][t]) = e[t][nt];
+        }
+      }
+      if (j_l == 0 && (uint32_t)b_l < len)   // the row joins the list of its i2
+        f_tab[(wave * kFuseSub + sub) * 16 + b_l] =
+            make_uint2(sub == 0 ? my_row0 : my_row1, atomicExch(&f_head[i2_cur], sub == 0 ? my_entry0 : my_entry1));
+      if (lane == 0) f_more[wave] = more1 ? 1u : 0u;
+    }
+#if !(defined(TTEMB_ABL) && (TTEMB_ABL & 1))
+    if constexpr (!FUSE) {
+      const rsrc_t r_e = make_rsrc(plan.etab + (size_t)uniform(d_cur.x) * C::ROW2, uniform(len) * (uint32_t)(C::ROW2 * 4));
+#pragma unroll
+      for (int nt = 0; nt < C::NT2; ++nt) {
+        if ((uint32_t)(16 * nt) < len * Q2) {
+#pragma unroll
+          for (int t = 0; t < C::RT2; ++t)
+            buf_store4(r_e, eoff[t] + (uint32_t)(16 * nt * R2 * 4), make_float4(e[t][nt][0], e[t][nt][1], e[t][nt][2], e[t][nt][3]));
+        }
+      }
+    }
+#endif
+    if constexpr (GF) {
+      // (the group products ran before the next chunk's rows were staged; their dG0 parts leave now, behind the E rows)
+      if (gf_store) {
+#pragma unroll
+        for (int t = 0; t < C::RT1; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int rho = 4 * hi + r;
+            const bool on = rho / Q0 < GM && ((gf_store_mask >> (rho / Q0)) & 1u) != 0u && 16 * t + lo < R1;
+            buf_store1(r_part, on ? (gf_store_group + (uint32_t)(rho / Q0)) * (uint32_t)(C::ROW0 * 4) + 4u * ((rho % Q0) * R1 + 16 * t + lo) : kOob, gf_out[t][r]);
+          }
       }
     } else
 #if defined(TTEMB_ABL) && (TTEMB_ABL & 512)   // (ablation 512: the dP table is not written -- with the epilogue launch skipped: what folding the epilogue into this kernel can save at most; timing only)
@@ -2232,7 +2264,11 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
       i2_nn = i2_n3;
       val_nn = val_n3;
     } else {
+#ifndef TTEMB_DESC_LATE
+      d_nn = d_n3x;   // (c has advanced: this is chunk c + 2)
+#else
       d_nn = load_desc(ctab, c + 2, nchunks);
+#endif
       if (!more2) d_nn = none;
       fetch_meta(d_nn, i2_nn, val_nn);
     }
@@ -2261,9 +2297,9 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
   }
 #ifdef TTEMB_STAMPS
   if (lane == 0 && wave == 0 && (blockIdx.x % 97) == 0 && st_n > 0)
-    printf("chunk kernel wg %u: %lld iterations, total %lld cycles; per iteration: dP %lld | E %lld | stage(+wait) %lld | stores %lld | request/B1 %lld | reduce %lld | B2 %lld | stage %lld | request %lld\n",
+    printf("chunk kernel wg %u: %lld iterations, total %lld cycles; per iteration: dP %lld | E %lld | stage(+wait) %lld | stores %lld | request/B1 %lld | reduce %lld | B2 %lld | stage %lld | request %lld%s | GF: group products %lld per iteration, %lld batches\n",
            blockIdx.x, st_n, (long long)(clock64() - st_begin), st_acc[0] / st_n, st_acc[1] / st_n, st_acc[2] / st_n, st_acc[3] / st_n,
-           st_acc[4] / st_n, st_acc[5] / st_n, st_acc[6] / st_n, st_acc[7] / st_n, st_acc[8] / st_n);
+           st_acc[4] / st_n, st_acc[5] / st_n, st_acc[6] / st_n, st_acc[7] / st_n, GF ? 0ll : st_acc[8] / st_n, "", GF ? st_acc[9] / st_n : 0ll, GF ? st_acc[8] : 0ll);
 #endif
 }
 

@@ -596,15 +596,15 @@ def _dp_gpu_worker(rank, world, port, out_dir, overlap=False, poison_rank=-1):
         import ttemb_native as nat
         nat.set_spin_limit(-1)
     out = emb(ids.cuda(), torch.arange(60001).cuda())
-    out.backward(d_out.cuda())
     if poison_rank >= 0:
         import ttemb_native as nat
         torch.cuda.synchronize()
         nat.set_spin_limit(0)
         if rank == poison_rank:
             assert bool(torch.isnan(out).all())
-            with pytest.raises(RuntimeError, match="gave up waiting"):   # consumed here, so that step() below reaches the collective
+            with pytest.raises(RuntimeError, match="gave up waiting"):   # consumed here: the backward and step() below must reach the collective
                 nat.status()
+        out.backward(d_out.cuda())   # on the forward's (poisoned) plan: NaN gradients, the header's poison word set
         dp.step(overlap=overlap)
         dp.flush()
         torch.cuda.synchronize()
@@ -614,6 +614,7 @@ def _dp_gpu_worker(rank, world, port, out_dir, overlap=False, poison_rank=-1):
         dist.barrier()
         dist.destroy_process_group()
         return
+    out.backward(d_out.cuda())
     dp.step(overlap=overlap)
     if overlap:  # the update is still pending; the next forward groups its ids, finishes the update, then looks up
         assert emb._before_weights is not None

@@ -7,14 +7,14 @@ tag=${1:-evidence}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$tag
 mkdir -p $O
-bash $R/tools/traffic.sh profiles/r04_traffic.json > $O/traffic.log 2>&1 || exit 1
-cp $R/profiles/r04_traffic.json $O/
-bash $R/tools/mfma_util.sh profiles/r04_mfma_util.json > $O/mfma.log 2>&1 || exit 1
-cp $R/profiles/r04_mfma_util.json $O/
+bash $R/tools/traffic.sh profiles/r05_traffic.json > $O/traffic.log 2>&1 || exit 1
+cp $R/profiles/r05_traffic.json $O/
+bash $R/tools/mfma_util.sh profiles/r05_mfma_util.json > $O/mfma.log 2>&1 || exit 1
+cp $R/profiles/r05_mfma_util.json $O/
 # the papers100M shape on one GPU (BASELINE configs[4]'s table): the same two counter passes + a kernel-stats pass
-TRAFFIC_KBENCH_ARGS="--cfg papers --n 819200 --no-rowidx" bash $R/tools/traffic.sh profiles/r04_papers_traffic.json > $O/papers_traffic.log 2>&1 || exit 1
-TRAFFIC_KBENCH_ARGS="--cfg papers --n 819200 --no-rowidx" bash $R/tools/mfma_util.sh profiles/r04_papers_mfma_util.json > $O/papers_mfma.log 2>&1 || exit 1
-cp $R/profiles/r04_papers_traffic.json $R/profiles/r04_papers_mfma_util.json $O/
+TRAFFIC_KBENCH_ARGS="--cfg papers --n 819200 --no-rowidx" bash $R/tools/traffic.sh profiles/r05_papers_traffic.json > $O/papers_traffic.log 2>&1 || exit 1
+TRAFFIC_KBENCH_ARGS="--cfg papers --n 819200 --no-rowidx" bash $R/tools/mfma_util.sh profiles/r05_papers_mfma_util.json > $O/papers_mfma.log 2>&1 || exit 1
+cp $R/profiles/r05_papers_traffic.json $R/profiles/r05_papers_mfma_util.json $O/
 cp $(find $R/gpurun_out/pmc_mfma_t -name "*kernel_stats.csv" | head -1) $O/papers_kernel_stats.csv
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $O/bench_profiled.json 2> $O/bench_profiled.err || exit 1
