@@ -2708,7 +2708,58 @@ __global__ __launch_bounds__(256) void fast3_finalize_kernel(GroupPlan plan, int
   // dG1 has few terms per output (one per slice): one thread per FOUR consecutive outputs (16-byte loads; a row of G1 is a
   // whole number of them), 1024 outputs per workgroup, the workgroups after those of dG2 / dG0.  (One output per thread
   // was 180 000 tiny workgroups for the 183 MB of dG1 at rank 256: the kernel was bound by their launch rate.)
-  const int wg_a = (g2_floats + n0 + 31) / 32;
+  const int wg_g2 = (g2_floats + 31) / 32, wg_g0 = (n0 + 31) / 32;
+  const int wg_a = wg_g2 + wg_g0;
+#ifndef TTEMB_FINALIZE_SCALAR
+  if (p1 >= 256 && (int)blockIdx.x >= wg_g2 && (int)blockIdx.x < wg_a) {
+    // dG0[i0] = sum over i1 of the parts of the groups (i1, i0), tables with many i1 (papers100M: 560): 32 consecutive outputs
+    // per workgroup as 8 threads x 16 bytes, 32 lane rows split the p1 terms -- a thread has p1 / 32 loads, six in flight.
+    // (One output per thread and 8 lane rows -- the form below -- is p1 / 8 loads in rounds of eight: this kernel is a chain of
+    // memory round trips.  papers100M r32, 819 200 ids: backward 1 063 -> 1 028 us; the products table, p1 = 140, has two
+    // rounds either way and keeps the scalar form: 11.2 against 11.5 us.)
+    __shared__ float4 part4[4][8];
+    const int xb = threadIdx.x & 7, yr = threadIdx.x >> 3;
+    const int o = ((int)blockIdx.x - wg_g2) * 32 + 4 * xb;
+    float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (o < n0) {
+      const int i0 = o / row0, c = o - i0 * row0;   // (row0 is a multiple of 4: the four outputs share their i0)
+      constexpr int U6 = 6;
+      for (int i1 = yr; i1 < p1; i1 += 32 * U6) {
+        bool on[U6];
+        float4 v[U6];
+#pragma unroll
+        for (int u = 0; u < U6; ++u) {   // dense form: every group has a part (zeros for an empty one); sparse: empty groups have none
+          const int g = (i1 + 32 * u) * p0 + i0;
+          on[u] = i1 + 32 * u < p1 && (!sparse || plan.counts[g] != 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < U6; ++u) {
+          const int g = (i1 + 32 * u) * p0 + i0;
+          v[u] = on[u] ? *reinterpret_cast<const float4*>(plan.g0part + (size_t)g * row0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < U6; ++u) {
+          s4.x += v[u].x; s4.y += v[u].y; s4.z += v[u].z; s4.w += v[u].w;
+        }
+      }
+    }
+#pragma unroll
+    for (int d = 8; d < kWave; d <<= 1) {   // the eight lane rows of a wavefront
+      s4.x += __shfl_xor(s4.x, d, kWave); s4.y += __shfl_xor(s4.y, d, kWave);
+      s4.z += __shfl_xor(s4.z, d, kWave); s4.w += __shfl_xor(s4.w, d, kWave);
+    }
+    if ((threadIdx.x & 63) < 8) part4[threadIdx.x >> 6][xb] = s4;
+    __syncthreads();
+    if (threadIdx.x < 8 && o < n0) {
+      const float4 a = part4[0][xb], b = part4[1][xb], c4 = part4[2][xb], d4 = part4[3][xb];
+      finalize_emit(upd, 0, dG0, o + 0, (a.x + b.x) + (c4.x + d4.x) + poison);
+      finalize_emit(upd, 0, dG0, o + 1, (a.y + b.y) + (c4.y + d4.y) + poison);
+      finalize_emit(upd, 0, dG0, o + 2, (a.z + b.z) + (c4.z + d4.z) + poison);
+      finalize_emit(upd, 0, dG0, o + 3, (a.w + b.w) + (c4.w + d4.w) + poison);
+    }
+    return;
+  }
+#endif
   if ((int)blockIdx.x >= wg_a) {
     const int o = (((int)blockIdx.x - wg_a) * 256 + (int)threadIdx.x) * 4;
     if (o >= g1_floats) return;
@@ -2735,7 +2786,9 @@ __global__ __launch_bounds__(256) void fast3_finalize_kernel(GroupPlan plan, int
     finalize_emit(upd, 1, dG1, o + 3, tot.w + poison);
     return;
   }
-  const int e = blockIdx.x * 32 + x;
+  // (dG2 outputs come first, 32 per workgroup; dG0's workgroups start at a 32-aligned output of their own)
+  const int e = (int)blockIdx.x < wg_g2 ? (blockIdx.x * 32 + x < g2_floats ? (int)(blockIdx.x * 32 + x) : g2_floats + n0)
+                                        : g2_floats + ((int)blockIdx.x - wg_g2) * 32 + x;
   float s = 0.f;
   // U independent partial sums per thread keep that many loads in flight (a single running sum issues them one by one)
   constexpr int U = 8;
@@ -3458,7 +3511,7 @@ static int run_backward_wide(const DevShape& s, const CorePtrs& cores, const Gro
   }
   {
     const int g2_floats = s.p[2] * C::ROW2, g1_floats = s.p[1] * C::ROW1;
-    const int wgs = (g2_floats + s.p[0] * C::ROW0 + 31) / 32 + (g1_floats + 1023) / 1024;
+    const int wgs = (g2_floats + 31) / 32 + (s.p[0] * C::ROW0 + 31) / 32 + (g1_floats + 1023) / 1024;
     hipLaunchKernelGGL(fast3_finalize_kernel, dim3((unsigned)wgs), dim3(256), 0, st, plan, (int)slab_count(s, nnz), epi_slices(s), s.p[0], s.p[1],
                        g2_floats, (int)C::ROW0, g1_floats, Q2, R2, d_cores.c[0], d_cores.c[1], d_cores.c[2], upd, 1);
   }
@@ -3648,7 +3701,7 @@ static int run_backward(const DevShape& s, const CorePtrs& cores, const GroupPla
   {
     // (group products fused: ONE dG1 slab, whole; dG0 parts of the non-empty groups only -- the form the wide chain leaves)
     const int g2_floats = s.p[2] * C::ROW2, g1_floats = s.p[1] * C::ROW1;
-    const int wgs = (g2_floats + s.p[0] * C::ROW0 + 31) / 32 + (g1_floats + 1023) / 1024;   // dG2 | dG0, then dG1
+    const int wgs = (g2_floats + 31) / 32 + (s.p[0] * C::ROW0 + 31) / 32 + (g1_floats + 1023) / 1024;   // dG2 | dG0 | dG1
     profile_begin(9, st);
     hipLaunchKernelGGL(fast3_finalize_kernel, dim3((unsigned)wgs), dim3(256), 0, st, plan, (int)slab_count(s, nnz), slices,
                        s.p[0], s.p[1], g2_floats, (int)C::ROW0, g1_floats, Q2, R2, d_cores.c[0], d_cores.c[1], d_cores.c[2], upd, gfuse ? 1 : 0);
