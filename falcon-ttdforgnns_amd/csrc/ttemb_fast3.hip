@@ -3051,7 +3051,38 @@ static int64_t fused_tiles(const DevShape& s, int64_t nnz) {   // workgroups: at
   const int64_t most = (int64_t)chain_cus() * (8 / kFuseWaves);
   return t < 1 ? 1 : (t > most ? most : t);
 }
+// Wide-rank chain: the backward that keeps its dG2 slices in LDS (wide3_bwd_slab_kernel, no E table).  A wavefront's slice is
+// p2 rows of 16 q2 + 4 floats + a tag word per row; `wpb` wavefronts per workgroup (one workgroup per CU) own consecutive rank
+// tiles, `shares` workgroup sets split the chunk table -- one slab of partial dG2 per share.
+static int wide_slab_js(const DevShape& s) {   // q2 = 8: a tile's slice is split over two wavefronts by k2 halves
+#ifdef TTEMB_WIDE_SLAB_JS1
+  return 1;
+#endif
+  return s.q[2] % 8 == 0 ? 2 : 1;
+}
+static int wide_slab_wpb(const DevShape& s) {
+  const int64_t per_wave = (int64_t)s.p[2] * (16 * (s.q[2] / wide_slab_js(s)) + 4 + 1) * 4;
+  int wpb = (int)(kCuLds / (per_wave > 0 ? per_wave : 1));
+  wpb = wpb >= 4 ? 4 : (wpb >= 2 ? 2 : wpb);
+  const int units = s.R[2] / 16 * wide_slab_js(s);
+  while (wpb > 1 && units % wpb != 0) wpb >>= 1;
+  return wpb;
+}
+static int wide_slab_shares(const DevShape& s) {
+  const int tgroups = (s.R[2] / 16 * wide_slab_js(s)) / wide_slab_wpb(s);
+  const int sh = chain_cus() / (tgroups > 0 ? tgroups : 1);
+  return sh < 1 ? 1 : sh;
+}
+// taken when the E table it saves is large against the slabs it writes (16 384 ids at rank 256: 1 176 us against 1 114 with the
+// table; 409 600 ids: 2 068 against 2 367): from 8 ids per (share, i2) slab row on
+static bool wide_slab(const DevShape& s, int64_t nnz) {
+#ifdef TTEMB_WIDE_E_TABLE   // (A/B: the round-4 form -- E table + reduce kernel)
+  return false;
+#endif
+  return wide(s) && wide_slab_wpb(s) >= 2 && nnz >= (int64_t)8 * wide_slab_shares(s) * s.p[2];
+}
 static int64_t slab_count(const DevShape& s, int64_t nnz) {
+  if (wide_slab(s, nnz)) return wide_slab_shares(s);
   return fused_dg2(s) ? fused_tiles(s, nnz) : (shared_slab(s) ? 1 : reduce_tiles(nnz));
 }
 // the epilogue cuts the i0 range of every i1 into ~kEpiSlices slices of `gpw` groups (one wavefront each)
@@ -3147,7 +3178,7 @@ static int64_t carve_workspace(const DevShape& s, int64_t nnz, bool bwd, bool pl
     }
   }
   if (bwd) {
-    float* e = (float*)take(fused_dg2(s) ? 0 : nnz * (int64_t)s.row_len[2] * 4);   // no E table in the fused form
+    float* e = (float*)take((fused_dg2(s) || wide_slab(s, nnz)) ? 0 : nnz * (int64_t)s.row_len[2] * 4);   // no E table in the fused forms
     float* d = (float*)take(G * (int64_t)s.q[0] * s.q[1] * s.R[2] * 4);
     float* g2 = (float*)take(slab_count(s, nnz) * (int64_t)s.p[2] * s.row_len[2] * 4);
     float* g0 = (float*)take(G * (int64_t)s.row_len[0] * 4);
@@ -3438,15 +3469,39 @@ static int run_backward_wide(const DevShape& s, const CorePtrs& cores, const Gro
   profile_begin(1, st);
   int rc = run_wide_rows(s, plan, st);   // (the workspace of this call; the forward's lists are not part of the plan)
   if (rc) return rc;
+  static_assert(C::ROW2 % 256 == 0, "the E reduce takes 256 columns per launch row");
+  const int tiles = (int)reduce_tiles(nnz);
+  const size_t reduce_lds = (size_t)(2 * s.p[2] + 1) * 4 + kRowsB * 2;
+  if (wide_slab(s, nnz)) {   // chunk products and the dG2 reduction in one launch: the tile slices of dG2 stay in LDS (no E table)
+    constexpr int kJS = Q2 % 8 == 0 ? 2 : 1;
+    const int js = wide_slab_js(s), wpb = wide_slab_wpb(s), shares = wide_slab_shares(s);
+    const size_t lds = (size_t)wpb * s.p[2] * (16 * (Q2 / js) + 4 + 1) * 4;
+    const dim3 grid((unsigned)(shares * (C::RT2 * js / wpb)));
+    static LdsGate lds_ok[2];
+    profile_begin(2, st);
+    if (js == kJS && kJS == 2) {
+      if constexpr (kJS == 2) {
+        rc = allow_big_lds(reinterpret_cast<const void*>(wide3_bwd_slab_kernel<Q0, Q1, Q2, R1, R2, kJS>), lds, &lds_ok[1], "wide3_bwd_slab_kernel");
+        if (rc) return rc;
+        hipLaunchKernelGGL((wide3_bwd_slab_kernel<Q0, Q1, Q2, R1, R2, kJS>), grid, dim3(256), lds, st, cores.c[2], (uint32_t)G, (uint32_t)s.p[2],
+                           d_output, (uint32_t)(B * s.D * 4), plan, (uint32_t)wpb, (uint32_t)shares);
+      }
+    } else {
+      rc = allow_big_lds(reinterpret_cast<const void*>(wide3_bwd_slab_kernel<Q0, Q1, Q2, R1, R2, 1>), lds, &lds_ok[0], "wide3_bwd_slab_kernel");
+      if (rc) return rc;
+      hipLaunchKernelGGL((wide3_bwd_slab_kernel<Q0, Q1, Q2, R1, R2, 1>), grid, dim3(256), lds, st, cores.c[2], (uint32_t)G, (uint32_t)s.p[2],
+                         d_output, (uint32_t)(B * s.D * 4), plan, (uint32_t)wpb, (uint32_t)shares);
+    }
+    profile_end(2, st);
+    rc = check_hip(hipGetLastError(), "wide3_bwd_slab_kernel");
+    if (rc) return rc;
+  } else {
   profile_begin(2, st);
   hipLaunchKernelGGL((wide3_bwd_chunk_kernel<Q0, Q1, Q2, R1, R2>), dim3((unsigned)((G * C::TS + 3) / 4)), dim3(256), 0, st, cores.c[2],
                      (uint32_t)G, (uint32_t)s.p[2], d_output, (uint32_t)(B * s.D * 4), plan);
   profile_end(2, st);
   rc = check_hip(hipGetLastError(), "wide3_bwd_chunk_kernel");
   if (rc) return rc;
-  static_assert(C::ROW2 % 256 == 0, "the E reduce takes 256 columns per launch row");
-  const int tiles = (int)reduce_tiles(nnz);
-  const size_t reduce_lds = (size_t)(2 * s.p[2] + 1) * 4 + kRowsB * 2;
 #if defined(TTEMB_ABL) && (TTEMB_ABL & 2048)   // (ablation 2048: no E stores in the wide chunk kernel, no reduce launch: what the E round trip costs; timing only)
   if (nnz < 0) {
 #else
@@ -3465,6 +3520,7 @@ static int run_backward_wide(const DevShape& s, const CorePtrs& cores, const Gro
   }
   rc = check_hip(hipGetLastError(), "fast3_dg2_reduce_kernel (wide)");
   if (rc) return rc;
+  }
   const uint32_t M = (uint32_t)(s.p[0] * Q0), N1 = (uint32_t)C::N1;
   {  // dG1[i1] (r1 x q1 r2) = G0^T (r1 x p0 q0) . dP[i1] (p0 q0 x q1 r2)
     WideGemm g;
@@ -3590,7 +3646,14 @@ struct GFuseCfg {
   using C = Cfg<Q0, Q1, Q2, R1, R2>;
   static constexpr bool ok = 16 / Q0 >= 2 && C::N1 % 16 == 0 && Q1 > 1;
 };
-static int64_t gfuse_limit(const DevShape& s) { return kGFuseIdsPerGroup >= 0 ? kGFuseIdsPerGroup : (s.q[0] == 8 ? 16 : 8); }
+// ids per group up to which the route is taken.  At rank 32 it wins at every density that was measured (papers100M 1.5 ... 8.6
+// ids per group and a METIS-like frontier of 130 per touched group; the products table at 5.6 / 7.7 / 23 uniform and 80 per
+// group METIS-like: -5 ... -22 %, profiles/r05_gf_rule.txt): no limit there.  Rank <= 16 shapes reach this kernel only when
+// their p2 is past the fused dG2 form; they keep the forward's rule (measured at ~3-4 ids per group only).
+static int64_t gfuse_limit(const DevShape& s) {
+  if (kGFuseIdsPerGroup >= 0) return kGFuseIdsPerGroup;
+  return s.R[2] >= 32 ? (int64_t(1) << 40) : (s.q[0] == 8 ? 16 : 8);
+}
 
 static bool gfuse_pays(const DevShape& s, int64_t nnz) {   // (the rule run_backward applies, for ttemb_kernel_family)
   if (gfuse_limit(s) <= 0 || !classify(s) || fused_dg2(s)) return false;
@@ -3599,7 +3662,7 @@ static bool gfuse_pays(const DevShape& s, int64_t nnz) {   // (the rule run_back
   TTEMB_FAST3_SHAPES(TTEMB_X)
 #undef TTEMB_X
   const int64_t G = num_groups(s);
-  return ok && nnz < gfuse_limit(s) * G && (uint64_t)G * (uint64_t)s.p[0] < (uint64_t(1) << 40);
+  return ok && (gfuse_limit(s) >= (int64_t(1) << 40) || nnz < gfuse_limit(s) * G) && (uint64_t)G * (uint64_t)s.p[0] < (uint64_t(1) << 40);
 }
 bool fast3_group_products_in_chain(const DevShape& s, int64_t nnz, int64_t B) { return fits_piece(s, nnz, B) && gfuse_pays(s, nnz); }
 
