@@ -76,8 +76,11 @@ def test_workspace_and_plan_sizes_follow_the_kernel_family():
     wide = nat.make_shape([125, 140, 140], [5, 5, 4], [256, 256])
     narrow = nat.make_shape([125, 140, 140], [5, 5, 4], [32, 32])
     ws = lambda shp, op, nnz: lib.ttemb_workspace_bytes(ctypes.byref(shp), op, nnz, nnz)
-    # wide-rank chain: the backward keeps an E table of nnz * r2 q2 floats and a dP table of G * q0 q1 r2 floats
-    assert ws(wide, nat.OP_BACKWARD, n) >= n * 256 * 4 * 4 + G * 25 * 256 * 4
+    # wide-rank chain: the backward keeps a dP table of G * q0 q1 r2 floats; a SMALL call also an E table of nnz * r2 q2 floats,
+    # a large one reduces dG2 in LDS and keeps partial slabs instead (one per share of the chunk table: p2 * r2 q2 floats each)
+    small = 16384
+    assert ws(wide, nat.OP_BACKWARD, small) >= small * 256 * 4 * 4 + G * 25 * 256 * 4
+    assert G * 25 * 256 * 4 + 16 * 140 * 1024 * 4 <= ws(wide, nat.OP_BACKWARD, n) < n * 256 * 4 * 4   # (no 1.7 GB E table)
     assert ws(wide, nat.OP_BACKWARD, n) < 6 * 2**30
     assert ws(wide, nat.OP_FORWARD, n) < ws(wide, nat.OP_BACKWARD, n)
     # the plan carries the prefix products of every group
