@@ -2986,7 +2986,7 @@ bool fast3_fits_in_pieces(const DevShape& s, int64_t nnz, int64_t B) { return fi
 static int64_t pieces_head_bytes(const DevShape& s, int64_t nnz, int64_t B) { return align256((int64_t)piece_slots(s, nnz, B) * (int64_t)sizeof(Piece)); }
 
 #ifndef TTEMB_ROWS_B
-#define TTEMB_ROWS_B 2048
+#define TTEMB_ROWS_B 4096   // (2 048 until round 5: papers100M r32 at 819 200 / 2.4 M ids writes and re-reads half / 40 % fewer 205 KB slabs: backward -10 / -29 us)
 #endif
 constexpr int kRowsB = TTEMB_ROWS_B;  // E rows per workgroup of the dG2 reduce, at most
 // One round of workgroups when the batch allows it: the kernel is as long as its longest workgroup, so 409 600 rows

@@ -23,4 +23,9 @@ cd $R && python3 bench.py > $O/bench_default.json 2> $O/bench_default.err || exi
 # per-kernel summaries of the wide-rank chain (ranks 64 / 256 of the rank sweep), uniform and METIS-like ids
 bash $R/tools/prof_cfg.sh q554_r64 q554_r256 q448_r256 < /dev/null 2>&1 | grep -E "^==|uniform|calls" > $O/wide_kernels.txt || exit 1
 cd $R && for c in q554_r64 q554_r256; do python3 tools/kbench.py --cfg $c --iters 5 --no-rowidx --dist windows 2>/dev/null | tail -1 >> $O/wide_kernels.txt; done
+# RCCL under this code at the one world size a one-GPU lease allows
+cd $R && python3 tools/rccl_selfcheck.py > $O/rccl_selfcheck.txt 2>&1 || exit 1
+# the wide-rank backward's traffic at rank 256 (no E table since round 5)
+TRAFFIC_KBENCH_ARGS="--cfg q554_r256 --no-rowidx --what bwd" bash $R/tools/traffic.sh profiles/r05_wide_traffic_q554_r256.json > $O/wide_traffic.log 2>&1 || exit 1
+cp $R/profiles/r05_wide_traffic_q554_r256.json $O/
 cat $O/bench_default.json
