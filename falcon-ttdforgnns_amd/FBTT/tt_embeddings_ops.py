@@ -261,8 +261,14 @@ class TTLookupFunction(torch.autograd.Function):
         bucket = getattr(m, "_dense_grad_out", None)
         # (for ttemb_dist: did this gradient come from a grouped backward -- the family with bounded device-side waits,
         #  whose last kernel leaves its verdict in the workspace header?  Host-side rule, launches nothing.)
-        m._last_bwd_grouped = nnz > 0 and (_nat.kernel_family(m._shape, nnz, B, rowidx is None) & 7) in (
-            _nat.FAMILY_GROUPED, _nat.FAMILY_GROUPED_WIDE)
+        fam_key = (nnz, B, rowidx is None, _nat.path_epoch)
+        grouped = m._family_cache.get(fam_key)
+        if grouped is None:
+            if len(m._family_cache) > 256:
+                m._family_cache.clear()
+            grouped = m._family_cache[fam_key] = nnz > 0 and (_nat.kernel_family(m._shape, nnz, B, rowidx is None) & 7) in (
+                _nat.FAMILY_GROUPED, _nat.FAMILY_GROUPED_WIDE)
+        m._last_bwd_grouped = grouped
         if bucket is not None and not ctx.live_cache:
             if m._bucket_filled:
                 # a second backward before dp.step() (micro-batches, two lookups through one module): the kernels
@@ -318,6 +324,48 @@ class _SparseLookup(torch.autograd.Function):
         state = None if m.optimizer in _SGD_LIKE else m._states()
         m._lean.backward(m._cores(), state, ctx.indices, ctx.offsets, ctx.indices.numel(), ctx.B, d_output,
                          float(m.learning_rate), float(m.eps), ctx.plan)
+        return None, None, None, None, None
+
+
+class _BucketLookup(torch.autograd.Function):
+    """The data-parallel step's call -- one table, ``sparse=False``, no live cache, a wrapper's flat gradient bucket attached
+    (``ttemb_dist.TTDataParallel``) -- with the lean bridge of ``_SparseLookup``: one tensor input, bound native arguments.
+    The forward is split around the wrapper's pending update; the backward writes the core gradients straight into the bucket
+    and hands nothing back to autograd.  (Through ``TTLookupFunction`` the same step cost the host ~200 us on a slow host --
+    as much as its GPU time at 409 600 ids.)  Same kernels and results."""
+
+    @staticmethod
+    def forward(ctx, anchor: torch.Tensor, module: "TableBatchedTTEmbeddingBag", indices: torch.Tensor,
+                offsets: torch.Tensor, B: int) -> torch.Tensor:
+        nnz = indices.numel()
+        out = torch.empty((B, module.embedding_dim), dtype=torch.float32, device=indices.device)
+        ctx.module, ctx.indices, ctx.offsets, ctx.B = module, indices, offsets, B
+        pending = module._before_weights
+        if pending is None:
+            ctx.plan = module._lean.forward(module._cores(), indices, offsets, nnz, B, out)
+        else:
+            ctx.plan = module._lean.forward_split(module._cores(), indices, offsets, nnz, B, out, pending)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_output: torch.Tensor):
+        m = ctx.module
+        if d_output.dtype != torch.float32 or not d_output.is_contiguous():
+            d_output = d_output.contiguous().float()
+        bucket = m._dense_grad_out
+        nnz = ctx.indices.numel()
+        if bucket is None:   # the wrapper was detached between forward and backward: gradients through .grad
+            grads = [torch.empty_like(c[0]) for c in m.tt_cores]
+            m._last_bwd_grouped = m._lean.backward_dense(m._cores(), ctx.indices, ctx.offsets, nnz, ctx.B, d_output, grads, ctx.plan)
+            for c, g in zip(m.tt_cores, grads):
+                c.grad = g.unsqueeze(0) if c.grad is None else c.grad + g.unsqueeze(0)
+        elif m._bucket_filled:   # a second backward before dp.step(): through scratch, added (what AccumulateGrad does)
+            more = [torch.empty_like(b) for b in bucket]
+            m._last_bwd_grouped = m._lean.backward_dense(m._cores(), ctx.indices, ctx.offsets, nnz, ctx.B, d_output, more, ctx.plan)
+            torch._foreach_add_(bucket, more)
+        else:
+            m._last_bwd_grouped = m._lean.backward_dense(m._cores(), ctx.indices, ctx.offsets, nnz, ctx.B, d_output, bucket, ctx.plan)
+            m._bucket_filled = True
         return None, None, None, None, None
 
 
@@ -486,6 +534,7 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         self._dense_grad_out = None
         self._before_weights = None   # set by ttemb_dist.TTDataParallel while an update of the cores is pending
         self._bucket_filled = False   # set by the backward when it wrote the core gradients into the wrapper's bucket
+        self._family_cache: dict = {}  # (nnz, B, ...) -> "the backward of this size runs on the grouped kernels" (ttemb_dist)
         self._shape = _nat.make_shape(self.tt_p_shapes, self.tt_q_shapes, self.tt_ranks)
         self._ws = _nat.Workspace()
         self._lean = _nat.LeanCalls(self._shape, self._ws)
@@ -577,6 +626,8 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         if not live:  # rows are derived from `offsets` inside the native calls: no separate launch, no tensor
             if self.sparse and self.num_tables == 1 and self._use_lean:
                 return _SparseLookup.apply(self._cores()[0], self, indices, offsets, B)
+            if not self.sparse and self.num_tables == 1 and self._use_lean and self._dense_grad_out is not None:
+                return _BucketLookup.apply(self._cores()[0], self, indices, offsets, B)
             return TTLookupFunction.apply(self, table, B, indices, None, offsets, None, None, None,
                                           *self.tt_cores)
         rowidx = torch.empty(nnz, dtype=torch.int64, device=dev)

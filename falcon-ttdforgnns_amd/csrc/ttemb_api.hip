@@ -608,7 +608,9 @@ __global__ void zero_rows_kernel(const int64_t* __restrict__ offsets, int64_t B,
 }
 
 __global__ void sgd_step_kernel(float* __restrict__ w, const float* __restrict__ g, int64_t n, float lr, const float* __restrict__ skip) {
-  if (skip != nullptr && *skip != 0.f) return;   // (ttemb_sgd_step_guarded: some rank's gradient came from a poisoned plan)
+  // (ttemb_sgd_step_guarded: some rank's gradient came from a poisoned plan.  The word is tested BIT-wise: an all-reduced float
+  //  count (k.0f) and the uint32 poison word of a workspace header (1) both read non-zero, +0.0f and 0u both zero)
+  if (skip != nullptr && *reinterpret_cast<const uint32_t*>(skip) != 0u) return;
   int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i + 3 < n) {
     float4 wv = *reinterpret_cast<float4*>(w + i);

@@ -3269,7 +3269,7 @@ static int prepare(const DevShape& s, const CorePtrs& cores, bool bwd, const int
   // building the whole plan: the prefix products ride in the last grouping launch
   // (prefix_in_chain: the forward chain kernel forms the prefix products itself -- fast3_forward_pfuse_kernel)
   if (plan_state <= 1) rc = group_ids(s, cores, indices, rowidx, offsets, nnz, nnz_dev, B, zero_out, plan_state == 0 && !prefix_in_chain, plan, st);
-  if (rc == TTEMB_OK && plan_state == 2) rc = run_prefix(s, cores, *plan, st);
+  if (rc == TTEMB_OK && plan_state == 2 && !prefix_in_chain) rc = run_prefix(s, cores, *plan, st);
   profile_end(3, st);
   return rc;
 }
@@ -3413,6 +3413,23 @@ static bool pfuse_pays(const DevShape& s, int64_t nnz) {
 }
 
 bool fast3_prefix_in_chain(const DevShape& s, int64_t nnz, int64_t B) { return fits_piece(s, nnz, B) && pfuse_pays(s, nnz); }
+// The lookup half of a two-phase forward (ttemb_forward_lookup: the data-parallel step groups the ids, finishes the
+// all-reduce + update, then looks up) cannot let its prefix products ride in the grouping launches -- they read the cores the
+// update has just written -- so they are a launch of their own there (8.6 us + its ramp at 409 600 ids on the products table).
+// The chain kernel that forms them itself is EQUAL to prefix launch + chain kernel at the products frontier's 23 ids per group
+// (profiles/r04_pfuse_forward.txt) when the launch rides for free; against a launch of its own it wins well past that: taken
+// up to 64 ids per group on average.
+static bool pfuse_pays_after_grouping(const DevShape& s, int64_t nnz) {
+#ifdef TTEMB_NO_PFUSE_PHASE2
+  return false;
+#endif
+  if (pfuse_limit(s) <= 0 || !classify(s)) return false;
+  bool ok = false;
+#define TTEMB_X(a, b, c, d, e) if (shape_is(s, a, b, c, d, e)) ok = pfuse_shape<a, b, c, d, e>();
+  TTEMB_FAST3_SHAPES(TTEMB_X)
+#undef TTEMB_X
+  return ok && nnz < 64 * num_groups(s);
+}
 
 template <int Q0, int Q1, int Q2, int R1, int R2>
 static int run_forward_pfuse(const DevShape& s, const CorePtrs& cores, const GroupPlan& plan, int64_t nnz, int64_t B,
@@ -3612,7 +3629,7 @@ int launch_forward_fast3(const DevShape& s, const CorePtrs& cores, const int64_t
   }
   GroupPlan plan;
   // a whole forward (phase 0) on a frontier with few ids per group: the chain kernel forms the prefix products itself
-  const bool pfuse = phase == 0 && pfuse_pays(s, nnz);
+  const bool pfuse = (phase == 0 && pfuse_pays(s, nnz)) || (phase == 2 && pfuse_pays_after_grouping(s, nnz));
   int rc = prepare(s, cores, false, indices, rowidx, offsets, nnz, nnz_dev, B, zero_rows ? output : nullptr, ws, ws_bytes,
                    plan_buf, plan_bytes, phase, &plan, st, header, nullptr, pfuse);   // phase 0 / 1 / 2 = whole forward / ids only / lookup on a grouped plan
   if (rc || phase == 1) return rc;

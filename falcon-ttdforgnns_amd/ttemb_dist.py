@@ -80,6 +80,10 @@ class TTDataParallel:
         self.flat_weights: Optional[torch.Tensor] = None
         self.weight_views: List[torch.Tensor] = []
         self._pending = None
+        self._skip: Optional[torch.Tensor] = None
+        self._fault_dirty = True     # (the bucket's fault slot holds something other than 0)
+        self._nat = None
+        self._word_buf, self._word = None, None
         self.adopt_parameters()
         # the backward kernels write the core gradients straight into the bucket
         module._dense_grad_out = [v[0] if v.dim() == 3 and v.shape[0] == 1 else v
@@ -133,10 +137,16 @@ class TTDataParallel:
         # bounded waits and do not write the word.  A fault some EARLIER call reported raises here, before NaN gradients
         # are summed into every rank.
         word = self._poison_word()
-        if word is None:
-            b.fault.zero_()
+        self._skip = b.fault
+        if self.world == 1:
+            self._skip = word      # one process: the guarded step reads the header word itself (no copy, nothing to sum)
+        elif word is None:
+            if self._fault_dirty:
+                b.fault.zero_()
+                self._fault_dirty = False
         else:
-            b.fault.copy_(word)
+            b.fault.copy_(word)    # int32 -> float: summed by the all-reduce below
+            self._fault_dirty = True
         work = None
         if self.world > 1:
             work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=overlap)
@@ -156,7 +166,7 @@ class TTDataParallel:
         if work is not None:
             work.wait()
         b = self.bucket
-        guard = (b.fault,) if self.apply_fn is default_apply else ()   # (an injected epilogue -- the CPU tests' -- takes no guard)
+        guard = (self._skip,) if self.apply_fn is default_apply else ()   # (an injected epilogue -- the CPU tests' -- takes no guard)
         if self._flat_ok():
             self.apply_fn(self.flat_weights, b.flat[:b.n_grad], lr / self.world, *guard)
         else:
@@ -164,10 +174,19 @@ class TTDataParallel:
                 self.apply_fn(p.data, g, lr / self.world, *guard)
 
     def _poison_word(self) -> Optional[torch.Tensor]:
+        """int32[1] view of the word the module's last grouped backward left in its workspace header, or None (CPU, or a
+        backward of a kernel family without device-side waits).  The view is cached per workspace buffer: this sits on the
+        host path of every step (a data-parallel rank is host-bound on a slow host)."""
         m = self.module
         if not self.bucket.flat.is_cuda or not getattr(m, "_last_bwd_grouped", False):
             return None
-        import ttemb_native as nat
+        nat = self._nat
+        if nat is None:
+            import ttemb_native as nat
+            self._nat = nat
         nat.status()   # an expired wait an earlier call reported: RuntimeError on this rank, before the collective
-        return nat.poison_word(m._ws)
+        buf = m._ws.buf
+        if buf is not self._word_buf:
+            self._word_buf, self._word = buf, nat.poison_word(m._ws)
+        return self._word
 

@@ -495,15 +495,19 @@ class LeanCalls:
         self.epoch = -1
         self.core_key, self.core_arr = None, None
         self.state_key, self.state_arr = None, None
+        self.grad_key, self.grad_arr = None, None
+        self.grouped: dict = {}
 
     def _entry(self, nnz: int, B: int):
         if self.epoch != path_epoch:
             self.sizes.clear()
+            self.grouped.clear()
             self.epoch = path_epoch
         e = self.sizes.get((nnz, B))
         if e is None:
             if len(self.sizes) > 1024:
                 self.sizes.clear()
+                self.grouped.clear()
             e = self.sizes[(nnz, B)] = (workspace_bytes(self.shape, OP_FORWARD, nnz, B),
                                         workspace_bytes(self.shape, OP_BACKWARD, nnz, B), plan_bytes(self.shape, nnz))
         return e
@@ -529,6 +533,51 @@ class LeanCalls:
         if rc:
             _check(rc)
         return plan
+
+    def forward_split(self, cores, indices, offsets, nnz: int, B: int, out, pending):
+        """The forward of a data-parallel step (ttemb_dist): the id-only half (grouping into the plan) is enqueued, THEN
+        ``pending()`` finishes the previous step's all-reduce + update, then the half that reads the cores.  A call without a
+        plan (per-bag / scalar kernels, a call in pieces) has no id-only half: ``pending()``, then the whole forward."""
+        fwd_ws, _, plan_n = self._entry(nnz, B)
+        self.core_key, self.core_arr = self._ptrs(cores, self.core_key, self.core_arr)
+        dev = out.device
+        w = self.ws.get(fwd_ws, dev)
+        plan = torch.empty(plan_n, dtype=torch.uint8, device=dev) if plan_n > 0 else None
+        args = (self.shape_ref, self.core_arr, indices.data_ptr() if nnz else None, None, offsets.data_ptr(), nnz, None, B,
+                out.data_ptr() if B else None, w.data_ptr(), w.numel(), plan.data_ptr() if plan is not None else None, plan_n,
+                _stream(out))
+        with _on_device(dev):
+            if plan is None:
+                pending()
+                rc = LIB.ttemb_forward(*args)
+            else:
+                rc = LIB.ttemb_forward_group(*args)
+                if rc == 0:
+                    pending()
+                    rc = LIB.ttemb_forward_lookup(*args)
+        if rc:
+            _check(rc)
+        return plan
+
+    def backward_dense(self, cores, indices, offsets, nnz: int, B: int, d_output, grads, plan) -> bool:
+        """Dense core gradients into ``grads`` (a fixed list of tensors: their pointer array is cached).  Returns whether
+        the gradient came from the grouped kernels (the family whose last kernel leaves its verdict in the workspace header)."""
+        _, bwd_ws, plan_n = self._entry(nnz, B)
+        self.core_key, self.core_arr = self._ptrs(cores, self.core_key, self.core_arr)
+        self.grad_key, self.grad_arr = self._ptrs(grads, self.grad_key, self.grad_arr)
+        dev = d_output.device
+        w = self.ws.get(bwd_ws, dev)
+        pp, pn = (plan.data_ptr(), plan_n) if plan is not None else (None, 0)
+        with _on_device(dev):
+            rc = LIB.ttemb_backward_dense(self.shape_ref, self.core_arr, indices.data_ptr() if nnz else None, None, offsets.data_ptr(),
+                                          nnz, None, B, d_output.data_ptr() if B else None, self.grad_arr, w.data_ptr(), w.numel(),
+                                          pp, pn, _stream(d_output))
+        if rc:
+            _check(rc)
+        g = self.grouped.get((nnz, B))
+        if g is None:
+            g = self.grouped[(nnz, B)] = nnz > 0 and (kernel_family(self.shape, nnz, B, True) & 7) in (FAMILY_GROUPED, FAMILY_GROUPED_WIDE)
+        return g
 
     def backward(self, cores, state, indices, offsets, nnz: int, B: int, d_output, lr: float, eps: float, plan):
         _, bwd_ws, plan_n = self._entry(nnz, B)

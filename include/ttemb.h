@@ -258,7 +258,8 @@ int ttemb_backward_adagrad(const ttemb_shape_t* shape, float* const* cores,
 /* Flat optimiser epilogues over n floats (used after the data-parallel all-reduce of
  * the flattened core gradients; same arithmetic as tt_embeddings_cuda.cu:381-419). */
 int ttemb_sgd_step(float* weights, const float* grads, int64_t n, float lr, void* stream);
-/* The same step, skipped as a whole when the device float *skip is non-zero.  The data-parallel step (no counterpart in the
+/* The same step, skipped as a whole when the 32-bit device word *skip is non-zero (tested bit-wise: a float count k.0f and
+ * the uint32 poison word of a workspace header both work; a single process passes the header word itself).  The data-parallel step (no counterpart in the
  * reference: its DDP path is a stub, sage_dgl_partition.py:198-255) all-reduces, next to the gradients, the number of ranks
  * whose gradient came from a POISONED plan (the word at TTEMB_HEADER_POISON_OFFSET of the workspace the backward ran on,
  * see "Device-side faults"): when any did, the summed gradient is NaN and every rank skips the update together -- replicas

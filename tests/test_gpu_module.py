@@ -675,6 +675,41 @@ def test_a_poisoned_rank_makes_every_rank_skip_the_data_parallel_update(tmp_path
             assert torch.equal(r[k]["end"][t], r[0]["start"][t]) and bool(torch.isfinite(r[k]["end"][t]).all())
 
 
+def test_single_process_data_parallel_step_skips_a_poisoned_gradient(ops):
+    """World size 1 (no collective): the guarded step reads the poison word of the module's workspace header itself --
+    a step whose grouping pass gave up leaves the weights alone, the next healthy step updates them."""
+    import ttemb_native as nat
+    from ttemb_dist import TTDataParallel
+    torch.manual_seed(4)
+    emb = ops.TTEmbeddingBag(2449029, 100, [16, 16], [125, 140, 140], [4, 5, 5], sparse=False, use_cache=False,
+                             weight_dist="normal", learning_rate=0.1)
+    for c in emb.tt_cores:
+        c.data.mul_(300.0)
+    dp = TTDataParallel(emb)
+    ids = torch.randperm(2449029)[:30000].cuda()
+    offs = torch.arange(30001).cuda()
+    d_out = ((torch.rand(30000, 100) - 0.5) * 0.02).cuda()
+    before = [c.detach().clone() for c in emb.tt_cores]
+    nat.set_spin_limit(-1)
+    try:
+        out = emb(ids, offs)
+        torch.cuda.synchronize()
+        with pytest.raises(RuntimeError, match="gave up waiting"):
+            nat.status()
+    finally:
+        nat.set_spin_limit(0)
+    assert bool(torch.isnan(out).all())
+    out.backward(d_out)
+    dp.step()
+    torch.cuda.synchronize()
+    assert all(torch.equal(c.detach(), b) for c, b in zip(emb.tt_cores, before)), "a poisoned gradient must not be applied"
+    emb(ids, offs).backward(d_out)
+    dp.step()
+    torch.cuda.synchronize()
+    assert not any(torch.equal(c.detach(), b) for c, b in zip(emb.tt_cores, before))
+    assert all(bool(torch.isfinite(c).all()) for c in emb.tt_cores)
+
+
 def test_bucket_accumulates_over_two_backwards_before_the_step(ops, orc):
     """Gradient accumulation with the data-parallel wrapper attached: two forward/backward passes before dp.step()
     must sum into the flat bucket (the kernels overwrite their destination; the second pass goes through scratch),

@@ -1242,3 +1242,46 @@ def test_backward_with_the_group_products_formed_in_the_chunk_kernel(nat, orc, q
         ref = w0 - lr * g / (np.sqrt(g * g) + 1e-6)
         big = np.abs(g) > 1e-3 * float(np.abs(g).max())   # (where g ~ 0 the step is lr * g / (|g| + eps): any rounding of g flips it)
         np.testing.assert_allclose(got.cpu().numpy()[big], ref[big], rtol=0, atol=2e-3 * lr)
+
+
+# ---------------------------------------------------------------------------------------
+# tables with many i1: the finalize kernel sums the dG0 parts with 16-byte loads over 32 lane rows (p1 >= 256)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("q,r,p,nnz_target", [
+    ([4, 5, 5], [16, 16], [16, 320, 24], 3000),     # epilogue kernel, sparse form (0.6 ids per group: parts of the non-empty groups only)
+    ([4, 5, 5], [16, 16], [16, 320, 24], 45000),    # epilogue kernel, dense form (every group has a part)
+    ([8, 4, 4], [32, 32], [14, 300, 20], 9000),     # the chunk kernel forms the group products (parts by the groups' counts)
+    ([5, 5, 4], [64, 64], [10, 260, 30], 30000),    # wide-rank chain (slab kernel or E table by size: parts by counts, one dG1 slab per K split)
+])
+def test_backward_on_tables_with_many_i1(nat, orc, q, r, p, nnz_target):
+    """p1 >= 256 (papers100M: 560; the reference's own papers run: 500): the dG0 sums of fast3_finalize_kernel take their
+    16-byte form -- 8 threads x float4 per 32 outputs, 32 lane rows over i1 -- in all three of its modes.  Dense gradients and
+    the fused SGD step against the oracle, ragged bags with duplicates."""
+    R = [1] + r + [1]
+    shape = nat.make_shape(p, q, R)
+    rng = np.random.default_rng(sum(p) + sum(q) + nnz_target)
+    idx, offsets = _random_bags(rng, int(np.prod(p)), nnz_target)
+    nnz, B = int(idx.shape[0]), int(offsets.shape[0] - 1)
+    nat.set_path(nat.PATH_FAST3)
+    fam = nat.kernel_family(shape, nnz, B, True)
+    assert fam & 7 in (nat.FAMILY_GROUPED, nat.FAMILY_GROUPED_WIDE), f"kernel family {fam}"
+    cores = [(rng.standard_normal((p[t], R[t] * q[t] * R[t + 1])) * (0.4 if r[0] < 64 else 0.15)).astype(np.float32) for t in range(3)]
+    c = [dev(x) for x in cores]
+    t_idx, t_offs = dev(idx, torch.int64), dev(offsets, torch.int64)
+    ws = nat.Workspace()
+    plan = nat.new_plan(shape, nnz, t_idx.device)
+    D = int(np.prod(q))
+    out = torch.empty((B, D), device="cuda")
+    nat.forward(shape, c, t_idx, None, t_offs, nnz, None, B, out, ws, plan)
+    d_out = ((rng.random((B, D)) - 0.5) * 0.2).astype(np.float32)
+    want_g = orc.tt_dense_backward(idx, offsets, d_out, cores, p, q, R)
+    grads = [torch.full_like(x, float("nan")) for x in c]
+    nat.backward_dense(shape, c, t_idx, None, nnz, None, B, dev(d_out), grads, ws, plan, t_offs)
+    torch.cuda.synchronize()
+    assert_grads_close([g.cpu().numpy() for g in grads], want_g, rel=2e-4 if r[0] >= 64 else 1e-4)
+    lr = 0.05
+    c2 = [x.clone() for x in c]
+    nat.backward_sgd(shape, c2, t_idx, None, nnz, None, B, dev(d_out), lr, ws, plan, t_offs)
+    torch.cuda.synchronize()
+    for got, w0, g in zip(c2, cores, want_g):
+        np.testing.assert_allclose(got.cpu().numpy(), w0 - lr * g, rtol=0, atol=1e-5 + 2e-4 * float(np.abs(lr * g).max()))
