@@ -3264,6 +3264,9 @@ static int prepare(const DevShape& s, const CorePtrs& cores, bool bwd, const int
     return fail(TTEMB_E_WORKSPACE, "fast path needs %lld workspace bytes, got %lld", (long long)need, (long long)ws_bytes);
   if (external) carve_plan_part(s, nnz, reinterpret_cast<char*>(plan_buf), plan);
   if (plan_state == 3) return TTEMB_OK;
+  // (the lookup half of a two-phase forward whose chain kernel forms the prefix products launches nothing here: the bracket of
+  //  the id-only half -- the grouping pass -- stays the one ttemb_profile_read(3) returns)
+  if (plan_state == 2 && prefix_in_chain) return TTEMB_OK;
   profile_begin(3, st);
   int rc = TTEMB_OK;
   // building the whole plan: the prefix products ride in the last grouping launch
