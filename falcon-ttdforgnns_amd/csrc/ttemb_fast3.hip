@@ -222,6 +222,8 @@ struct GroupPlan {           // device pointers into the caller's plan buffer / 
   uint32_t* wrows;           // wide-rank chain: [p1][stride] the rows (i0, a) of every i1 whose group holds an id (wide3_rows_kernel)
   uint32_t* wnrows;          // [p1] their number
   uint32_t* ticket;          // header word: the place step's range tickets (zeroed by the spread step of the same call)
+  uint32_t use_ticket;       // the place step draws its ranges from the ticket (the id-only half of a two-phase forward: the launch
+                             //     that runs beside the data-parallel step's all-reduce) instead of taking its workgroup indices
   uint32_t* fault_host;      // pinned host word (device address) a bounded wait that ran out reports to, or null
   uint32_t spin_limit;       // tries of the bounded waits of the grouping pass (ttemb_set_spin_limit; 0 = none: every wait expires)
 };
@@ -500,12 +502,19 @@ __global__ __launch_bounds__(kSortThreads) void fast3_spread_kernel(uint32_t nnz
 //      of step 2 sits between a workgroup's own publication and its first look (a separate count launch in front of the
 //      place launch cost ~5 us + the launch gap; a look-back BEFORE the scatter waited for the slowest histogram);
 //   4. chunk descriptors and group starts, one thread per group (a chunk's descriptor depends on its group's numbers only).
-// A workgroup's range is a TICKET it draws when it starts (one atomic on a header word the spread step zeroed), not its
-// blockIdx: it then waits only for ranges whose workgroups have already started, whatever order the dispatcher chose and
-// whatever else occupies the CUs -- the data-parallel step runs this launch next to an RCCL all-reduce kernel
-// (TTDataParallel.step(overlap=True)), where "every workgroup of the launch is resident" is no longer a given (rocPRIM's
-// look-back scan draws its tile ids the same way).  The wait is bounded all the same: one that runs out poisons the plan and
-// reports (report_fault) -- never a hung device, never a plausible wrong table.
+// Which range a workgroup takes.  In a WHOLE forward (and a backward that regroups) it is the workgroup's index: workgroups
+// are dispatched in index order per XCD, so the lowest-numbered unfinished workgroup is always running or next in line for a
+// slot of its XCD, and it waits only on finished ones -- progress does not need the launch to be resident (it is NOT at rank
+// 32, where the prefix units' registers leave one 512-thread workgroup per CU: 300 ranges on 256 slots; a validation build
+// that rotates the ranges against the dispatch order expires there at once).  In the ID-ONLY HALF of a two-phase forward --
+// the launch the data-parallel step runs BESIDE its RCCL all-reduce kernel (TTDataParallel.step(overlap=True)), where CUs
+// are held by a kernel this library does not control -- the range is a TICKET the workgroup draws when it starts (one atomic
+// on a header word the spread step zeroed): it then waits only for workgroups that have started, whatever the dispatcher did
+// (rocPRIM's look-back scan draws its tile ids the same way).  The ticket is not free -- the ~270 atomics of a launch queue
+// up on one address: +3 us on the grouping pass at 409 600 ids, A/B in one call; requesting the likely range's bounds next to
+// the ticket instead of behind it changed nothing -- which is why the whole forward, whose launches share the GPU with nothing
+// of this process, does not pay it (-DTTEMB_PLACE_TICKET_ALWAYS does).  Either way the wait is bounded: one that runs out
+// poisons the plan and reports (report_fault) -- never a hung device, never a plausible wrong table.
 constexpr uint64_t kEpochMask = (1ull << 40) - 1ull;
 static_assert(kMaxRanges <= kRangeThreads, "the look-back reads one published word per thread");
 __device__ __forceinline__ void place_range(const uint32_t ranges, uint32_t G, uint32_t shift,
@@ -520,17 +529,19 @@ __device__ __forceinline__ void place_range(const uint32_t ranges, uint32_t G, u
   constexpr int NWV = kRangeThreads / kWave;
   // (the ticket's round trip runs next to the epoch load and the clearing of the counters: neither needs the range)
   const uint64_t epoch = (plan.epochs[1] & (kEpochMask >> 1)) | (1ull << 39);   // (top bit set: zeros / all-ones never match)
-#ifdef TTEMB_PLACE_BY_BLOCK   // (A/B: the range is the workgroup's index, as until round 4)
-  const uint32_t range = blockIdx.x;
+  const bool ticketed = plan.use_ticket != 0u;   // (workgroup-uniform: a kernel argument)
+  if (ticketed && threadIdx.x == 0) reinterpret_cast<uint32_t*>(red)[0] = atomicAdd(plan.ticket, 1u);
   for (uint32_t i = threadIdx.x; i < span; i += kRangeThreads) gcount[i] = 0u;
   __syncthreads();
+  uint32_t range = blockIdx.x;
+  if (ticketed) {
+#ifdef TTEMB_TICKET_ROTATE   // (validation build: every workgroup's range differs from its index.  NOT a valid order: range 0 is
+    range = (reinterpret_cast<uint32_t*>(red)[0] + 1u) % ranges;   // drawn last, so a launch whose workgroups are not all resident expires)
 #else
-  if (threadIdx.x == 0) reinterpret_cast<uint32_t*>(red)[0] = atomicAdd(plan.ticket, 1u);
-  for (uint32_t i = threadIdx.x; i < span; i += kRangeThreads) gcount[i] = 0u;
-  __syncthreads();
-  const uint32_t range = reinterpret_cast<uint32_t*>(red)[0];   // (red is the scan's scratch next: two barriers further down)
-  if (range >= ranges) return;   // (cannot happen: `ranges` workgroups draw from a counter that started at 0)
+    range = reinterpret_cast<uint32_t*>(red)[0];   // (red is the scan's scratch next: two barriers further down)
 #endif
+    if (range >= ranges) return;   // (cannot happen: `ranges` workgroups draw from a counter that started at 0)
+  }
   const uint32_t g0 = range << shift;
   const uint32_t n0 = plan.rstart[range], n1 = plan.rstart[range + 1];
   // ---- 1. histogram, scan, publication ----
@@ -3254,6 +3265,11 @@ static int prepare(const DevShape& s, const CorePtrs& cores, bool bwd, const int
   plan->epochs = reinterpret_cast<uint64_t*>(header);
   plan->rcount = plan->epochs ? plan->epochs + 2 : nullptr;
   plan->ticket = header ? reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(header) + kHeaderPoisonOffset + 8) : nullptr;
+#ifdef TTEMB_PLACE_TICKET_ALWAYS
+  plan->use_ticket = 1u;
+#else
+  plan->use_ticket = plan_state == 1 ? 1u : 0u;   // (see place_range)
+#endif
   static_assert(kHeaderPoisonOffset + 16 <= kFast3HeaderBytes, "the header holds the epoch words, every bank of range counters, the poison word and the ticket");
   const bool external = plan_buf != nullptr && plan_bytes >= fast3_plan_bytes(s, nnz);
   if (plan_state != 0 && !external) return fail(TTEMB_E_BADARG, "this call needs a plan buffer of ttemb_plan_bytes() bytes");
