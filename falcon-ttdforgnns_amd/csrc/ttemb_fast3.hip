@@ -1761,6 +1761,28 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
   auto has_next = [&](uint32_t cc, const uint4& d) { return cc + 1 < nchunks && !((d.z & kLastBit) && cc + 1 >= c1); };
   const uint4 none = make_uint4(0u, 0u, 0u, 0u);
 
+  // MFMA operands of the dP product, two sets (block b4 in set b4 & 1).  !FUSE (short iterations, ONE wavefront per SIMD at rank
+  // 32: nothing hides an LDS round trip): the reads of a chunk's first block are issued right after its rows were staged, an
+  // iteration ahead, and the blocks / column tiles past the chunk's length are not read at all (three ids per chunk on the
+  // papers100M frontier: 70 of the ~100 operand reads of an iteration fed nothing).
+  float av2[2][Q2][C::MT2], bv2[2][Q2][C::RT2];
+  auto load_block = [&](int b4, int slot) {
+#pragma unroll
+    for (int kk = 0; kk < Q2; ++kk) {
+#pragma unroll
+      for (int mt = 0; mt < C::MT2; ++mt) av2[slot][kk][mt] = dbuf[offA[mt] + b4 * 4 * C::LDOB + kk];
+#pragma unroll
+      for (int t = 0; t < C::RT2; ++t) {
+        bv2[slot][kk][t] = bbuf[offB[t] + b4 * 4 * C::LDBB + kk];
+        if (16 * t + lo >= R2) bv2[slot][kk][t] = 0.f;
+      }
+    }
+  };
+#if defined(TTEMB_NO_LDS_AHEAD) || defined(TTEMB_NO_PIPE_LDS) || defined(TTEMB_ABL)   // (A/B: the round-4 order -- every read of an iteration issued inside it, whatever the chunk's length)
+  constexpr bool kAhead = false;
+#else
+  constexpr bool kAhead = !FUSE;
+#endif
   // ---- prologue: chunk 0 into LDS, rows of chunk 1 and the pairs of chunk 2 in flight ----
   uint4 d_cur = load_desc(ctab, c, nchunks);
   if (!have) d_cur = none;
@@ -1780,6 +1802,12 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
 #endif
   request(offsets(d_cur, i2_a, val_a), d_cur);
   stage(true);
+  if constexpr (kAhead) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    load_block(0, 0);
+  }
   __builtin_amdgcn_sched_barrier(0);
   request(offsets(d_nxt, i2_b, val_b), d_nxt);
   uint32_t i2_nn, val_nn;
@@ -1841,6 +1869,30 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
         for (int t = 0; t < C::RT2; ++t) dp[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 
+    // operands of the E product: A = P^T (read once per chunk), B = the staged d_output rows, one column tile at a time
+    constexpr int KS = (C::M2 + 3) / 4;
+    float ap[KS][C::RT2];
+    float be[2][KS];
+    auto load_ap = [&]() {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        // q0 q1 not a multiple of the MFMA K: the last step's rows past M2 are read (inside the buffers) and zeroed
+        const bool k_ok = 4 * s + 3 < C::M2 || 4 * s + hi < C::M2;
+#pragma unroll
+        for (int t = 0; t < C::RT2; ++t) {
+          ap[s][t] = pbuf[(4 * s + hi) * C::LDPB + (16 * t + lo) % R2];
+          if (16 * t + lo >= R2 || !k_ok) ap[s][t] = 0.f;
+        }
+      }
+    };
+    auto load_tile = [&](int nt, int slot) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const bool k_ok = 4 * s + 3 < C::M2 || 4 * s + hi < C::M2;
+        be[slot][s] = dbuf[offE[nt] + 4 * s * Q2];
+        if (!k_ok) be[slot][s] = 0.f;
+      }
+    };
 #if !(defined(TTEMB_ABL) && (TTEMB_ABL & 4))
     // ---- dP += dO (q0q1 x 16 q2) . G2s^T (16 q2 x r2); K-steps whose four ids lie past the chunk's length are skipped ----
 #ifndef TTEMB_NO_PIPE_LDS
@@ -1848,24 +1900,16 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
     // with a wait for its own reads (~100 cycles, three or four times per block).  The reads of a block past the chunk's
     // length are issued all the same (they hit rows of an older chunk and are not used).
     {
-      float av2[2][Q2][C::MT2], bv2[2][Q2][C::RT2];
-      auto load_block = [&](int b4, int slot) {
-#pragma unroll
-        for (int kk = 0; kk < Q2; ++kk) {
-#pragma unroll
-          for (int mt = 0; mt < C::MT2; ++mt) av2[slot][kk][mt] = dbuf[offA[mt] + b4 * 4 * C::LDOB + kk];
-#pragma unroll
-          for (int t = 0; t < C::RT2; ++t) {
-            bv2[slot][kk][t] = bbuf[offB[t] + b4 * 4 * C::LDBB + kk];
-            if (16 * t + lo >= R2) bv2[slot][kk][t] = 0.f;
-          }
-        }
-      };
-      load_block(0, 0);
+      if constexpr (kAhead) {   // the E product's first operands ride in front of the dP MFMAs (they need nothing of them)
+        load_ap();
+        load_tile(0, 0);
+      } else {
+        load_block(0, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int b4 = 0; b4 < kChunk / 4; ++b4) {
-        if (b4 + 1 < kChunk / 4) load_block(b4 + 1, (b4 + 1) & 1);
+        if (b4 + 1 < kChunk / 4 && (!kAhead || (uint32_t)(4 * (b4 + 1)) < len)) load_block(b4 + 1, (b4 + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
         if ((uint32_t)(4 * b4) < len) {
 #pragma unroll
@@ -1916,34 +1960,14 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
     // ---- E = P^T (r2 x q0q1) . dO (q0q1 x 16 q2): the A operand (P^T) is read once, column tiles without an id are skipped ----
     f32x4 e[C::RT2][C::NT2];
 #if !(defined(TTEMB_ABL) && (TTEMB_ABL & 8))
-    constexpr int KS = (C::M2 + 3) / 4;
-    float ap[KS][C::RT2];
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      // q0 q1 not a multiple of the MFMA K: the last step's rows past M2 are read (inside the buffers) and zeroed
-      const bool k_ok = 4 * s + 3 < C::M2 || 4 * s + hi < C::M2;
-#pragma unroll
-      for (int t = 0; t < C::RT2; ++t) {
-        ap[s][t] = pbuf[(4 * s + hi) * C::LDPB + (16 * t + lo) % R2];
-        if (16 * t + lo >= R2 || !k_ok) ap[s][t] = 0.f;
-      }
-    }
+    if constexpr (!kAhead) load_ap();
 #ifndef TTEMB_NO_PIPE_LDS   // (the same two-set scheme for the B operand of the E product: -2.5 % on the fused kernel, A/B in one call)
     {
-      float be[2][KS];
-      auto load_tile = [&](int nt, int slot) {
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          const bool k_ok = 4 * s + 3 < C::M2 || 4 * s + hi < C::M2;
-          be[slot][s] = dbuf[offE[nt] + 4 * s * Q2];
-          if (!k_ok) be[slot][s] = 0.f;
-        }
-      };
-      load_tile(0, 0);
+      if constexpr (!kAhead) load_tile(0, 0);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int nt = 0; nt < C::NT2; ++nt) {
-        if (nt + 1 < C::NT2) load_tile(nt + 1, (nt + 1) & 1);
+        if (nt + 1 < C::NT2 && (!kAhead || (uint32_t)(16 * (nt + 1)) < len * Q2)) load_tile(nt + 1, (nt + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
         if ((uint32_t)(16 * nt) < len * Q2) {
 #pragma unroll
@@ -2101,6 +2125,12 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
     uint4 d_n3x = none;
     if constexpr (!FUSE) {
       stage((d_nxt.z & kFirstBit) != 0u);
+      if constexpr (kAhead) {   // the next chunk's first dP operands: its rows have just landed, the stores and requests below hide the trip
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        load_block(0, 0);
+      }
 #ifndef TTEMB_DESC_LATE
       // the descriptor of chunk c + 3 is requested HERE and used at the end of the iteration (loaded there, its scalar round
       // trip -- a wait of its own, ~600 cycles -- closed every iteration).  From here to the end of the iteration no LDS
