@@ -850,6 +850,11 @@ int ttemb_set_piece_limits(int64_t rows, int64_t ids) {
   return TTEMB_OK;
 }
 
+int ttemb_set_wide_slab_min_ids(int64_t ids) {
+  fast3_set_wide_slab_min_ids(ids);
+  return TTEMB_OK;
+}
+
 int ttemb_set_spin_limit(int64_t tries) {
   fast3_set_spin_limit(tries);
   return TTEMB_OK;

@@ -74,6 +74,7 @@ bool fast3_fits(const DevShape& s, int64_t nnz, int64_t B);   // the call fits o
 bool fast3_fits_in_pieces(const DevShape& s, int64_t nnz, int64_t B);   // ... or runs as several pieces (needs `offsets`)
 void fast3_set_piece_limits(int64_t rows, int64_t ids);                  // diagnostic: smaller pieces than the hardware's
 void fast3_set_spin_limit(int64_t tries);                                // diagnostic: tries of the grouping pass's bounded waits
+void fast3_set_wide_slab_min_ids(int64_t ids);                           // diagnostic: call size from which the wide backward reduces dG2 in LDS
 // The pinned host word a device-side wait that ran out reports to (ttemb_api.hip): its device address for the kernels
 // (null until ttemb_init() / ttemb_status() has created it -- the lookups allocate nothing), and the host-side check every
 // lookup entry point starts with -- TTEMB_E_HIP once per reported fault.

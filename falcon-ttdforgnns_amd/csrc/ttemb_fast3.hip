@@ -3116,11 +3116,17 @@ static int wide_slab_shares(const DevShape& s) {
 }
 // taken when the E table it saves is large against the slabs it writes (16 384 ids at rank 256: 1 176 us against 1 114 with the
 // table; 409 600 ids: 2 068 against 2 367): from 8 ids per (share, i2) slab row on
+// DIAGNOSTIC (ttemb_set_wide_slab_min_ids): the call size from which the slab kernel is taken; 0 = the rule, 1 = always (how
+// the unit tests -- a few thousand ids -- reach the kernel), a huge value = never
+static std::atomic<int64_t> g_wide_slab_min{0};
+void fast3_set_wide_slab_min_ids(int64_t ids) { g_wide_slab_min.store(ids > 0 ? ids : 0); }
 static bool wide_slab(const DevShape& s, int64_t nnz) {
 #ifdef TTEMB_WIDE_E_TABLE   // (A/B: the round-4 form -- E table + reduce kernel)
   return false;
 #endif
-  return wide(s) && wide_slab_wpb(s) >= 2 && nnz >= (int64_t)8 * wide_slab_shares(s) * s.p[2];
+  const int64_t forced = g_wide_slab_min.load();
+  const int64_t least = forced > 0 ? forced : (int64_t)8 * wide_slab_shares(s) * s.p[2];
+  return wide(s) && wide_slab_wpb(s) >= 2 && nnz >= least;
 }
 static int64_t slab_count(const DevShape& s, int64_t nnz) {
   if (wide_slab(s, nnz)) return wide_slab_shares(s);

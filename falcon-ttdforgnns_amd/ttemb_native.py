@@ -28,7 +28,7 @@ PATH_AUTO, PATH_GENERIC, PATH_FAST3, PATH_PER_BAG = 0, 1, 2, 3
 # every symbol include/ttemb.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = (
     "ttemb_abi_version", "ttemb_last_error", "ttemb_workspace_bytes", "ttemb_plan_bytes", "ttemb_set_path",
-    "ttemb_profile_enable", "ttemb_profile_read", "ttemb_kernel_family", "ttemb_set_piece_limits", "ttemb_init", "ttemb_status", "ttemb_set_spin_limit",
+    "ttemb_profile_enable", "ttemb_profile_read", "ttemb_kernel_family", "ttemb_set_piece_limits", "ttemb_set_wide_slab_min_ids", "ttemb_init", "ttemb_status", "ttemb_set_spin_limit",
     "ttemb_forward", "ttemb_forward_group", "ttemb_forward_lookup", "ttemb_backward_dense", "ttemb_backward_sgd", "ttemb_backward_adagrad",
     "ttemb_sgd_step", "ttemb_sgd_step_guarded", "ttemb_adagrad_step", "ttemb_cache_update", "ttemb_cache_update_one_sweep", "ttemb_cache_populate",
     "ttemb_preprocess", "ttemb_preprocess_update", "ttemb_cache_forward", "ttemb_cache_backward_sgd",
@@ -80,6 +80,7 @@ def _load() -> ctypes.CDLL:
     lib.ttemb_kernel_family.argtypes = [shp, i64, i64, i32]
     lib.ttemb_set_piece_limits.argtypes = [i64, i64]
     lib.ttemb_set_spin_limit.argtypes = [i64]
+    lib.ttemb_set_wide_slab_min_ids.argtypes = [i64]
     lib.ttemb_status.argtypes = []
     lib.ttemb_init.argtypes = []
     lib.ttemb_plan_bytes.restype = i64
@@ -291,6 +292,14 @@ def set_piece_limits(rows: int = 0, ids: int = 0) -> None:
     """Diagnostic: cut calls into pieces of at most ``rows`` bags / ``ids`` ids (0 = the hardware's limits)."""
     global path_epoch
     _check(LIB.ttemb_set_piece_limits(rows, ids))
+    _size_cache.clear()
+    path_epoch += 1
+
+
+def set_wide_slab_min_ids(ids: int = 0) -> None:
+    """Diagnostic: from how many ids on the wide-rank backward reduces dG2 in LDS (0 = the rule, 1 = always)."""
+    global path_epoch
+    _check(LIB.ttemb_set_wide_slab_min_ids(ids))
     _size_cache.clear()
     path_epoch += 1
 

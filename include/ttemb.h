@@ -109,6 +109,12 @@ int ttemb_set_path(int32_t path);
  * tests can cut a small call into many pieces.  Never changes a result. */
 int ttemb_set_piece_limits(int64_t rows, int64_t ids);
 
+/* DIAGNOSTIC, process-wide: the number of ids from which the backward of the wide-rank chain (ranks 64 / 128 / 256) reduces
+ * dG2 inside its chunk kernel (LDS slabs, no E table) instead of writing one E row per id and reducing them in a second
+ * kernel.  0 = the library's rule (8 ids per slab row: the slabs are written whatever the batch), 1 = always, a huge value =
+ * never.  Changes workspace sizes (ask ttemb_workspace_bytes again); never changes a result beyond fp32 summation order. */
+int ttemb_set_wide_slab_min_ids(int64_t ids);
+
 /* Device-side faults.  The grouping pass of the grouped lookup has two BOUNDED waits between workgroups (the take-over of a
  * range counter that carries another call's tag, and the place step's look back at the chunk totals of the ranges before
  * it).  They cannot run out on a GPU that runs the launch's workgroups together; under CU masking, profiler

@@ -111,9 +111,19 @@ def test_four_core_module_trains_on_the_grouped_path(ops, q, r):
         torch.testing.assert_close(c.detach(), want, rtol=1e-3, atol=2e-4)
 
 
+@pytest.fixture(params=["e_table", "lds_slabs"])
+def wide_backward_form(request):
+    """Both backward forms of the wide-rank chain (see tests/test_gpu_parity.py): the module's few hundred ids would take the
+    E table by the library's rule; the diagnostic sends them to the kernel that reduces dG2 in LDS."""
+    import ttemb_native as nat
+    nat.set_wide_slab_min_ids(1 if request.param == "lds_slabs" else 0)
+    yield request.param
+    nat.set_wide_slab_min_ids(0)
+
+
 @pytest.mark.parametrize("q,r", [([5, 5, 4], [64, 64]), ([4, 4, 8], [128, 128])])
 @pytest.mark.parametrize("mode", ["dense", "SGD", "EXACT_ADAGRAD"])
-def test_wide_rank_module_on_the_grouped_chain(ops, q, r, mode):
+def test_wide_rank_module_on_the_grouped_chain(ops, q, r, mode, wide_backward_form):
     """Rank 64 / 128 tables through the module: batches of >= 256 ids take the wide-rank grouped chain (GEMM prefix,
     per-group backward, GEMM dG1 / dG0, optimiser step in the finalize kernel); checked against autograd through
     tt_matrix_to_full."""

@@ -494,12 +494,23 @@ def test_random_tables_fast_path(nat, orc, shape, seed):
 WIDE3_SHAPES = [(5, 5, 4, 64, 64), (5, 5, 4, 128, 128), (5, 5, 4, 256, 256), (4, 4, 8, 64, 64), (4, 4, 8, 128, 128), (4, 4, 8, 256, 256)]
 
 
+@pytest.fixture(params=["e_table", "lds_slabs"])
+def wide_backward_form(request, nat):
+    """The two backward forms of the wide-rank chain: an E row per id + the reduce kernel (what a call of a few thousand ids
+    takes by the library's rule), and the dG2 reduction inside the chunk kernel (LDS slabs: taken from 8 ids per slab row on --
+    forced here with the diagnostic, so that the unit tests' small calls reach wide3_bwd_slab_kernel)."""
+    nat.set_wide_slab_min_ids(1 if request.param == "lds_slabs" else 1 << 40)
+    yield request.param
+    nat.set_wide_slab_min_ids(0)
+
+
 @pytest.mark.parametrize("shape", WIDE3_SHAPES)
 @pytest.mark.parametrize("seed", [0, 1])
-def test_random_tables_wide_rank_chain(nat, orc, shape, seed):
+def test_random_tables_wide_rank_chain(nat, orc, shape, seed, wide_backward_form):
     """Ranks 64 / 128 / 256 forced onto the grouped path (GEMM prefix, per-chunk forward, per-group backward, E reduce
-    by column slices, dG1 / dG0 GEMMs): random table factorisations incl. p0 q0 that is no multiple of 64, empty
-    groups, bags of several ids, repeated ids."""
+    by column slices or dG2 slabs in LDS, dG1 / dG0 GEMMs): random table factorisations incl. p0 q0 that is no multiple of 64,
+    empty groups, bags of several ids, repeated ids (p2 < 90 with thousands of ids: most chunks hold ids with EQUAL i2 -- the
+    slab kernel's tag rounds)."""
     q, R = list(shape[:3]), [1, shape[3], shape[4], 1]
     rng = np.random.default_rng(1234 * seed + sum(shape))
     p = [int(rng.integers(1, 30)), int(rng.integers(1, 12)), int(rng.integers(1, 90))]
@@ -519,7 +530,7 @@ def test_random_tables_wide_rank_chain(nat, orc, shape, seed):
 
 @pytest.mark.parametrize("shape", [(5, 5, 4, 64, 64), (4, 4, 8, 128, 128)])
 @pytest.mark.parametrize("kind", ["few_groups", "one_i1_full", "windows"])
-def test_wide_rank_chain_on_frontiers_that_leave_groups_empty(nat, orc, shape, kind):
+def test_wide_rank_chain_on_frontiers_that_leave_groups_empty(nat, orc, shape, kind, wide_backward_form):
     """The wide-rank GEMMs walk the non-empty groups only: frontiers that touch a few (i0, i1) groups, that fill every
     group of ONE i1 (that batch takes the plain form, the others the compacted one or nothing), and METIS-like windows of
     consecutive ids; p0 q0 is no multiple of 64 and some values of i1 hold no id at all."""
@@ -553,7 +564,7 @@ def test_wide_rank_chain_on_frontiers_that_leave_groups_empty(nat, orc, shape, k
 
 
 @pytest.mark.parametrize("shape", [(5, 5, 4, 128, 128), (4, 4, 8, 256, 256)])
-def test_wide_rank_gemms_keep_fp32_accuracy(nat, shape):
+def test_wide_rank_gemms_keep_fp32_accuracy(nat, shape, wide_backward_form):
     """The GEMMs of the wide-rank chain carry their fp32 products on the bf16 matrix pipe (operands split into three
     bf16 planes, eight of nine partial products, ttemb_wide3.inc).  Against a float64 restatement the forward and the
     dense gradients must be as close as fp32 arithmetic is -- a few 1e-7 of the largest value, where a two-plane split
@@ -595,7 +606,7 @@ def test_wide_rank_gemms_keep_fp32_accuracy(nat, shape):
 
 
 @pytest.mark.parametrize("name", [n for n in RANK_CASES if any(f"r{r}" in n for r in (64, 128, 256))])
-def test_rank_sweep_golden_on_the_wide_rank_chain(nat, name):
+def test_rank_sweep_golden_on_the_wide_rank_chain(nat, name, wide_backward_form):
     """The rank 64 / 128 / 256 points of the reference's rank sweep, forced onto the grouped wide-rank chain, against the
     vectors from the reference's tt_matrix_to_full + autograd."""
     g = load_golden(name)
@@ -890,6 +901,13 @@ def test_small_call_cut_into_pieces(nat, orc, q, r, rows, ids):
     out, grads = _run_ids_offsets(nat, p, q, R, cores, idx, offsets, d_out)
     np.testing.assert_allclose(out, want, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(want).max())))
     assert_grads_close(grads, want_g, rel=2e-4)
+    if r[0] >= 64:   # the wide chain's other backward form (dG2 slabs in LDS, no E table), piece by piece
+        nat.set_wide_slab_min_ids(1)
+        try:
+            _, grads = _run_ids_offsets(nat, p, q, R, cores, idx, offsets, d_out)
+        finally:
+            nat.set_wide_slab_min_ids(0)
+        assert_grads_close(grads, want_g, rel=2e-4)
     # fused SGD through the C ABI: summed gradient, one step
     ws = nat.Workspace()
     c = [dev(x) for x in cores]
