@@ -2764,7 +2764,10 @@ __global__ __launch_bounds__(256) void fast3_finalize_kernel(GroupPlan plan, int
     float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (o < n0) {
       const int i0 = o / row0, c = o - i0 * row0;   // (row0 is a multiple of 4: the four outputs share their i0)
-      constexpr int U6 = 6;
+#ifndef TTEMB_FIN_U
+#define TTEMB_FIN_U 6
+#endif
+      constexpr int U6 = TTEMB_FIN_U;
       for (int i1 = yr; i1 < p1; i1 += 32 * U6) {
         bool on[U6];
         float4 v[U6];

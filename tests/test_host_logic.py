@@ -112,6 +112,30 @@ def test_a_large_merged_first_pair_needs_a_batch_that_amortises_its_rebuild():
     assert merged(medium, 120000 // 16)      # one id per 16 rows: the merged per-bag view
 
 
+def test_kernel_family_reports_the_routes_of_the_grouped_path():
+    """Host-side rules only (ttemb_kernel_family launches nothing): which frontiers form their prefix products in the forward
+    chain kernel and their group products in the backward chunk kernel."""
+    G, PF, GP = nat.FAMILY_GROUPED, nat.FAMILY_PREFIX_IN_CHAIN, nat.FAMILY_GROUP_PRODUCTS_IN_CHAIN
+    fam = lambda p, q, r, n: nat.kernel_family(nat.make_shape(p, q, r), n, n, True)
+    # BASELINE configs[1]: 23 ids per group, dG2 fused into the chunk kernel: neither route
+    assert fam([125, 140, 140], [4, 5, 5], [16, 16], 409600) == G
+    # BASELINE configs[4]'s table, 819 200 ids (3 per group): both
+    assert fam([500, 560, 400], [8, 4, 4], [32, 32], 819200) == G | PF | GP
+    # ... 8.6 ids per group: still both (q0 = 8: up to 16); 20 per group: the backward's route only (rank 32: every density)
+    assert fam([500, 560, 400], [8, 4, 4], [32, 32], 2400000) == G | PF | GP
+    assert fam([100, 112, 400], [8, 4, 4], [32, 32], 224000) == G | GP
+    assert fam([500, 560, 400], [8, 4, 4], [32, 32], 5600000) == G            # past one piece: each piece is routed by itself
+    # the products table at rank 32 (unfused dG2): the backward's route at 23 ids per group, the forward's not (and never at rank 32
+    # for q0 = 4: that instance spilled)
+    assert fam([125, 140, 140], [4, 5, 5], [32, 32], 409600) == G | GP
+    assert fam([125, 140, 140], [4, 5, 5], [32, 32], 98000) == G | GP
+    # the reference's own papers100M invocation (run_script.sh:408-431): p2 = 600 is past the fused dG2 form at rank 16
+    assert fam([400, 500, 600], [4, 4, 8], [16, 16], 819200) == G | PF | GP
+    assert fam([100, 125, 600], [4, 4, 8], [16, 16], 250000) == G             # 20 ids per group at rank 16: neither
+    # wide ranks: their own family, no route flags
+    assert fam([125, 140, 140], [5, 5, 4], [256, 256], 409600) == nat.FAMILY_GROUPED_WIDE
+
+
 def test_status_and_spin_limit_are_host_side_calls():
     """ttemb_status() reads a pinned host word that ttemb_init() (or the first status call) creates: without a GPU there is
     no such memory, init says so once and status reports nothing; the spin limit is a process-wide diagnostic value."""
