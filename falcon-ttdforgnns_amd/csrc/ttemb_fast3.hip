@@ -3113,7 +3113,8 @@ static int wide_slab_wpb(const DevShape& s) {
   return wpb;
 }
 static int wide_slab_shares(const DevShape& s) {
-  const int tgroups = (s.R[2] / 16 * wide_slab_js(s)) / wide_slab_wpb(s);
+  const int wpb = wide_slab_wpb(s);   // (0: a slice of this p2 does not fit a CU's LDS -- wide_slab() is false then)
+  const int tgroups = (s.R[2] / 16 * wide_slab_js(s)) / (wpb > 0 ? wpb : 1);
   const int sh = chain_cus() / (tgroups > 0 ? tgroups : 1);
   return sh < 1 ? 1 : sh;
 }
@@ -3127,9 +3128,10 @@ static bool wide_slab(const DevShape& s, int64_t nnz) {
 #ifdef TTEMB_WIDE_E_TABLE   // (A/B: the round-4 form -- E table + reduce kernel)
   return false;
 #endif
+  if (!wide(s) || wide_slab_wpb(s) < 2) return false;
   const int64_t forced = g_wide_slab_min.load();
   const int64_t least = forced > 0 ? forced : (int64_t)8 * wide_slab_shares(s) * s.p[2];
-  return wide(s) && wide_slab_wpb(s) >= 2 && nnz >= least;
+  return nnz >= least;
 }
 static int64_t slab_count(const DevShape& s, int64_t nnz) {
   if (wide_slab(s, nnz)) return wide_slab_shares(s);

@@ -112,6 +112,22 @@ def test_a_large_merged_first_pair_needs_a_batch_that_amortises_its_rebuild():
     assert merged(medium, 120000 // 16)      # one id per 16 rows: the merged per-bag view
 
 
+def test_size_queries_over_every_shape_and_size():
+    """ttemb_workspace_bytes / ttemb_plan_bytes / ttemb_kernel_family are host arithmetic over (shape, nnz, B): swept over the
+    (q, rank) list x small and large p2 x empty to large calls (a p2 whose dG2 slice does not fit a CU's LDS once divided by zero
+    in the wide-rank sizing -- at rank 16, where that form is never taken)."""
+    qs = ([4, 5, 5], [4, 4, 8], [8, 4, 4], [5, 4, 5], [5, 5, 4], [4, 4, 4], [2, 2, 4], [16, 4, 2])
+    for q in qs:
+        for r in (4, 8, 16, 32, 64, 128, 256, 24):
+            for p in ([125, 140, 140], [400, 500, 600], [3, 2, 5000], [1, 1, 1], [7, 300, 900]):
+                shape = nat.make_shape(p, q, [r, r])
+                for nnz, B in ((0, 0), (0, 7), (1, 1), (5000, 1200), (409600, 409600), (819200, 819200), (6000000, 100)):
+                    for op in (nat.OP_FORWARD, nat.OP_BACKWARD):
+                        assert nat.workspace_bytes(shape, op, nnz, B) >= 0
+                    assert nat.plan_bytes(shape, nnz) >= 0
+                    assert nat.kernel_family(shape, nnz, B, True) >= 0 and nat.kernel_family(shape, nnz, B, False) >= 0
+
+
 def test_kernel_family_reports_the_routes_of_the_grouped_path():
     """Host-side rules only (ttemb_kernel_family launches nothing): which frontiers form their prefix products in the forward
     chain kernel and their group products in the backward chunk kernel."""
