@@ -2344,6 +2344,15 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
 #endif
 }
 
+#ifndef TTEMB_REDUCE_NB
+#define TTEMB_REDUCE_NB 1   // (2 / 3 / 4 buckets in flight per wavefront measured: 103-105 us at papers100M whichever -- see below)
+#endif
+#ifndef TTEMB_REDUCE_U
+#define TTEMB_REDUCE_U 6
+#endif
+constexpr int NWB = 16;                       // wavefronts per workgroup of the dG2 reduce
+constexpr int kReduceNB = TTEMB_REDUCE_NB;    // buckets a wavefront sums together
+constexpr int kReduceU = TTEMB_REDUCE_U;      // row loads in flight per bucket and lane group
 // B. dG2 reduce.  A workgroup takes kRowsB consecutive E rows, buckets them by i2 inside LDS
 // (a tile-local counting sort of row numbers), then each wave sums the rows of "its" i2 values
 // in registers and stores one (r2 q2)-float row per i2 into the tile's slab of partial sums
@@ -2432,51 +2441,74 @@ __global__ __launch_bounds__(NWB * 64) void fast3_dg2_reduce_kernel(GroupPlan pl
   for (int k = 0; k < kRowsMax / (NWB * 64); ++k)
     if (my_i2[k] != 0xffffffffu) rows[bstart[my_i2[k]] + my_rank[k]] = (unsigned short)(k * NWB * 64 + tid);
   __syncthreads();
-  // wave w sums the buckets i2 = w, w + NWB, ...
+  // wave w sums the buckets i2 = w, w + NWB, ... -- kReduceNB of them at a time.  A bucket of a tile is a handful of rows (8 at
+  // papers100M: 3 200 rows over 400 values of i2) and the kernel reads its 512-byte rows at 4.6 TB/s there; two, three or four
+  // buckets in flight per wavefront change nothing (105.2 / 104.4 / 104.9 against 103.2 us, one call, round 5): the rate is
+  // what gathered 512-byte rows get (the guide: 5.5 TB/s for 1 152-byte rows, 6.3 streaming), not a latency chain.
   const int sub = lane / F4, c4 = lane - sub * F4;
-  for (uint32_t i2 = wave; i2 < p2; i2 += NWB) {
-    const uint32_t b0 = bstart[i2], b1 = bstart[i2 + 1];
-    if (SHARED && b0 == b1) continue;   // nothing to add
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (uint32_t i2a = wave; i2a < p2; i2a += kReduceNB * NWB) {
+    uint32_t b0[kReduceNB], b1[kReduceNB];
+    float4 acc[kReduceNB];
+    uint32_t longest = 0;
+#pragma unroll
+    for (int n = 0; n < kReduceNB; ++n) {
+      const uint32_t i2 = i2a + n * NWB;
+      b0[n] = i2 < p2 ? bstart[i2] : 0u;
+      b1[n] = i2 < p2 ? bstart[i2 + 1] : 0u;
+      acc[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+      longest = b1[n] - b0[n] > longest ? b1[n] - b0[n] : longest;
+    }
     if (sub < SUB) {
       // several independent row loads in flight per lane group (the loop is latency-bound otherwise)
-      constexpr int U = 6;
-      for (uint32_t j = b0 + sub; j < b1; j += U * SUB) {
-        uint32_t rr[U];
-        float4 v[U];
+      constexpr int U = kReduceU;
+      for (uint32_t t = sub; t - sub < longest; t += U * SUB) {
+        uint32_t rr[kReduceNB][U];
+        float4 v[kReduceNB][U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) rr[u] = j + u * SUB < b1 ? rows[j + u * SUB] : 0xffffffffu;
+        for (int n = 0; n < kReduceNB; ++n)
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (rr[u] != 0xffffffffu)
-            v[u] = *reinterpret_cast<const float4*>(plan.etab + (size_t)(s0 + rr[u]) * stride + col0 + 4 * c4);
-        }
+          for (int u = 0; u < U; ++u) rr[n][u] = b0[n] + t + u * SUB < b1[n] ? rows[b0[n] + t + u * SUB] : 0xffffffffu;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
-        }
+        for (int n = 0; n < kReduceNB; ++n)
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            v[n][u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rr[n][u] != 0xffffffffu)
+              v[n][u] = *reinterpret_cast<const float4*>(plan.etab + (size_t)(s0 + rr[n][u]) * stride + col0 + 4 * c4);
+          }
+#pragma unroll
+        for (int n = 0; n < kReduceNB; ++n)
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            acc[n].x += v[n][u].x; acc[n].y += v[n][u].y; acc[n].z += v[n][u].z; acc[n].w += v[n][u].w;
+          }
       }
     }
 #pragma unroll
-    for (int k = 1; k < SUB; ++k) {
-      const int src = (lane + k * F4) & 63;
-      const float x = __shfl(acc.x, src, kWave), y = __shfl(acc.y, src, kWave);
-      const float z = __shfl(acc.z, src, kWave), w = __shfl(acc.w, src, kWave);
-      if (lane < F4) { acc.x += x; acc.y += y; acc.z += z; acc.w += w; }
-    }
-    if constexpr (SHARED) {
-      // element e of the row sits in lane e / 4, component e % 4: hand it to lane e so that an atomic instruction adds
-      // 64 consecutive floats (the shape the memory system takes at full rate; 16 lanes x 4 strided scalars did not)
-      for (int e0 = 0; e0 < ROW2; e0 += kWave) {
-        const int e = e0 + lane, src = (e >> 2) & 63;
-        const float x = __shfl(acc.x, src, kWave), y = __shfl(acc.y, src, kWave);
-        const float z = __shfl(acc.z, src, kWave), w = __shfl(acc.w, src, kWave);
-        const float v = (e & 3) == 0 ? x : ((e & 3) == 1 ? y : ((e & 3) == 2 ? z : w));
-        if (e < ROW2) atomicAdd(slab + (size_t)i2 * stride + e, v);
+    for (int n = 0; n < kReduceNB; ++n) {
+      const uint32_t i2 = i2a + n * NWB;
+      if (i2 >= p2) break;   // wave-uniform
+      if (SHARED && b0[n] == b1[n]) continue;   // nothing to add
+#pragma unroll
+      for (int k = 1; k < SUB; ++k) {
+        const int src = (lane + k * F4) & 63;
+        const float x = __shfl(acc[n].x, src, kWave), y = __shfl(acc[n].y, src, kWave);
+        const float z = __shfl(acc[n].z, src, kWave), w = __shfl(acc[n].w, src, kWave);
+        if (lane < F4) { acc[n].x += x; acc[n].y += y; acc[n].z += z; acc[n].w += w; }
       }
-    } else {
-      if (lane < F4) *reinterpret_cast<float4*>(slab + (size_t)i2 * stride + 4 * lane) = acc;
+      if constexpr (SHARED) {
+        // element e of the row sits in lane e / 4, component e % 4: hand it to lane e so that an atomic instruction adds
+        // 64 consecutive floats (the shape the memory system takes at full rate; 16 lanes x 4 strided scalars did not)
+        for (int e0 = 0; e0 < ROW2; e0 += kWave) {
+          const int e = e0 + lane, src = (e >> 2) & 63;
+          const float x = __shfl(acc[n].x, src, kWave), y = __shfl(acc[n].y, src, kWave);
+          const float z = __shfl(acc[n].z, src, kWave), w = __shfl(acc[n].w, src, kWave);
+          const float v = (e & 3) == 0 ? x : ((e & 3) == 1 ? y : ((e & 3) == 2 ? z : w));
+          if (e < ROW2) atomicAdd(slab + (size_t)i2 * stride + e, v);
+        }
+      } else {
+        if (lane < F4) *reinterpret_cast<float4*>(slab + (size_t)i2 * stride + 4 * lane) = acc[n];
+      }
     }
   }
 }
@@ -3043,7 +3075,6 @@ static int reduce_rows(int64_t nnz) {
   int64_t r = ((nnz + 255) / 256 + 63) / 64 * 64;
   return (int)(r < 512 ? 512 : (r > kRowsB ? kRowsB : r));
 }
-constexpr int NWB = 16;
 static int64_t reduce_tiles(int64_t nnz) { const int r = reduce_rows(nnz); return (nnz + r - 1) / r; }
 // slabs of more than 256 KB are not replicated per tile: one shared slab, float atomics (see the reduce kernel)
 static bool shared_slab(const DevShape& s) { return (int64_t)s.p[2] * s.row_len[2] * 4 > (256 << 10); }
