@@ -1227,10 +1227,18 @@ __global__ __launch_bounds__(kChainWaves * 64, 2) void fast3_forward_pfuse_kerne
 
   float4 pre_g[NLG];
   float pre_a[C::KS1];
+#ifdef TTEMB_PFABL   // (ablation: the row traffic of a chunk -- G2 row loads, staging, row reads and stores, i2 / row words -- only for
+                     //  every TTEMB_PFABL-th chunk: what serving 16 ids per trip instead of one group's could save; wrong rows, timing only)
+  bool pf_io = true;
+#else
+  constexpr bool pf_io = true;
+#endif
   auto request = [&](uint32_t row, const Grp& gp) {   // row: byte offset of the lane's G2 row
+    if (pf_io) {
 #pragma unroll
     for (int k = 0; k < NLG; ++k)
       pre_g[k] = k + 1 < NLG ? buf_load4(r_g2, row + rowpiece + 64u * k) : buf_load4(r_g2, row + g_last);
+    }
     // the batch's rows of G0 when the chunk opens one (else the loads fall off the buffer: the instruction stream is fixed)
     const uint32_t i0a = gp.i0b + a_grp;
     const uint32_t base = (gp.fresh && a_grp < (uint32_t)GM && i0a < p0) ? i0a * (uint32_t)(C::ROW0 * 4) + a_off : kOobBase;
@@ -1246,6 +1254,7 @@ __global__ __launch_bounds__(kChainWaves * 64, 2) void fast3_forward_pfuse_kerne
     }
   };
   auto stage_rows = [&]() {   // G2 rows: registers -> LDS
+    if (!pf_io) return;
 #pragma unroll
     for (int k = 0; k < NLG; ++k) {
       const int idx = j_l + 4 * k;
@@ -1318,6 +1327,9 @@ __global__ __launch_bounds__(kChainWaves * 64, 2) void fast3_forward_pfuse_kerne
   for (uint32_t c = c0;; ++c) {
     const uint32_t len = d_cur.z & 0xffu;
     const uint32_t val = val_cur;
+#ifdef TTEMB_PFABL
+    pf_io = (c - c0) % TTEMB_PFABL == 0;
+#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1384,10 +1396,12 @@ __global__ __launch_bounds__(kChainWaves * 64, 2) void fast3_forward_pfuse_kerne
     TTEMB_PRIO(2);
     // ---- this lane's pieces of its output row: LDS -> registers ----
     float4 x[NLO];
+    if (pf_io) {
 #pragma unroll
     for (int k = 0; k < NLO; ++k) {
       const int idx = 4 * k + j_l < D4 ? 4 * k + j_l : D4 - 1;
       x[k] = *reinterpret_cast<const float4*>(obuf + b_l * C::LDO + 4 * idx);
+    }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();  // the row buffer has been read: the next chunk's G2 rows may land in it
@@ -1401,7 +1415,7 @@ __global__ __launch_bounds__(kChainWaves * 64, 2) void fast3_forward_pfuse_kerne
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- 16-byte global stores, four lanes per row ----
-    {
+    if (pf_io) {
       const bool row_ok = (uint32_t)b_l < len;
       const bool multi = (val & kMultiBit) != 0u;
       const uint32_t row_off = __umul24(val & 0x00ffffffu, (uint32_t)(C::D * 4)) + rowpiece;   // rows < 2^24 (fast3_fits)
@@ -1434,8 +1448,10 @@ __global__ __launch_bounds__(kChainWaves * 64, 2) void fast3_forward_pfuse_kerne
     if (c + 1 >= c1) break;
     // ---- loads of the chunk after next, i2 of the one after that, output rows of the next ----
     request(row_nn, g_nn);
+    if (pf_io) {
     i2_nn = fetch_i2(d_n3);
     val_cur = fetch_val(d_nxt);
+    }
     d_cur = d_nxt;
     g_cur = g_nxt;
     d_nxt = d_nn;
