@@ -115,6 +115,7 @@ def matrix_leg(nat, name, n_ids, dist_kind, iters=50):
     ws = nat.Workspace()
     plan = nat.new_plan(shape, n_ids, idx.device)
     fwd = lambda: nat.forward(shape, cores, idx, None, offs, n_ids, None, n_ids, out, ws, plan)
+    fwd_inference = lambda: nat.forward(shape, cores, idx, None, offs, n_ids, None, n_ids, out, ws, None)   # no plan kept
     bwd_dense = lambda: nat.backward_dense(shape, cores, idx, None, n_ids, None, n_ids, d_out, grads, ws, plan, offs)
     bwd_sgd = lambda: nat.backward_sgd(shape, cores, idx, None, n_ids, None, n_ids, d_out, 1e-12, ws, plan, offs)
 
@@ -154,6 +155,7 @@ def matrix_leg(nat, name, n_ids, dist_kind, iters=50):
     r = {"ids": n_ids, "ids_kind": dist_kind, "fwd_us": round(med(fwd), 1), "bwd_dense_us": round(med(bwd_dense), 1),
          "bwd_fused_sgd_us": round(med(bwd_sgd), 1), "fwd_bwd_sgd_us": round(med(both), 1)}
     r["fwd_in_step_us"], r["bwd_in_step_us"] = (round(x, 1) for x in in_step())
+    r["fwd_inference_us"] = round(med(fwd_inference), 1)   # (a forward nobody's backward follows: what the module runs under no_grad)
     r["fwd_lookups_per_s"] = round(n_ids / (r["fwd_us"] * 1e-6), 1)
     r["fwd_bwd_lookups_per_s"] = round(n_ids / (r["fwd_bwd_sgd_us"] * 1e-6), 1)
     return r

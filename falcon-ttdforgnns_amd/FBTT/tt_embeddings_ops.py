@@ -624,6 +624,14 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         dev = indices.device
         live = self.use_cache and not self.warmup
         if not live:  # rows are derived from `offsets` inside the native calls: no separate launch, no tensor
+            if self.num_tables == 1 and self._use_lean and not torch.is_grad_enabled():
+                # inference (the drivers' evaluation passes run under no_grad): no autograd node and no plan kept -- a forward
+                # that forms its prefix products in the chain kernel then stores none of them (1.08 GB at papers100M, 819 200 ids)
+                if self._before_weights is not None:
+                    self._before_weights()   # a data-parallel update of the cores is pending: finish it first
+                out = torch.empty((B, self.embedding_dim), dtype=torch.float32, device=dev)
+                self._lean.forward(self._cores(), indices, offsets, nnz, B, out, keep_plan=False)
+                return out
             if self.sparse and self.num_tables == 1 and self._use_lean:
                 return _SparseLookup.apply(self._cores()[0], self, indices, offsets, B)
             if not self.sparse and self.num_tables == 1 and self._use_lean and self._dense_grad_out is not None:

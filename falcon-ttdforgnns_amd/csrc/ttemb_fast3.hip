@@ -226,6 +226,9 @@ struct GroupPlan {           // device pointers into the caller's plan buffer / 
                              //     that runs beside the data-parallel step's all-reduce) instead of taking its workgroup indices
   uint32_t* fault_host;      // pinned host word (device address) a bounded wait that ran out reports to, or null
   uint32_t spin_limit;       // tries of the bounded waits of the grouping pass (ttemb_set_spin_limit; 0 = none: every wait expires)
+  uint32_t keep_p;           // the caller keeps the plan (it passed a plan buffer): the forward that forms the prefix products in its
+                             //     chain kernel stores them for the backward.  0 = the plan lives in the workspace and dies with the
+                             //     call -- a forward nobody's backward reads (inference, a piece of a larger call): no stores
 };
 
 // ---------------------------------------------------------------------------------
@@ -1285,7 +1288,7 @@ __global__ __launch_bounds__(kChainWaves * 64, 2) void fast3_forward_pfuse_kerne
 #pragma unroll
       for (int s = 0; s < C::KS1; ++s) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bvp[s][nt], pre_a[s], acc[nt], 0, 0, 0);
     }
-    const rsrc_t r_p = make_rsrc(plan.ptab + (size_t)gp.first_group * PF, (uint32_t)(GM * PF * 4));
+    const rsrc_t r_p = make_rsrc(plan.ptab + (size_t)gp.first_group * PF, plan.keep_p ? (uint32_t)(GM * PF * 4) : 0u);   // (0: every store falls off)
     const int gi = lo / Q0, a = lo % Q0;
     const bool on = gi < GM && gp.i0b + (uint32_t)gi < p0;   // (q0 = 5: column 15 is no group's; a batch at the end of an i1 may be short)
     float* slot = pbuf + (gi < GM ? gi : 0) * PC::SLOT_FLOATS;
@@ -3360,6 +3363,11 @@ static int prepare(const DevShape& s, const CorePtrs& cores, bool bwd, const int
 #endif
   static_assert(kHeaderPoisonOffset + 16 <= kFast3HeaderBytes, "the header holds the epoch words, every bank of range counters, the poison word and the ticket");
   const bool external = plan_buf != nullptr && plan_bytes >= fast3_plan_bytes(s, nnz);
+#ifdef TTEMB_KEEP_P_ALWAYS   // (A/B: the P table written by every forward)
+  plan->keep_p = 1u;
+#else
+  plan->keep_p = external ? 1u : 0u;
+#endif
   if (plan_state != 0 && !external) return fail(TTEMB_E_BADARG, "this call needs a plan buffer of ttemb_plan_bytes() bytes");
   const bool reuse = plan_state >= 2;
   const int64_t need = carve_workspace(s, nnz, bwd, !external, !reuse, reinterpret_cast<char*>(ws), plan);

@@ -529,16 +529,17 @@ class LeanCalls:
             key = k
         return key, arr
 
-    def forward(self, cores, indices, offsets, nnz: int, B: int, out):
+    def forward(self, cores, indices, offsets, nnz: int, B: int, out, keep_plan: bool = True):
+        """``keep_plan=False``: a forward whose backward never comes (inference): the plan lives and dies in the workspace."""
         fwd_ws, _, plan_n = self._entry(nnz, B)
         self.core_key, self.core_arr = self._ptrs(cores, self.core_key, self.core_arr)
         dev = out.device
         w = self.ws.get(fwd_ws, dev)
-        plan = torch.empty(plan_n, dtype=torch.uint8, device=dev) if plan_n > 0 else None
+        plan = torch.empty(plan_n, dtype=torch.uint8, device=dev) if plan_n > 0 and keep_plan else None
         with _on_device(dev):
             rc = LIB.ttemb_forward(self.shape_ref, self.core_arr, indices.data_ptr() if nnz else None, None, offsets.data_ptr(),
                                    nnz, None, B, out.data_ptr() if B else None, w.data_ptr(), w.numel(),
-                                   plan.data_ptr() if plan is not None else None, plan_n, _stream(out))
+                                   plan.data_ptr() if plan is not None else None, plan_n if plan is not None else 0, _stream(out))
         if rc:
             _check(rc)
         return plan

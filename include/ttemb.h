@@ -202,7 +202,9 @@ int ttemb_profile_read(int32_t which, float* ms_host);
  * length is not 1 are zero-filled before the lookups (a bag of one id has exactly one writer,
  * this call or ttemb_cache_forward(offsets)); with offsets == NULL the whole output is
  * zero-filled first and single-id detection falls back to neighbouring rowidx values.
- * `plan` (nullable, ttemb_plan_bytes() bytes) receives the id grouping for the backward.
+ * `plan` (nullable, ttemb_plan_bytes() bytes) receives the id grouping (and the prefix products) for the backward.
+ * plan == NULL is the INFERENCE form: the grouping lives and dies in the workspace, and a forward that forms its prefix
+ * products inside the chain kernel (TTEMB_FAMILY_PREFIX_IN_CHAIN) stores none of them -- same rows, less HBM traffic.
  * There is no batch_count chunking: intermediates never leave the chip.
  * ------------------------------------------------------------------------------- */
 int ttemb_forward(const ttemb_shape_t* shape, const float* const* cores,

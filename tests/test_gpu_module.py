@@ -54,6 +54,51 @@ def test_forward_equals_embedding_bag_over_full_weight(ops, p, q, r):
     torch.testing.assert_close(out, want, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("sparse", [True, False])
+@pytest.mark.parametrize("p,q,r,n_ids,prefix_in_chain", [
+    ([50, 56, 40], [8, 4, 4], [32, 32], 9000, True),      # 3 ids per group: the forward chain kernel forms the prefix products
+    ([40, 50, 60], [4, 4, 8], [16, 16], 6000, True),
+    ([125, 140, 140], [4, 5, 5], [16, 16], 200000, False), # 11 ids per group: prefix launch, the chain kernel reads P whoever keeps the plan
+    ([7, 9, 11], [4, 5, 5], [16, 16], 300, False),         # per-bag kernels: no plan at all
+])
+def test_forward_under_no_grad_equals_the_training_forward(ops, orc, p, q, r, n_ids, prefix_in_chain, sparse):
+    """Inference (`torch.no_grad()`: the drivers' evaluation passes) takes no autograd node and keeps no plan -- a forward that
+    forms its prefix products in the chain kernel stores none of them then.  Same rows, bit for bit, as the training forward;
+    against the oracle; and a training step after an inference forward still trains (fused SGD against the oracle)."""
+    import ttemb_native as nat
+    torch.manual_seed(4)
+    rng = np.random.default_rng(4)
+    n, D, lr = int(np.prod(p)), int(np.prod(q)), 0.05
+    emb = ops.TTEmbeddingBag(n, D, r, p, q, sparse=sparse, use_cache=False, weight_dist="normal", learning_rate=lr)
+    for c in emb.tt_cores:
+        c.data.mul_(2.0)
+    fam = nat.kernel_family(nat.make_shape(p, q, r), n_ids, n_ids, True)
+    assert bool(fam & nat.FAMILY_PREFIX_IN_CHAIN) == prefix_in_chain
+    idx = rng.choice(n, size=n_ids, replace=False).astype(np.int64)
+    ids, offs = torch.tensor(idx).cuda(), torch.arange(n_ids + 1).cuda()
+    cores = [c.detach()[0].cpu().numpy().copy() for c in emb.tt_cores]
+    R = [1] + r + [1]
+    with torch.no_grad():
+        out_inf = emb(ids, offs)
+    assert not out_inf.requires_grad and out_inf.grad_fn is None
+    out = emb(ids, offs)
+    assert out.requires_grad
+    assert torch.equal(out_inf, out.detach())
+    want = orc.tt_forward(idx, np.arange(n_ids + 1), cores, p, q, R)
+    np.testing.assert_allclose(out_inf.cpu().numpy(), want, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(want).max())))
+    d = torch.randn(n_ids, D, device="cuda")
+    with torch.no_grad():   # an inference forward BETWEEN the training forward and its backward: the kept plan is the training forward's
+        emb(ids[: n_ids // 2].contiguous(), offs[: n_ids // 2 + 1].contiguous())
+    out.backward(d)
+    grads = orc.tt_dense_backward(idx, np.arange(n_ids + 1), d.cpu().numpy(), cores, p, q, R)
+    for t in range(3):
+        if sparse:
+            got, ref = emb.tt_cores[t].detach()[0].cpu().numpy(), cores[t] - np.float32(lr) * grads[t]
+        else:
+            got, ref = emb.tt_cores[t].grad[0].cpu().numpy(), grads[t]
+        np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-4 * max(1.0, float(np.abs(ref).max())))
+
+
 @pytest.mark.parametrize("p,q,r", SHAPES)
 def test_backward_dense_equals_autograd_through_full_weight(ops, p, q, r):
     torch.manual_seed(2)
