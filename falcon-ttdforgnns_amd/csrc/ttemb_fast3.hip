@@ -113,6 +113,20 @@ __device__ __forceinline__ void buf_store4(rsrc_t r, uint32_t voff, const float4
   v.w = __float_as_uint(x.w);
   __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, 0, 0);
 }
+// (experiment knob TTEMB_NT: bit mask of the stores issued non-temporally -- 1 the prefix-in-chain forward's P table, 2 its output
+//  rows, 4 the plain forward's output rows, 8 the backward chunk kernel's E rows / dG0 parts)
+#ifndef TTEMB_NT
+#define TTEMB_NT 0
+#endif
+template <bool NT>
+__device__ __forceinline__ void buf_store4_p(rsrc_t r, uint32_t voff, const float4& x) {
+  u32x4 v;
+  v.x = __float_as_uint(x.x);
+  v.y = __float_as_uint(x.y);
+  v.z = __float_as_uint(x.z);
+  v.w = __float_as_uint(x.w);
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, 0, NT ? 2 : 0);   // (aux 2 = nt on gfx94x / gfx950)
+}
 __device__ __forceinline__ void buf_store1(rsrc_t r, uint32_t voff, float x) {
   __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), r, (int)voff, 0, 0);
 }
@@ -1089,7 +1103,7 @@ __global__ __launch_bounds__(kChainWaves * 64) void fast3_forward_kernel(const f
       const uint32_t row_off = __umul24(val & 0x00ffffffu, (uint32_t)(C::D * 4)) + rowpiece;   // rows < 2^24 (fast3_fits)
       const uint32_t off = row_ok && !multi ? row_off : kOobBase;   // bags with several ids accumulate below
 #pragma unroll
-      for (int k = 0; k < NLO; ++k) buf_store4(r_out, (k + 1 < NLO || o_has_last) ? off + 64u * k : kOobBase, x[k]);
+      for (int k = 0; k < NLO; ++k) buf_store4_p<(TTEMB_NT & 4) != 0>(r_out, (k + 1 < NLO || o_has_last) ? off + 64u * k : kOobBase, x[k]);
       if (__ballot(row_ok && multi) != 0ull) {  // rare: float atomics (buffer atomics fault on an out-of-range offset
         if (row_ok && multi) {                  // instead of vanishing, so they sit in a branch)
           float* dst = out + (size_t)(val & 0x00ffffffu) * (uint32_t)C::D;
@@ -1298,7 +1312,7 @@ __global__ __launch_bounds__(kChainWaves * 64, 2) void fast3_forward_pfuse_kerne
       const bool col = C::N1 % 16 == 0 || n < C::N1;
       const int m = a * Q1 + n / R2, c2 = n % R2;
       if (on && col) *reinterpret_cast<f32x4*>(slot + m * R2 + (c2 ^ PC::swz(m))) = acc[nt];
-      buf_store4(r_p, (on && col) ? (uint32_t)((gi * PF + m * R2 + c2) * 4) : kOobBase, make_float4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]));
+      buf_store4_p<(TTEMB_NT & 1) != 0>(r_p, (on && col) ? (uint32_t)((gi * PF + m * R2 + c2) * 4) : kOobBase, make_float4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]));
     }
   };
   auto fetch_i2 = [&](const uint4& d) {   // lanes past the chunk's length read 0: G2 row 0 stands in, nothing of theirs is stored
@@ -1424,7 +1438,7 @@ __global__ __launch_bounds__(kChainWaves * 64, 2) void fast3_forward_pfuse_kerne
       const uint32_t row_off = __umul24(val & 0x00ffffffu, (uint32_t)(C::D * 4)) + rowpiece;   // rows < 2^24 (fast3_fits)
       const uint32_t off = row_ok && !multi ? row_off : kOobBase;   // bags with several ids accumulate below
 #pragma unroll
-      for (int k = 0; k < NLO; ++k) buf_store4(r_out, (k + 1 < NLO || o_has_last) ? off + 64u * k : kOobBase, x[k]);
+      for (int k = 0; k < NLO; ++k) buf_store4_p<(TTEMB_NT & 2) != 0>(r_out, (k + 1 < NLO || o_has_last) ? off + 64u * k : kOobBase, x[k]);
       if (__ballot(row_ok && multi) != 0ull) {  // rare: float atomics
         if (row_ok && multi) {
           float* dst = out + (size_t)(val & 0x00ffffffu) * (uint32_t)C::D;
@@ -2193,7 +2207,7 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
         if ((uint32_t)(16 * nt) < len * Q2) {
 #pragma unroll
           for (int t = 0; t < C::RT2; ++t)
-            buf_store4(r_e, eoff[t] + (uint32_t)(16 * nt * R2 * 4), make_float4(e[t][nt][0], e[t][nt][1], e[t][nt][2], e[t][nt][3]));
+            buf_store4_p<(TTEMB_NT & 8) != 0>(r_e, eoff[t] + (uint32_t)(16 * nt * R2 * 4), make_float4(e[t][nt][0], e[t][nt][1], e[t][nt][2], e[t][nt][3]));
         }
       }
     }
