@@ -194,7 +194,20 @@ def papers_roofline_leg(nat, n_ids=819200, iters=20):
     nat.profile_enable(False)
     torch.cuda.synchronize()
     m = {k: float(np.median(v)) for k, v in t.items()}   # ms
-    fwd_ms, bwd_ms = m["group"] + m["fwd"], m["bwd"]
+    # the two calls' own times: forward and backward alternating as above with the library's brackets OFF, one HIP event
+    # between the calls (the brackets put six event packets into every backward: ~10-25 us on a ~1 ms chain; `kernel_ms` keeps them)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+           for _ in range(iters)]
+    for a, b, c in evs:
+        a.record()
+        nat.forward(shape, cores, idx, None, offs, n_ids, None, n_ids, out, ws, plan)
+        b.record()
+        nat.backward_sgd(shape, cores, idx, None, n_ids, None, n_ids, d_out, 1e-12, ws, plan, offs)
+        c.record()
+    torch.cuda.synchronize()
+    fwd_ms = float(np.median([a.elapsed_time(b) for a, b, c in evs]))
+    bwd_ms = float(np.median([b.elapsed_time(c) for a, b, c in evs]))
+    bracket_fwd_ms, bracket_bwd_ms = m["group"] + m["fwd"], m["bwd"]
     nominal_f, nominal_b = n_ids * (f0 + f1), n_ids * (3 * f0 + 2 * f1)
     executed_f = groups * f0 + n_ids * f1                 # P once per group
     executed_b = groups * 2 * f0 + n_ids * 2 * f1         # dG0 / dG1 products per group, dP / E per id (P is the forward's)
@@ -205,6 +218,9 @@ def papers_roofline_leg(nat, n_ids=819200, iters=20):
          "groups_touched": groups, "ids_per_group": round(n_ids / groups, 2),
          "kernel_ms": {k: round(v, 4) for k, v in m.items()},
          "fwd_ms_incl_grouping": round(fwd_ms, 4), "bwd_ms": round(bwd_ms, 4),
+         "timing": "fwd / bwd: HIP events around the two C-ABI calls alternating as in a training step, library brackets off "
+                   "(median of %d); kernel_ms / *_from_brackets: the library's own brackets (ttemb_profile_read), which add event packets" % iters,
+         "fwd_ms_from_brackets": round(bracket_fwd_ms, 4), "bwd_ms_from_brackets": round(bracket_bwd_ms, 4),
          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
          "fwd_nominal_tflops": round(tfl(nominal_f, fwd_ms), 2), "fwd_executed_tflops": round(tfl(executed_f, fwd_ms), 2),
          "bwd_nominal_tflops": round(tfl(nominal_b, bwd_ms), 2), "bwd_executed_tflops": round(tfl(executed_b, bwd_ms), 2),
