@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--path", default="auto", choices=["auto", "generic", "fast3", "per_bag"])
     ap.add_argument("--what", default="both", choices=["both", "fwd", "bwd"])
     ap.add_argument("--no-rowidx", action="store_true", help="ids + offsets only, as the module passes them (the per-bag kernels need this form)")
+    ap.add_argument("--plan", action="store_true", help="the forward keeps a plan and the backward runs on it, as the module's training step does (default: neither call gets one -- the forward is then the inference form, the backward groups the ids itself)")
     ap.add_argument("--split", action="store_true", help="two-phase forward (ttemb_forward_group, then ttemb_forward_lookup): the grouping steps and the prefix products as launches of their own")
     a = ap.parse_args()
     p, q, R, n_emb = CFG[a.cfg]
@@ -84,6 +85,9 @@ def main():
                     plan = nat.new_plan(shape, N, idx.device)
                     nat.forward(shape, cores, idx, rowidx, offs, N, None, N, out, ws, plan, phase=1)
                     nat.forward(shape, cores, idx, rowidx, offs, N, None, N, out, ws, plan, phase=2)
+                elif a.plan:
+                    plan = nat.new_plan(shape, N, idx.device)
+                    nat.forward(shape, cores, idx, rowidx, offs, N, None, N, out, ws, plan)
                 else:
                     nat.forward(shape, cores, idx, rowidx, offs, N, None, N, out, ws)
                 if i >= 3:
@@ -93,7 +97,7 @@ def main():
                     except RuntimeError:   # no grouping pass on this path (per-bag / scalar kernels)
                         g.append(0.0)
             if a.what in ("both", "bwd"):
-                nat.backward_dense(shape, cores, idx, rowidx, N, None, N, d_out, grads, ws, None, offs)
+                nat.backward_dense(shape, cores, idx, rowidx, N, None, N, d_out, grads, ws, plan if (a.plan and a.what == "both") else None, offs)
                 if i >= 3:
                     b.append(nat.profile_read(1))
                     c.append(nat.profile_read(2))

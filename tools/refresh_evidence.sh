@@ -12,8 +12,9 @@ cp $R/profiles/r05_traffic.json $O/
 bash $R/tools/mfma_util.sh profiles/r05_mfma_util.json > $O/mfma.log 2>&1 || exit 1
 cp $R/profiles/r05_mfma_util.json $O/
 # the papers100M shape on one GPU (BASELINE configs[4]'s table): the same two counter passes + a kernel-stats pass
-TRAFFIC_KBENCH_ARGS="--cfg papers --n 819200 --no-rowidx" bash $R/tools/traffic.sh profiles/r05_papers_traffic.json > $O/papers_traffic.log 2>&1 || exit 1
-TRAFFIC_KBENCH_ARGS="--cfg papers --n 819200 --no-rowidx" bash $R/tools/mfma_util.sh profiles/r05_papers_mfma_util.json > $O/papers_mfma.log 2>&1 || exit 1
+# (--plan: the forward keeps its plan -- the training form, P table stored -- and the backward runs on it, as the module and bench.py do)
+TRAFFIC_KBENCH_ARGS="--cfg papers --n 819200 --no-rowidx --plan" bash $R/tools/traffic.sh profiles/r05_papers_traffic.json > $O/papers_traffic.log 2>&1 || exit 1
+TRAFFIC_KBENCH_ARGS="--cfg papers --n 819200 --no-rowidx --plan" bash $R/tools/mfma_util.sh profiles/r05_papers_mfma_util.json > $O/papers_mfma.log 2>&1 || exit 1
 cp $R/profiles/r05_papers_traffic.json $R/profiles/r05_papers_mfma_util.json $O/
 cp $(find $R/gpurun_out/pmc_mfma_t -name "*kernel_stats.csv" | head -1) $O/papers_kernel_stats.csv
 cd /tmp && export TMPDIR=/tmp
