@@ -1541,12 +1541,19 @@ constexpr bool fuse_shape(int r2, int row2) { return r2 <= 16 && row2 % 4 == 0 &
 // another batch.  G1[i1] as the B operand of the dG0 product stays in registers, K-permuted so that it is loaded with
 // 16-byte pieces (lane group hi owns n = (N1/4) hi + s); the batch's G0 rows are requested at the top of the iteration
 // that multiplies the batch's last chunk (an instruction of every iteration: off the buffer when no batch ends).
+#ifndef TTEMB_G0T
+#define TTEMB_G0T 1   // (0: parts in group order, the round-5 first form -- finalize 78.4 against 74.8 us at papers100M, chunk kernel equal)
+#endif
+constexpr bool kPartsByI0 = TTEMB_G0T != 0;
 struct GroupFuse {
   const float* G0;
   const float* G1;
   float* dg1;          // [p1][ROW1], zero-filled by the host: dG1 (added with float atomics, one flush per (wavefront, i1))
   uint32_t p0;
   uint64_t p0_magic;   // g / p0 = (g * magic) >> 40
+  uint32_t p1;
+  uint32_t parts_by_i0;   // the dG0 part of group (i1, i0) is stored at row i0 * p1 + i1 (the p1 parts the finalize kernel sums for one
+                          // i0 are then consecutive kilobytes) instead of i1 * p0 + i0
 };
 
 template <int Q0, int Q1, int Q2, int R1, int R2, bool FUSE, bool GF = false>
@@ -2138,7 +2145,7 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
           for (int t = 0; t < C::RT1; ++t) gf_out[t] = (g0p[0][t] + g0p[1][t]) + (g0p[2][t] + g0p[3][t]);
           gf_store = true;
           gf_store_mask = gf_mask;
-          gf_store_group = b_cur.first_group;
+          gf_store_group = gf.parts_by_i0 ? b_cur.i0b * gf.p1 + b_cur.i1 : b_cur.first_group;
           gf_batch = 0xffffffffu;
           gf_mask = 0u;
         }
@@ -2215,13 +2222,14 @@ __global__ __launch_bounds__((FUSE ? kFuseWaves : kChainWaves) * 64, FUSE ? 8 / 
     if constexpr (GF) {
       // (the group products ran before the next chunk's rows were staged; their dG0 parts leave now, behind the E rows)
       if (gf_store) {
+        const uint32_t gf_store_step = gf.parts_by_i0 ? gf.p1 : 1u;   // rows between the parts of two neighbouring groups of the batch
 #pragma unroll
         for (int t = 0; t < C::RT1; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int rho = 4 * hi + r;
             const bool on = rho / Q0 < GM && ((gf_store_mask >> (rho / Q0)) & 1u) != 0u && 16 * t + lo < R1;
-            buf_store1(r_part, on ? (gf_store_group + (uint32_t)(rho / Q0)) * (uint32_t)(C::ROW0 * 4) + 4u * ((rho % Q0) * R1 + 16 * t + lo) : kOob, gf_out[t][r]);
+            buf_store1(r_part, on ? (gf_store_group + (uint32_t)(rho / Q0) * gf_store_step) * (uint32_t)(C::ROW0 * 4) + 4u * ((rho % Q0) * R1 + 16 * t + lo) : kOob, gf_out[t][r]);
           }
       }
     } else
@@ -2844,7 +2852,8 @@ __global__ __launch_bounds__(256) void fast3_finalize_kernel(GroupPlan plan, int
 #pragma unroll
         for (int u = 0; u < U6; ++u) {
           const int g = (i1 + 32 * u) * p0 + i0;
-          v[u] = on[u] ? *reinterpret_cast<const float4*>(plan.g0part + (size_t)g * row0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+          const size_t row = (all_parts & 2) ? (size_t)i0 * p1 + (i1 + 32 * u) : (size_t)g;   // (2: the parts lie by i0 -- GroupFuse::parts_by_i0)
+          v[u] = on[u] ? *reinterpret_cast<const float4*>(plan.g0part + row * row0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int u = 0; u < U6; ++u) {
@@ -2927,7 +2936,8 @@ __global__ __launch_bounds__(256) void fast3_finalize_kernel(GroupPlan plan, int
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int g = (i1 + 8 * u) * p0 + i0;
-        v[u] = on[u] ? plan.g0part[(size_t)g * row0 + c] : 0.f;
+        const size_t row = (all_parts & 2) ? (size_t)i0 * p1 + (i1 + 8 * u) : (size_t)g;
+        v[u] = on[u] ? plan.g0part[row * row0 + c] : 0.f;
       }
       s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
     }
@@ -3857,6 +3867,8 @@ static int run_backward(const DevShape& s, const CorePtrs& cores, const GroupPla
       gf.dg1 = plan.g1part;
       gf.p0 = (uint32_t)s.p[0];
       gf.p0_magic = (uint64_t(1) << 40) / (uint64_t)s.p[0] + 1ull;
+      gf.p1 = (uint32_t)s.p[1];
+      gf.parts_by_i0 = kPartsByI0 ? 1u : 0u;
       profile_begin(2, st);
       hipLaunchKernelGGL((fast3_bwd_chunk_kernel<Q0, Q1, Q2, R1, R2, false, true>), dim3(grid), dim3(kChainWaves * 64), lds, st, cores.c[2],
                          (uint32_t)G, (uint32_t)s.p[2], (uint32_t)nnz, d_output, (uint32_t)(B * s.D * 4), plan, gf);
@@ -3913,7 +3925,7 @@ static int run_backward(const DevShape& s, const CorePtrs& cores, const GroupPla
     const int wgs = (g2_floats + 31) / 32 + (s.p[0] * C::ROW0 + 31) / 32 + (g1_floats + 1023) / 1024;   // dG2 | dG0 | dG1
     profile_begin(9, st);
     hipLaunchKernelGGL(fast3_finalize_kernel, dim3((unsigned)wgs), dim3(256), 0, st, plan, (int)slab_count(s, nnz), slices,
-                       s.p[0], s.p[1], g2_floats, (int)C::ROW0, g1_floats, Q2, R2, d_cores.c[0], d_cores.c[1], d_cores.c[2], upd, gfuse ? 1 : 0);
+                       s.p[0], s.p[1], g2_floats, (int)C::ROW0, g1_floats, Q2, R2, d_cores.c[0], d_cores.c[1], d_cores.c[2], upd, gfuse ? (kPartsByI0 ? 3 : 1) : 0);
     profile_end(9, st);
   }
   profile_end(1, st);
