@@ -676,7 +676,8 @@ def main():
                                     fan_out="5,10,15", hidden=256, classes=47, emb="tt", epochs=2, max_steps=0)
             epoch = sage_epoch.run(ea, quiet=True)
             epoch["what"] = ("synthetic graph + sampler + 3 mean-SAGE layers in stock PyTorch around TTEmbeddingBag "
-                             "(tools/sage_epoch.py), second epoch")
+                             "(tools/sage_epoch.py), second epoch; eval_*: the drivers' evaluation pass over the embedding "
+                             "layer -- every node, 2^20 ids per call, under no_grad")
         cpu, cpu2048 = None, None
         if world == 1 and not args.no_cpu_baseline:
             from oracle import cpu_einsum

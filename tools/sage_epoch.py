@@ -170,6 +170,25 @@ def run(a, quiet=False):
         stats = {"epoch_s": round(wall, 3), "steps": steps, "ms_per_step": round(wall / steps * 1e3, 3),
                  "frontier_ids_per_step": int(frontier / steps),
                  "split_ms": {k: round(v / steps, 3) for k, v in split.items()}}
+    if a.emb == "tt":
+        # the evaluation pass of the drivers (SAGE.inference, gnn_model.py:220-253): the embedding of EVERY node, batch by batch,
+        # under no_grad -- the class then keeps no plan and records no autograd node
+        with torch.no_grad():
+            eb = 1 << 20
+            offs = torch.arange(eb + 1, device=dev)
+            all_nodes = torch.arange(a.nodes, device=dev)
+            emb(all_nodes[:eb], offs[: min(eb, a.nodes) + 1])   # (sizes the workspace)
+            e0, e1 = ev(), ev()
+            e0.record()
+            for lo in range(0, a.nodes, eb):
+                ids = all_nodes[lo:lo + eb]
+                h = emb(ids, offs[: ids.numel() + 1])
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1)
+        stats["eval_embedding_all_nodes_ms"] = round(ms, 3)
+        stats["eval_lookups_per_s"] = round(a.nodes / (ms * 1e-3), 1)
+        say(f"evaluation: embedding of all {a.nodes} nodes under no_grad in {ms:.2f} ms ({a.nodes / ms / 1e6:.2f} G lookups/s)", flush=True)
     return stats
 
 
