@@ -230,7 +230,8 @@ struct GroupPlan {           // device pointers into the caller's plan buffer / 
   float* etab;               // [nnz][ROW2] dG2 contribution rows, in grouped order
   float* dptab;              // [G][M2*R2] dP of every non-empty group
   float* g2part;             // [tiles][p2][ROW2] per-tile partial dG2
-  float* g0part;             // [G][ROW0] per-group contribution to dG0
+  float* g0part;             // [G][ROW0] per-group contribution to dG0: row i1 * p0 + i0 (the group's number) -- row i0 * p1 + i1 when the
+                             //     chunk kernel that forms the group products wrote them (GroupFuse::parts_by_i0)
   float* g1part;             // [slices][p1][ROW1] per-slice partial dG1
   uint32_t* epi_live;        // [slices][p1] sparse form only: 1 when the slice of that i1 holds an id (its slab exists)
   uint32_t* wrows;           // wide-rank chain: [p1][stride] the rows (i0, a) of every i1 whose group holds an id (wide3_rows_kernel)
