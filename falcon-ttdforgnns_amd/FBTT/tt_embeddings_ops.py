@@ -301,6 +301,44 @@ class TTLookupFunction(torch.autograd.Function):
         return (None,) * (n_fixed - 1) + (d_cache,) + tuple(full)
 
 
+class _TablesLookup(torch.autograd.Function):
+    """``num_tables`` > 1 without a host synchronisation: every table is a *window* of the id list whose bounds the kernels
+    read from ``offsets`` on the device (``ttemb_forward_window`` ...; the reference hands its kernels a per-id ``tableidx``
+    instead, tt_embeddings_cuda.cu:1349-1365).  One node for the whole call: the output is the [num_tables, B, D] tensor the
+    windows write their rows of; the backward runs table by table (fused step, or dense gradients of the [num_tables, p, row]
+    parameters, each table's slice written by its own window)."""
+
+    @staticmethod
+    def forward(ctx, module: "TableBatchedTTEmbeddingBag", B: int, indices: torch.Tensor, offsets: torch.Tensor,
+                *tt_cores: torch.Tensor) -> torch.Tensor:
+        T = module.num_tables
+        out = torch.empty((T, B, module.embedding_dim), dtype=torch.float32, device=indices.device)
+        ctx.module, ctx.B, ctx.indices, ctx.offsets = module, B, indices, offsets
+        if module._before_weights is not None:
+            module._before_weights()   # a data-parallel update of the cores is pending: finish it first
+        for k in range(T):
+            _nat.forward_window(module._shape, _nat.core_ptrs(tt_cores, k), indices, offsets, k * B, B, out, module._ws)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_output: torch.Tensor):
+        m, B, indices, offsets = ctx.module, ctx.B, ctx.indices, ctx.offsets
+        if d_output.dtype != torch.float32 or not d_output.is_contiguous():
+            d_output = d_output.contiguous().float()
+        T = m.num_tables
+        if m.sparse:
+            for k in range(T):
+                state = None if m.optimizer in _SGD_LIKE else _nat.core_ptrs(list(m.optimizer_state), k)
+                _nat.backward_window(m._shape, _nat.core_ptrs(m.tt_cores, k), indices, offsets, k * B, B, d_output, m._ws,
+                                     opt_state=state, lr=float(m.learning_rate), eps=float(m.eps))
+            return (None,) * (4 + len(m.tt_cores))
+        grads = [torch.empty_like(c) for c in m.tt_cores]
+        for k in range(T):
+            _nat.backward_window(m._shape, _nat.core_ptrs(m.tt_cores, k), indices, offsets, k * B, B, d_output, m._ws,
+                                 d_cores=_nat.core_ptrs(grads, k))
+        return (None,) * 4 + tuple(grads)
+
+
 class _SparseLookup(torch.autograd.Function):
     """The common training call -- one table, ``sparse=True``, no live cache -- with as little Python around the two
     native calls as autograd allows: ONE tensor input (the first core, so that the node is recorded; every gradient is
@@ -533,6 +571,7 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         self.warmup = True
         self._dense_grad_out = None
         self._before_weights = None   # set by ttemb_dist.TTDataParallel while an update of the cores is pending
+        self._use_windows = True      # num_tables > 1: per-table windows read on the device (False: always split on the host)
         self._bucket_filled = False   # set by the backward when it wrote the core gradients into the wrapper's bucket
         self._family_cache: dict = {}  # (nnz, B, ...) -> "the backward of this size runs on the grouped kernels" (ttemb_dist)
         self._shape = _nat.make_shape(self.tt_p_shapes, self.tt_q_shapes, self.tt_ranks)
@@ -666,7 +705,13 @@ class TableBatchedTTEmbeddingBag(nn.Module):
             self.update_cache(indices)
         if self.num_tables == 1:
             return self._lookup_one_table(0, B, indices, offsets).unsqueeze(0)
-        bounds = offsets[:: B].tolist()  # host sync: only the multi-table path pays it
+        # every table is a window of the id list, its bounds read from `offsets` on the device (no host synchronisation) -- when the
+        # grouped kernels serve the shape; else the id list is split on the host, one plain lookup per table
+        nnz = indices.numel()
+        if (not self.use_cache and self._use_windows and nnz > 0 and B > 0
+                and _nat.window_workspace_bytes(self._shape, _nat.OP_BACKWARD, nnz, offsets.numel() - 1, B) >= 0):
+            return _TablesLookup.apply(self, B, indices, offsets, *self.tt_cores)
+        bounds = offsets[:: B].tolist()  # host sync: only this fallback of the multi-table path pays it
         outs = []
         for k in range(self.num_tables):
             lo, hi = int(bounds[k]), int(bounds[k + 1])

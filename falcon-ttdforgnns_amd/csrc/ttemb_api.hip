@@ -1213,6 +1213,116 @@ int ttemb_backward_adagrad(const ttemb_shape_t* shape, float* const* cores, floa
                         workspace, workspace_bytes, plan, plan_bytes, stream);
 }
 
+// ---- a window of a longer id list: one table of a table-batched call (include/ttemb.h) ----
+int64_t ttemb_window_workspace_bytes(const ttemb_shape_t* shape, int32_t op, int64_t nnz, int64_t bags_total, int64_t B) {
+  if (nnz < 0 || B < 0 || bags_total < B) return fail(TTEMB_E_BADARG, "negative size, or more bags in the window than in the call");
+  if (op != TTEMB_OP_FORWARD && op != TTEMB_OP_BACKWARD) return fail(TTEMB_E_BADARG, "a window is looked up (TTEMB_OP_FORWARD) or differentiated (TTEMB_OP_BACKWARD)");
+  DevShape ds;
+  int rc = make_dev_shape(shape, &ds);
+  if (rc) return rc;
+  if (nnz == 0 || B == 0) return kFast3HeaderBytes;
+  if (current_path() == TTEMB_PATH_GENERIC || current_path() == TTEMB_PATH_PER_BAG || !fast3_window_fits(ds, nnz, bags_total, B))
+    return fail(TTEMB_E_UNSUPPORTED, "the grouped kernels do not cover this window (shape, size or forced path)");
+  return kFast3HeaderBytes + fast3_window_workspace_bytes(ds, op == TTEMB_OP_BACKWARD, nnz);
+}
+
+static int window_args(const ttemb_shape_t* shape, const float* const* cores, const int64_t* indices, const int64_t* offsets,
+                       int64_t nnz, int64_t bags_total, int64_t bag0, int64_t B, void** workspace, int64_t* workspace_bytes,
+                       DevShape* ds, CorePtrs* cp, void** header) {
+  int rc = pending_device_fault();
+  if (rc) return rc;
+  rc = make_dev_shape(shape, ds);
+  if (rc) return rc;
+  rc = check_lookup_args(cores, indices, nnz, B);
+  if (rc) return rc;
+  if (offsets == nullptr) return fail(TTEMB_E_BADARG, "a window needs the bag boundaries (offsets)");
+  if (bag0 < 0 || B < 0 || bag0 + B > bags_total) return fail(TTEMB_E_BADARG, "the window [%lld, %lld) does not lie inside the call's %lld bags",
+                                                                (long long)bag0, (long long)(bag0 + B), (long long)bags_total);
+  if (current_path() == TTEMB_PATH_GENERIC || current_path() == TTEMB_PATH_PER_BAG)
+    return fail(TTEMB_E_UNSUPPORTED, "a window is served by the grouped kernels (path forced elsewhere)");
+  for (int t = 0; t < TTEMB_MAX_CORES; ++t) cp->c[t] = t < ds->T ? cores[t] : nullptr;
+  if (*workspace == nullptr || *workspace_bytes < kFast3HeaderBytes) return fail(TTEMB_E_WORKSPACE, "a window call needs ttemb_window_workspace_bytes() bytes");
+  *header = *workspace;
+  *workspace = reinterpret_cast<char*>(*workspace) + kFast3HeaderBytes;
+  *workspace_bytes -= kFast3HeaderBytes;
+  return TTEMB_OK;
+}
+
+int ttemb_forward_window(const ttemb_shape_t* shape, const float* const* cores, const int64_t* indices, const int64_t* offsets,
+                         int64_t nnz, int64_t bags_total, int64_t bag0, int64_t B, float* output, void* workspace,
+                         int64_t workspace_bytes, void* stream) {
+  ApiRange api_range("ttemb_forward_window");
+  DevShape ds;
+  CorePtrs cp;
+  void* header = nullptr;
+  int rc = window_args(shape, cores, indices, offsets, nnz, bags_total, bag0, B, &workspace, &workspace_bytes, &ds, &cp, &header);
+  if (rc || B == 0) return rc;
+  if (output == nullptr) return fail(TTEMB_E_BADARG, "output is null");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (nnz == 0) return launch_zero(output + bag0 * ds.D, (size_t)B * ds.D * 4, st, "zero the window's rows");
+  return launch_forward_window_fast3(ds, cp, indices, offsets, nnz, bags_total, bag0, B, output, workspace, workspace_bytes, st, header);
+}
+
+static int backward_window(const ttemb_shape_t* shape, float* const* cores, float* const* opt_state, float* const* d_cores,
+                           const int64_t* indices, const int64_t* offsets, int64_t nnz, int64_t bags_total, int64_t bag0, int64_t B,
+                           const float* d_output, float lr, float eps, void* workspace, int64_t workspace_bytes, void* stream) {
+  DevShape ds;
+  CorePtrs cp;
+  void* header = nullptr;
+  int rc = window_args(shape, cores, indices, offsets, nnz, bags_total, bag0, B, &workspace, &workspace_bytes, &ds, &cp, &header);
+  if (rc) return rc;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  CorePtrsMut dp;
+  for (int t = 0; t < TTEMB_MAX_CORES; ++t) dp.c[t] = (d_cores != nullptr && t < ds.T) ? d_cores[t] : nullptr;
+  if (d_cores != nullptr) {   // dense: every gradient is written whole
+    for (int t = 0; t < ds.T; ++t)
+      if (d_cores[t] == nullptr) return fail(TTEMB_E_BADARG, "d_cores[%d] is null", t);
+    if (nnz == 0 || B == 0) return launch_zero_cores(ds, dp, st);
+  } else if (nnz == 0 || B == 0) {
+    return TTEMB_OK;   // zero gradient: SGD is a no-op, Adagrad adds 0 and divides 0
+  }
+  if (d_output == nullptr) return fail(TTEMB_E_BADARG, "d_output is null");
+  FusedUpdate upd;
+  memset(&upd, 0, sizeof(upd));
+  if (d_cores == nullptr) {
+    for (int t = 0; t < ds.T; ++t) {
+      upd.w[t] = cores[t];
+      upd.st[t] = opt_state ? opt_state[t] : nullptr;
+      if (cores[t] == nullptr || (opt_state && opt_state[t] == nullptr)) return fail(TTEMB_E_BADARG, "null core / optimizer state");
+    }
+    upd.lr = lr;
+    upd.eps = eps;
+  }
+  return launch_backward_window_fast3(ds, cp, indices, offsets, nnz, bags_total, bag0, B, d_output, dp, workspace, workspace_bytes, st,
+                                      d_cores == nullptr ? &upd : nullptr, header);
+}
+
+int ttemb_backward_dense_window(const ttemb_shape_t* shape, const float* const* cores, const int64_t* indices, const int64_t* offsets,
+                                int64_t nnz, int64_t bags_total, int64_t bag0, int64_t B, const float* d_output, float* const* d_cores,
+                                void* workspace, int64_t workspace_bytes, void* stream) {
+  ApiRange api_range("ttemb_backward_dense_window");
+  if (d_cores == nullptr) return fail(TTEMB_E_BADARG, "d_cores is null");
+  return backward_window(shape, const_cast<float* const*>(cores), nullptr, d_cores, indices, offsets, nnz, bags_total, bag0, B, d_output, 0.f, 0.f,
+                         workspace, workspace_bytes, stream);
+}
+
+int ttemb_backward_sgd_window(const ttemb_shape_t* shape, float* const* cores, const int64_t* indices, const int64_t* offsets,
+                              int64_t nnz, int64_t bags_total, int64_t bag0, int64_t B, const float* d_output, float lr,
+                              void* workspace, int64_t workspace_bytes, void* stream) {
+  ApiRange api_range("ttemb_backward_sgd_window");
+  return backward_window(shape, cores, nullptr, nullptr, indices, offsets, nnz, bags_total, bag0, B, d_output, lr, 0.f, workspace,
+                         workspace_bytes, stream);
+}
+
+int ttemb_backward_adagrad_window(const ttemb_shape_t* shape, float* const* cores, float* const* opt_state, const int64_t* indices,
+                                  const int64_t* offsets, int64_t nnz, int64_t bags_total, int64_t bag0, int64_t B,
+                                  const float* d_output, float lr, float eps, void* workspace, int64_t workspace_bytes, void* stream) {
+  ApiRange api_range("ttemb_backward_adagrad_window");
+  if (opt_state == nullptr) return fail(TTEMB_E_BADARG, "opt_state is null");
+  return backward_window(shape, cores, opt_state, nullptr, indices, offsets, nnz, bags_total, bag0, B, d_output, lr, eps, workspace,
+                         workspace_bytes, stream);
+}
+
 int ttemb_sgd_step(float* weights, const float* grads, int64_t n, float lr, void* stream) {
   ApiRange api_range("ttemb_sgd_step");
   if (n > 0 && (weights == nullptr || grads == nullptr)) return fail(TTEMB_E_BADARG, "null buffer");

@@ -115,6 +115,17 @@ int launch_backward_fast3(const DevShape& s, const CorePtrs& cores, const int64_
                           int64_t ws_bytes, const void* plan, int64_t plan_bytes, hipStream_t st,
                           const FusedUpdate* update, void* header);
 
+// a window of a longer id list (one table of a table-batched call): bags [bag0, bag0 + B) of `offsets`, bounds read on the device
+bool fast3_window_fits(const DevShape& s, int64_t nnz, int64_t bags_total, int64_t B);
+int64_t fast3_window_workspace_bytes(const DevShape& s, bool bwd, int64_t nnz);
+int launch_forward_window_fast3(const DevShape& s, const CorePtrs& cores, const int64_t* indices, const int64_t* offsets,
+                                int64_t nnz, int64_t bags_total, int64_t bag0, int64_t B, float* output, void* ws, int64_t ws_bytes,
+                                hipStream_t st, void* header);
+int launch_backward_window_fast3(const DevShape& s, const CorePtrs& cores, const int64_t* indices, const int64_t* offsets,
+                                 int64_t nnz, int64_t bags_total, int64_t bag0, int64_t B, const float* d_output,
+                                 const CorePtrsMut& d_cores, void* ws, int64_t ws_bytes, hipStream_t st, const FusedUpdate* update,
+                                 void* header);
+
 // small batches of a 3-core table (ttemb_small3.inc): one wavefront per bag, MFMA per id, no grouping; `offsets` required.
 // The backward ADDS into d_cores (zeroed by the caller) with float atomics.
 bool small3_supported(const DevShape& s);   // (includes the run-time-shape kernels of ttemb_rt3.inc)

@@ -4001,6 +4001,95 @@ int launch_backward_fast3(const DevShape& s, const CorePtrs& cores, const int64_
   return fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
 }
 
+// ---------------------------------------------------------------------------------
+// A WINDOW of a longer id list: the bags [bag0, bag0 + B) of `offsets` and the ids that belong to them -- one table of a
+// table-batched call (the reference passes `tableidx` to its kernels and never learns on the host where a table's ids begin,
+// tt_embeddings_cuda.cu:1349-1365).  The window is a Piece whose bounds are read from `offsets` ON THE DEVICE; the launches
+// are sized by `nnz`, the length of the whole list, and a window that turns out empty costs its launches and nothing else.
+// `output` / `d_output` are the [bags_total][D] tensors of the whole call.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void window_piece_kernel(const int64_t* __restrict__ offsets, long long bag0, long long B, int D,
+                                                          Piece* __restrict__ out) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  Piece pc;
+  pc.pos0 = (long long)offsets[bag0];
+  pc.count = (long long)offsets[bag0 + B] - pc.pos0;
+  if (pc.count < 0) pc.count = 0;
+  pc.rowbase = bag0;
+  pc.zero0 = bag0;
+  pc.zero1 = bag0 + B;
+  pc.window_bytes = B * (long long)D * 4;
+  *out = pc;
+}
+constexpr int64_t kWindowHeadBytes = 256;   // the Piece, in front of the call's tables
+bool fast3_window_fits(const DevShape& s, int64_t nnz, int64_t bags_total, int64_t B) {
+  return fits_shape(s) && (classify(s) || wide(s)) && nnz > 0 && B > 0 && fits_piece(s, nnz, B) && bags_total < 0x7fffffffll;
+}
+int64_t fast3_window_workspace_bytes(const DevShape& s, bool bwd, int64_t nnz) {
+  return kWindowHeadBytes + carve_workspace(s, nnz, bwd, true, true, nullptr, nullptr) + 256;
+}
+
+int launch_forward_window_fast3(const DevShape& s, const CorePtrs& cores, const int64_t* indices, const int64_t* offsets,
+                                int64_t nnz, int64_t bags_total, int64_t bag0, int64_t B, float* output, void* ws, int64_t ws_bytes,
+                                hipStream_t st, void* header) {
+  if (!fast3_window_fits(s, nnz, bags_total, B)) return fail(TTEMB_E_UNSUPPORTED, "the grouped kernels do not cover this window (shape or size)");
+  if (ws == nullptr || ws_bytes < kWindowHeadBytes) return fail(TTEMB_E_WORKSPACE, "forward needs room for the window");
+  Piece* tab = reinterpret_cast<Piece*>(ws);
+  hipLaunchKernelGGL(window_piece_kernel, dim3(1), dim3(64), 0, st, offsets, (long long)bag0, (long long)B, s.D, tab);
+  int rc = check_hip(hipGetLastError(), "window_piece_kernel");
+  if (rc) return rc;
+  GroupPlan plan;
+  rc = prepare(s, cores, false, indices, nullptr, offsets, nnz, nullptr, bags_total, output, reinterpret_cast<char*>(ws) + kWindowHeadBytes,
+               ws_bytes - kWindowHeadBytes, nullptr, 0, 0, &plan, st, header, tab);
+  if (rc) return rc;
+  rc = fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
+  if (wide(s)) {
+#define TTEMB_X(a, b, c, d, e) if (shape_is(s, a, b, c, d, e)) rc = run_forward_direct<a, b, c, d, e>(s, cores, plan, nnz, B, output, st);
+    TTEMB_WIDE3_SHAPES(TTEMB_X)
+#undef TTEMB_X
+  } else {
+#define TTEMB_X(a, b, c, d, e) if (shape_is(s, a, b, c, d, e)) rc = run_forward<a, b, c, d, e>(s, cores, plan, nnz, B, output, st);
+    TTEMB_FAST3_SHAPES(TTEMB_X)
+#undef TTEMB_X
+  }
+  return rc;
+}
+
+// `update` != null: the optimiser step of THIS table rides in the finalize kernel (a window is a whole table's share of the
+// call: nothing of another call has to be summed first); null: the gradient is written to d_cores
+int launch_backward_window_fast3(const DevShape& s, const CorePtrs& cores, const int64_t* indices, const int64_t* offsets,
+                                 int64_t nnz, int64_t bags_total, int64_t bag0, int64_t B, const float* d_output,
+                                 const CorePtrsMut& d_cores, void* ws, int64_t ws_bytes, hipStream_t st, const FusedUpdate* update,
+                                 void* header) {
+  if (!fast3_window_fits(s, nnz, bags_total, B)) return fail(TTEMB_E_UNSUPPORTED, "the grouped kernels do not cover this window (shape or size)");
+  if (ws == nullptr || ws_bytes < kWindowHeadBytes) return fail(TTEMB_E_WORKSPACE, "backward needs room for the window");
+  FusedUpdate upd;
+  memset(&upd, 0, sizeof(upd));
+  if (update != nullptr) upd = *update;
+  upd.poison_out = header != nullptr ? reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(header) + kHeaderPoisonOffset) : nullptr;
+  upd.sticky = 0;
+  if (update == nullptr) upd.eps = 0.f;   // (dense mode: the gradient is written, not added to an earlier piece's)
+  Piece* tab = reinterpret_cast<Piece*>(ws);
+  hipLaunchKernelGGL(window_piece_kernel, dim3(1), dim3(64), 0, st, offsets, (long long)bag0, (long long)B, s.D, tab);
+  int rc = check_hip(hipGetLastError(), "window_piece_kernel");
+  if (rc) return rc;
+  GroupPlan plan;
+  rc = prepare(s, cores, true, indices, nullptr, offsets, nnz, nullptr, bags_total, nullptr, reinterpret_cast<char*>(ws) + kWindowHeadBytes,
+               ws_bytes - kWindowHeadBytes, nullptr, 0, 0, &plan, st, header, tab);
+  if (rc) return rc;
+  rc = fail(TTEMB_E_UNSUPPORTED, "fast3 path does not cover this shape");
+  if (wide(s)) {
+#define TTEMB_X(a, b, c, d, e) if (shape_is(s, a, b, c, d, e)) rc = run_backward_wide<a, b, c, d, e>(s, cores, plan, nnz, B, d_output, d_cores, upd, st);
+    TTEMB_WIDE3_SHAPES(TTEMB_X)
+#undef TTEMB_X
+  } else {
+#define TTEMB_X(a, b, c, d, e) if (shape_is(s, a, b, c, d, e)) rc = run_backward<a, b, c, d, e>(s, cores, plan, nnz, B, d_output, d_cores, upd, st);
+    TTEMB_FAST3_SHAPES(TTEMB_X)
+#undef TTEMB_X
+  }
+  return rc;
+}
+
 #include "ttemb_small3.inc"
 
 }  // namespace ttemb

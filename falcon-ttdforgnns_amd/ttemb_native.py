@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TTEMB_LIB") or os.path.join(_HERE, "lib", "libttemb_hip.so")
 
 MAX_CORES = 4
-ABI_VERSION = 3
+ABI_VERSION = 4
 OP_FORWARD, OP_BACKWARD, OP_PREPROCESS, OP_CACHE_POPULATE = 0, 1, 2, 3
 PATH_AUTO, PATH_GENERIC, PATH_FAST3, PATH_PER_BAG = 0, 1, 2, 3
 
@@ -30,6 +30,7 @@ EXPORTED_SYMBOLS = (
     "ttemb_abi_version", "ttemb_last_error", "ttemb_workspace_bytes", "ttemb_plan_bytes", "ttemb_set_path",
     "ttemb_profile_enable", "ttemb_profile_read", "ttemb_kernel_family", "ttemb_set_piece_limits", "ttemb_set_wide_slab_min_ids", "ttemb_init", "ttemb_status", "ttemb_set_spin_limit",
     "ttemb_forward", "ttemb_forward_group", "ttemb_forward_lookup", "ttemb_backward_dense", "ttemb_backward_sgd", "ttemb_backward_adagrad",
+    "ttemb_window_workspace_bytes", "ttemb_forward_window", "ttemb_backward_dense_window", "ttemb_backward_sgd_window", "ttemb_backward_adagrad_window",
     "ttemb_sgd_step", "ttemb_sgd_step_guarded", "ttemb_adagrad_step", "ttemb_cache_update", "ttemb_cache_update_one_sweep", "ttemb_cache_populate",
     "ttemb_preprocess", "ttemb_preprocess_update", "ttemb_cache_forward", "ttemb_cache_backward_sgd",
     "ttemb_cache_backward_dense", "ttemb_cache_backward_rowwise_adagrad",
@@ -91,6 +92,12 @@ def _load() -> ctypes.CDLL:
     lib.ttemb_backward_dense.argtypes = [shp, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, i64, vp, i64, vp]
     lib.ttemb_backward_sgd.argtypes = [shp, vp, vp, vp, vp, i64, vp, i64, vp, f32, vp, i64, vp, i64, vp]
     lib.ttemb_backward_adagrad.argtypes = [shp, vp, vp, vp, vp, vp, i64, vp, i64, vp, f32, f32, vp, i64, vp, i64, vp]
+    lib.ttemb_window_workspace_bytes.restype = i64
+    lib.ttemb_window_workspace_bytes.argtypes = [shp, i32, i64, i64, i64]
+    lib.ttemb_forward_window.argtypes = [shp, vp, vp, vp, i64, i64, i64, i64, vp, vp, i64, vp]
+    lib.ttemb_backward_dense_window.argtypes = [shp, vp, vp, vp, i64, i64, i64, i64, vp, vp, vp, i64, vp]
+    lib.ttemb_backward_sgd_window.argtypes = [shp, vp, vp, vp, i64, i64, i64, i64, vp, f32, vp, i64, vp]
+    lib.ttemb_backward_adagrad_window.argtypes = [shp, vp, vp, vp, vp, i64, i64, i64, i64, vp, f32, f32, vp, i64, vp]
     lib.ttemb_sgd_step.argtypes = [vp, vp, i64, f32, vp]
     lib.ttemb_sgd_step_guarded.argtypes = [vp, vp, i64, f32, vp, vp]
     lib.ttemb_adagrad_step.argtypes = [vp, vp, vp, i64, f32, f32, vp]
@@ -105,7 +112,7 @@ def _load() -> ctypes.CDLL:
     lib.ttemb_cache_backward_rowwise_adagrad.argtypes = [vp, vp, i64, vp, i64, vp, i64, f32, f32, vp, vp, vp]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
-        if name not in ("ttemb_last_error", "ttemb_workspace_bytes", "ttemb_plan_bytes"):
+        if name not in ("ttemb_last_error", "ttemb_workspace_bytes", "ttemb_plan_bytes", "ttemb_window_workspace_bytes"):
             fn.restype = ctypes.c_int
     return lib
 
@@ -387,6 +394,52 @@ def adagrad_step(weights, state, grads, lr: float, eps: float) -> None:
     with _on_device(weights.device):
         _check(LIB.ttemb_adagrad_step(_ptr(weights), _ptr(state), _ptr(grads), weights.numel(), lr, eps,
                                       _stream(weights)))
+
+
+E_UNSUPPORTED = -3
+
+
+def window_workspace_bytes(shape: Shape, op: int, nnz: int, bags_total: int, B: int) -> int:
+    """Bytes a window call needs, or -1 when the grouped kernels do not serve such a window (the caller then splits the id
+    list on the host: one plain call per table)."""
+    key = ("win", _shape_key(shape), op, nnz, bags_total, B, path_epoch)
+    n = _size_cache.get(key)
+    if n is None:
+        n = int(LIB.ttemb_window_workspace_bytes(ctypes.byref(shape), op, nnz, bags_total, B))
+        if n < 0 and n != E_UNSUPPORTED:
+            _check(n)
+        n = _size_cache[key] = (-1 if n < 0 else n)
+    return n
+
+
+def forward_window(shape: Shape, cores: Sequence[torch.Tensor], indices: torch.Tensor, offsets: torch.Tensor, bag0: int, B: int,
+                   output: torch.Tensor, ws: Workspace) -> None:
+    """One table of a table-batched call: the bags [bag0, bag0 + B) of ``offsets`` (the whole call's) and their ids;
+    ``output`` is the [bags_total, D] tensor of the whole call.  No host synchronisation."""
+    nnz, bags = indices.numel(), offsets.numel() - 1
+    dev = output.device
+    w = ws.get(window_workspace_bytes(shape, OP_FORWARD, nnz, bags, B), dev)
+    with _on_device(dev):
+        _check(LIB.ttemb_forward_window(ctypes.byref(shape), _ptr_array(cores), _ptr(indices), _ptr(offsets), nnz, bags, bag0, B,
+                                        _ptr(output), _ptr(w), w.numel(), _stream(output)))
+
+
+def backward_window(shape: Shape, cores: Sequence[torch.Tensor], indices: torch.Tensor, offsets: torch.Tensor, bag0: int, B: int,
+                    d_output: torch.Tensor, ws: Workspace, d_cores: Optional[Sequence[torch.Tensor]] = None,
+                    opt_state: Optional[Sequence[torch.Tensor]] = None, lr: float = 0.0, eps: float = 0.0) -> None:
+    """``d_cores``: dense gradients of the window's table; else the fused step (Adagrad when ``opt_state`` is given)."""
+    nnz, bags = indices.numel(), offsets.numel() - 1
+    dev = d_output.device
+    w = ws.get(window_workspace_bytes(shape, OP_BACKWARD, nnz, bags, B), dev)
+    head = (ctypes.byref(shape), _ptr_array(cores))
+    ids = (_ptr(indices), _ptr(offsets), nnz, bags, bag0, B, _ptr(d_output))
+    with _on_device(dev):
+        if d_cores is not None:
+            _check(LIB.ttemb_backward_dense_window(*head, *ids, _ptr_array(d_cores), _ptr(w), w.numel(), _stream(d_output)))
+        elif opt_state is None:
+            _check(LIB.ttemb_backward_sgd_window(*head, *ids, lr, _ptr(w), w.numel(), _stream(d_output)))
+        else:
+            _check(LIB.ttemb_backward_adagrad_window(*head, _ptr_array(opt_state), *ids, lr, eps, _ptr(w), w.numel(), _stream(d_output)))
 
 
 def cache_update(indices: torch.Tensor, hashtbl: torch.Tensor, cache_freq: torch.Tensor, one_sweep: bool = False) -> None:

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TTEMB_ABI_VERSION 3   /* 3: + ttemb_init / ttemb_status / ttemb_set_spin_limit, TTEMB_FAMILY_PREFIX_IN_CHAIN, plan of G + 3 group words */
+#define TTEMB_ABI_VERSION 4   /* 4: + the *_window calls (one table of a table-batched call); 3: + ttemb_init / ttemb_status / ttemb_set_spin_limit, TTEMB_FAMILY_PREFIX_IN_CHAIN, plan of G + 3 group words */
 #define TTEMB_MAX_CORES 4
 
 enum {
@@ -262,6 +262,37 @@ int ttemb_backward_adagrad(const ttemb_shape_t* shape, float* const* cores,
                            float lr, float eps,
                            void* workspace, int64_t workspace_bytes, const void* plan, int64_t plan_bytes,
                            void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * A WINDOW of a longer id list: one table of a table-batched call.
+ * Replaces, for `num_tables` > 1: the `tableidx` the reference's kernels derive per id (compute_rowidx_kernel,
+ * tt_embeddings_cuda.cu:1349-1365) and index their per-table core pointers with (tt_embeddings_cuda.cu:443-609,
+ * called by TableBatchedTTEmbeddingBag.forward, tt_embeddings_ops.py:862-916) -- the host never learns where a table's ids
+ * begin.  Here a table is a call of its own on a window: the bags [bag0, bag0 + B) of `offsets` (int64[bags_total + 1], the
+ * whole call's) and the ids that belong to them; where the window begins and ends in `indices` is read from `offsets` ON THE
+ * DEVICE -- no host synchronisation.  `nnz` = length of the WHOLE id list (the launches are sized by it; a window that turns
+ * out empty costs its launches and nothing else); `output` / `d_output` = the [bags_total][D] tensor of the whole call (the
+ * window's rows are bag0 .. bag0 + B - 1; no other row is touched).  `cores` / `d_cores` / `opt_state` are the window's own
+ * table.  Served by the grouped kernels, whatever the size: TTEMB_E_UNSUPPORTED (from the size query already) for a shape they
+ * do not cover (2- / 4-core tables, ranks off the list) or a window past their limits -- the caller then splits the id list on
+ * the host, one plain call per table.  Workspace: ttemb_window_workspace_bytes(shape, TTEMB_OP_FORWARD | TTEMB_OP_BACKWARD, ...);
+ * one workspace serves every window and every other op.  A window keeps no plan: its backward groups the window's ids again.
+ * ------------------------------------------------------------------------------- */
+int64_t ttemb_window_workspace_bytes(const ttemb_shape_t* shape, int32_t op, int64_t nnz, int64_t bags_total, int64_t B);
+int ttemb_forward_window(const ttemb_shape_t* shape, const float* const* cores, const int64_t* indices,
+                         const int64_t* offsets, int64_t nnz, int64_t bags_total, int64_t bag0, int64_t B,
+                         float* output, void* workspace, int64_t workspace_bytes, void* stream);
+int ttemb_backward_dense_window(const ttemb_shape_t* shape, const float* const* cores, const int64_t* indices,
+                                const int64_t* offsets, int64_t nnz, int64_t bags_total, int64_t bag0, int64_t B,
+                                const float* d_output, float* const* d_cores, void* workspace,
+                                int64_t workspace_bytes, void* stream);
+int ttemb_backward_sgd_window(const ttemb_shape_t* shape, float* const* cores, const int64_t* indices,
+                              const int64_t* offsets, int64_t nnz, int64_t bags_total, int64_t bag0, int64_t B,
+                              const float* d_output, float lr, void* workspace, int64_t workspace_bytes, void* stream);
+int ttemb_backward_adagrad_window(const ttemb_shape_t* shape, float* const* cores, float* const* opt_state,
+                                  const int64_t* indices, const int64_t* offsets, int64_t nnz, int64_t bags_total,
+                                  int64_t bag0, int64_t B, const float* d_output, float lr, float eps,
+                                  void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Flat optimiser epilogues over n floats (used after the data-parallel all-reduce of
  * the flattened core gradients; same arithmetic as tt_embeddings_cuda.cu:381-419). */

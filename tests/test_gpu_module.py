@@ -232,27 +232,45 @@ def test_sparse_mode_updates_in_backward(ops, optimizer):
             assert torch.equal(c.data[ref.grad == 0], b[ref.grad == 0])
 
 
-def test_table_batched(ops):
+@pytest.mark.parametrize("windows", [True, False])
+@pytest.mark.parametrize("sparse", [False, True])
+def test_table_batched(ops, windows, sparse):
+    """``num_tables`` = 3 in one call (reference: TableBatchedTTEmbeddingBag, tt_embeddings_ops.py:446-916).  windows: every
+    table is a window of the id list whose bounds the kernels read from ``offsets`` on the device -- the call must not
+    synchronise the host (checked with torch's sync-debug mode); not windows: the id list is split on the host, one plain lookup
+    per table.  Dense gradients against autograd through the full weight; sparse: the fused SGD step against the same."""
     torch.manual_seed(4)
     p, q, r = [10, 12, 9], [4, 4, 8], [8, 8]
-    n, D, Tn, B = int(np.prod(p)), int(np.prod(q)), 3, 20
-    emb = ops.TableBatchedTTEmbeddingBag(Tn, n, D, r, p, q, sparse=False, use_cache=False, weight_dist="normal")
+    n, D, Tn, B, lr = int(np.prod(p)), int(np.prod(q)), 3, 20, 0.05
+    emb = ops.TableBatchedTTEmbeddingBag(Tn, n, D, r, p, q, sparse=sparse, use_cache=False, weight_dist="normal", learning_rate=lr)
+    emb._use_windows = windows
     for c in emb.tt_cores:
         c.data.mul_(50.0)
+    start = [c.detach().clone() for c in emb.tt_cores]
     idx, offs = ragged(np.random.default_rng(3), Tn * B, n, 3.0)
-    out = emb(idx, offs)
-    assert tuple(out.shape) == (Tn, B, D)
-    d_out = torch.rand_like(out)
-    out.backward(d_out)
+    d_out = torch.rand(Tn, B, D, device="cuda")
+    emb(idx, offs)   # (first call: workspace allocation synchronises nothing, but keep it out of the checked region)
+    torch.cuda.synchronize()
+    if windows:
+        torch.cuda.set_sync_debug_mode("error")
+    try:
+        out = emb(idx, offs)
+        assert tuple(out.shape) == (Tn, B, D)
+        out.backward(d_out)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
     bounds = offs[::B].tolist()
     for k in range(Tn):
-        clones = [c.detach()[k:k + 1].clone().requires_grad_(True) for c in emb.tt_cores]
+        clones = [c[k:k + 1].clone().requires_grad_(True) for c in start]
         full = ops.tt_matrix_to_full(p, q, r, clones, [1, 0, 2, 3])
         o = reference_bag(full, idx[bounds[k]:bounds[k + 1]], offs[k * B:(k + 1) * B + 1] - bounds[k])
         torch.testing.assert_close(out[k], o, rtol=1e-4, atol=1e-5)
         o.backward(d_out[k])
-        for a, b in zip(emb.tt_cores, clones):
-            torch.testing.assert_close(a.grad[k:k + 1], b.grad, rtol=1e-3, atol=1e-4 * float(b.grad.abs().max()))
+        for a, b, c0 in zip(emb.tt_cores, clones, start):
+            if sparse:
+                torch.testing.assert_close(a.data[k:k + 1], c0[k:k + 1] - lr * b.grad, rtol=1e-3, atol=1e-4 * float(b.grad.abs().max()))
+            else:
+                torch.testing.assert_close(a.grad[k:k + 1], b.grad, rtol=1e-3, atol=1e-4 * float(b.grad.abs().max()))
 
 
 def test_extension_shim_signatures(ops, orc):

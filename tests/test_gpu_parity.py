@@ -1303,3 +1303,92 @@ def test_backward_on_tables_with_many_i1(nat, orc, q, r, p, nnz_target):
     torch.cuda.synchronize()
     for got, w0, g in zip(c2, cores, want_g):
         np.testing.assert_allclose(got.cpu().numpy(), w0 - lr * g, rtol=0, atol=1e-5 + 2e-4 * float(np.abs(lr * g).max()))
+
+
+# ---------------------------------------------------------------------------------------
+# windows of a longer id list: one table of a table-batched call (ttemb_*_window)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("p,q,R", [
+    ([10, 12, 9], [4, 4, 8], [1, 8, 8, 1]),
+    ([20, 25, 30], [4, 5, 5], [1, 16, 16, 1]),
+    ([12, 14, 40], [8, 4, 4], [1, 32, 32, 1]),
+    ([9, 11, 13], [5, 5, 4], [1, 64, 64, 1]),      # the wide-rank chain
+])
+@pytest.mark.parametrize("mode", ["dense", "sgd", "adagrad"])
+def test_window_calls_serve_the_tables_of_a_table_batched_call(nat, orc, p, q, R, mode):
+    """Four tables looked up in one id list (`offsets` of 4 B + 1 entries, as TableBatchedTTEmbeddingBag gets them): every table
+    is a window call that finds its ids through `offsets` on the device.  Ragged bags, empty bags, a table WITHOUT ids, one
+    with a single id; rows of the other tables are not touched.  Forward, then dense gradients / fused SGD / fused Adagrad per
+    table, against the oracle run on the host-side split."""
+    nat.set_path(nat.PATH_AUTO)
+    rng = np.random.default_rng(p[0] + R[1])
+    n_emb, D, T, B = int(np.prod(p)), int(np.prod(q)), 4, 37
+    lens = rng.integers(0, 5, size=T * B)
+    lens[2 * B:3 * B] = 0                      # table 2 holds no id at all
+    lens[3 * B:] = 0
+    lens[3 * B + 5] = 1                        # table 3: one id
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    nnz = int(offsets[-1])
+    idx = rng.integers(0, n_emb, size=nnz).astype(np.int64)
+    idx[:40] = idx[40:80]                      # repeated ids
+    cores = [[(rng.standard_normal((p[t], R[t] * q[t] * R[t + 1])) * 0.4).astype(np.float32) for t in range(3)] for _ in range(T)]
+    shape = nat.make_shape(p, q, R)
+    assert nat.window_workspace_bytes(shape, nat.OP_BACKWARD, nnz, T * B, B) > 0
+    ws = nat.Workspace()
+    d_idx, d_offs = dev(idx, torch.int64), dev(offsets, torch.int64)
+    d_cores = [[dev(c) for c in tab] for tab in cores]
+    out = torch.full((T * B, D), 7.0, device="cuda")
+    for k in (1, 3):                           # two of the four first: the others' rows keep their sentinel
+        nat.forward_window(shape, d_cores[k], d_idx, d_offs, k * B, B, out, ws)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert (got[:B] == 7.0).all() and (got[2 * B:3 * B] == 7.0).all()
+    for k in (0, 2):
+        nat.forward_window(shape, d_cores[k], d_idx, d_offs, k * B, B, out, ws)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    split = lambda k: (idx[offsets[k * B]:offsets[(k + 1) * B]], offsets[k * B:(k + 1) * B + 1] - offsets[k * B])
+    for k in range(T):
+        ids_k, offs_k = split(k)
+        want = orc.tt_forward(ids_k, offs_k, cores[k], p, q, R)
+        np.testing.assert_allclose(got[k * B:(k + 1) * B], want, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(want).max())))
+    d_out = (rng.standard_normal((T * B, D)) * 0.5).astype(np.float32)
+    d_dout = dev(d_out)
+    lr, eps = 0.05, 1e-3
+    for k in range(T):
+        ids_k, offs_k = split(k)
+        grads = orc.tt_dense_backward(ids_k, offs_k, d_out[k * B:(k + 1) * B], cores[k], p, q, R)
+        if mode == "dense":
+            g = [torch.full_like(c, float("nan")) for c in d_cores[k]]
+            nat.backward_window(shape, d_cores[k], d_idx, d_offs, k * B, B, d_dout, ws, d_cores=g)
+            torch.cuda.synchronize()
+            assert_grads_close([x.cpu().numpy() for x in g], grads, rel=2e-4)
+        elif mode == "sgd":
+            w = [c.clone() for c in d_cores[k]]
+            nat.backward_window(shape, w, d_idx, d_offs, k * B, B, d_dout, ws, lr=lr)
+            torch.cuda.synchronize()
+            assert_grads_close([x.cpu().numpy() for x in w], orc.sgd_step(cores[k], grads, lr), rel=2e-4)
+        else:
+            w = [c.clone() for c in d_cores[k]]
+            st0 = [(rng.random(c.shape) * 0.1).astype(np.float32) for c in cores[k]]
+            st = [dev(s) for s in st0]
+            nat.backward_window(shape, w, d_idx, d_offs, k * B, B, d_dout, ws, opt_state=st, lr=lr, eps=eps)
+            torch.cuda.synchronize()
+            want_w, want_s = orc.adagrad_step(cores[k], st0, grads, lr, eps)
+            assert_grads_close([x.cpu().numpy() for x in st], want_s, rel=2e-4)
+            assert_grads_close([x.cpu().numpy() for x in w], want_w, rel=5e-4)
+
+
+def test_window_calls_refuse_what_the_grouped_kernels_do_not_cover(nat):
+    """A shape off the grouped kernels' list, a forced generic path: the size query answers -1 (the binding's spelling of
+    TTEMB_E_UNSUPPORTED) and the caller splits the id list on the host instead."""
+    nat.set_path(nat.PATH_AUTO)
+    assert nat.window_workspace_bytes(nat.make_shape([7, 9, 11, 5], [2, 2, 5, 4], [5, 6, 3]), nat.OP_FORWARD, 1000, 80, 20) == -1
+    assert nat.window_workspace_bytes(nat.make_shape([10, 12, 9], [4, 4, 8], [12, 12]), nat.OP_FORWARD, 1000, 80, 20) == -1
+    ok = nat.make_shape([10, 12, 9], [4, 4, 8], [8, 8])
+    assert nat.window_workspace_bytes(ok, nat.OP_FORWARD, 1000, 80, 20) > 0
+    nat.set_path(nat.PATH_GENERIC)
+    try:
+        assert nat.window_workspace_bytes(ok, nat.OP_FORWARD, 1000, 80, 20) == -1
+    finally:
+        nat.set_path(nat.PATH_AUTO)

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(nat.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ttemb_abi_version() == 3
+    assert lib.ttemb_abi_version() == 4
 
 
 def test_no_shipped_kernel_spills():
@@ -126,6 +126,21 @@ def test_size_queries_over_every_shape_and_size():
                         assert nat.workspace_bytes(shape, op, nnz, B) >= 0
                     assert nat.plan_bytes(shape, nnz) >= 0
                     assert nat.kernel_family(shape, nnz, B, True) >= 0 and nat.kernel_family(shape, nnz, B, False) >= 0
+
+
+def test_window_size_query_is_host_arithmetic():
+    """ttemb_window_workspace_bytes: what a window call (one table of a table-batched call) needs, -1 through the binding when
+    the grouped kernels do not serve the window -- the caller then splits the id list on the host."""
+    ok = nat.make_shape([10, 12, 9], [4, 4, 8], [8, 8])
+    f = nat.window_workspace_bytes(ok, nat.OP_FORWARD, 1000, 80, 20)
+    b = nat.window_workspace_bytes(ok, nat.OP_BACKWARD, 1000, 80, 20)
+    assert 40960 < f <= b
+    assert nat.window_workspace_bytes(ok, nat.OP_FORWARD, 0, 80, 20) == 40960      # nothing but the header
+    assert nat.window_workspace_bytes(nat.make_shape([125, 140, 140], [5, 5, 4], [256, 256]), nat.OP_BACKWARD, 100000, 3000, 1000) > 0
+    assert nat.window_workspace_bytes(nat.make_shape([7, 9, 11, 5], [2, 2, 5, 4], [5, 6, 3]), nat.OP_FORWARD, 1000, 80, 20) == -1
+    assert nat.window_workspace_bytes(nat.make_shape([10, 12, 9], [4, 4, 8], [12, 12]), nat.OP_FORWARD, 1000, 80, 20) == -1
+    with pytest.raises(RuntimeError):
+        nat.window_workspace_bytes(ok, nat.OP_FORWARD, 1000, 10, 20)                # more bags in the window than in the call
 
 
 def test_kernel_family_reports_the_routes_of_the_grouped_path():
