@@ -107,4 +107,11 @@ class Eff_TTEmbedding(torch.nn.Module):
     def forward(self, indices: torch.Tensor, offsets=None, unique=None, inverse=None) -> torch.Tensor:
         if not indices.is_cuda:
             raise RuntimeError("Eff_TTEmbedding.forward needs tensors on a ROCm device; there is no CPU fallback")
-        return TT_core_function.apply(self, indices.long().contiguous(), *self.tt_cores)
+        indices = indices.long().contiguous()
+        if not torch.is_grad_enabled():   # inference: no autograd node, no plan kept (ttemb_forward with plan == NULL)
+            n = indices.numel()
+            _, offs = self._iota(n, indices.device)
+            out = torch.empty((n, self.embedding_dim), dtype=torch.float32, device=indices.device)
+            _nat.forward(self._shape, _nat.core_views(self.tt_cores), indices, None, offs, n, None, n, out, self._ws, None)
+            return out
+        return TT_core_function.apply(self, indices, *self.tt_cores)

@@ -584,7 +584,10 @@ def test_eff_tt_embedding_api(ops, orc):
     rng = np.random.default_rng(9)
     ids = rng.integers(0, 2449029, size=50000, dtype=np.int64)  # duplicates included, fast path engaged
     ids[:4] = [0, 2449028, 7, 7]
+    with torch.no_grad():   # inference: same rows, no autograd node (and no plan kept)
+        out_inf = emb(torch.tensor(ids).cuda(), None, None, None)
     out = emb(torch.tensor(ids).cuda(), None, None, None)
+    assert out_inf.grad_fn is None and out.grad_fn is not None and torch.equal(out_inf, out.detach())
     R = [1] + r + [1]
     pick = rng.choice(ids.shape[0], size=400, replace=False)
     np.testing.assert_allclose(out.detach().cpu().numpy()[pick], orc.tt_rows(ids[pick], cores, p, q, R), rtol=1e-5,
