@@ -1245,6 +1245,8 @@ __global__ __launch_bounds__(kChainWaves * 64, 2) void fast3_forward_pfuse_kerne
 
   float4 pre_g[NLG];
   float pre_a[C::KS1];
+  uint32_t pre_cnt = 0u;   // ids of "this lane's" group of the batch: the product of a sibling group WITHOUT ids is formed with the tile, not stored
+  const rsrc_t r_cnt = make_rsrc(plan.counts, G * 4u);
 #ifdef TTEMB_PFABL   // (ablation: the row traffic of a chunk -- G2 row loads, staging, row reads and stores, i2 / row words -- only for
                      //  every TTEMB_PFABL-th chunk: what serving 16 ids per trip instead of one group's could save; wrong rows, timing only)
   bool pf_io = true;
@@ -1260,6 +1262,11 @@ __global__ __launch_bounds__(kChainWaves * 64, 2) void fast3_forward_pfuse_kerne
     // the batch's rows of G0 when the chunk opens one (else the loads fall off the buffer: the instruction stream is fixed)
     const uint32_t i0a = gp.i0b + a_grp;
     const uint32_t base = (gp.fresh && a_grp < (uint32_t)GM && i0a < p0) ? i0a * (uint32_t)(C::ROW0 * 4) + a_off : kOobBase;
+#ifndef TTEMB_PSTORE_ALL   // (A/B: the P of every group of a batch stored, with or without ids)
+    pre_cnt = buf_load1u(r_cnt, (gp.fresh && a_grp < (uint32_t)GM && i0a < p0) ? (gp.first_group + a_grp) * 4u : kOobBase);
+#else
+    pre_cnt = 1u;
+#endif
     if constexpr (KPH % 4 == 0) {
 #pragma unroll
       for (int v = 0; v < KPH / 4; ++v) {
@@ -1313,7 +1320,7 @@ __global__ __launch_bounds__(kChainWaves * 64, 2) void fast3_forward_pfuse_kerne
       const bool col = C::N1 % 16 == 0 || n < C::N1;
       const int m = a * Q1 + n / R2, c2 = n % R2;
       if (on && col) *reinterpret_cast<f32x4*>(slot + m * R2 + (c2 ^ PC::swz(m))) = acc[nt];
-      buf_store4_p<(TTEMB_NT & 1) != 0>(r_p, (on && col) ? (uint32_t)((gi * PF + m * R2 + c2) * 4) : kOobBase, make_float4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]));
+      buf_store4_p<(TTEMB_NT & 1) != 0>(r_p, (on && col && pre_cnt != 0u) ? (uint32_t)((gi * PF + m * R2 + c2) * 4) : kOobBase, make_float4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]));
     }
   };
   auto fetch_i2 = [&](const uint4& d) {   // lanes past the chunk's length read 0: G2 row 0 stands in, nothing of theirs is stored
